@@ -1,0 +1,312 @@
+"""torch-CPU restatement of the network the reference builds through Keras (TEST INFRASTRUCTURE).
+
+PARITY UNPINNED at the Keras/TensorFlow boundary (see oracle/__init__.py): this file restates
+  * the stem                       spnet/models.py:315-342
+  * keras.applications.Xception    call site spnet/models.py:357-359 (Keras 2.1.3, not vendored;
+                                   layer list reproduced from the published architecture and checked
+                                   against the reference's logged parameter counts and shapes)
+  * Flatten + Dense('FinalOutput') spnet/models.py:378,388
+  * custom_loss                    spnet/models.py:564-589
+  * add_regularization l2(1e-4)    spnet/models.py:47-71 (10 kernels, run-log line 98)
+  * Adam                           spnet/models.py:494 (Keras form, eps outside bias correction)
+with TensorFlow semantics: NHWC tensors, SAME padding (extra pad bottom/right), BatchNorm eps 1e-3 /
+momentum 0.99 with batch statistics in training, NHWC flatten order.
+
+All tensors at this module's boundary are NHWC; weights are kept in Keras layouts
+(conv HWIO, depthwise [3,3,C], pointwise [Cin,Cout], dense [in,out]).
+"""
+import math
+from collections import OrderedDict
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+BN_EPS = 1e-3
+BN_MOMENTUM = 0.99
+L2 = 1e-4
+LAMBDAS = dict(center=2.0, size=1.0, angle=3.0, noobj=0.3, cls=5.0)
+
+
+# ------------------------------------------------------------------ primitive ops (NHWC in / out)
+def _nchw(x):
+    return x.permute(0, 3, 1, 2)
+
+
+def _nhwc(x):
+    return x.permute(0, 2, 3, 1)
+
+
+def conv2d(x, w_hwio, stride=1, padding="valid"):
+    """Dense conv, TF semantics.  'same' pads total=max((out-1)*s+k-in,0), floor(total/2) before."""
+    kh, kw = w_hwio.shape[0], w_hwio.shape[1]
+    xc = _nchw(x)
+    if padding == "same":
+        H, W = x.shape[1], x.shape[2]
+        oh, ow = -(-H // stride), -(-W // stride)
+        ph = max((oh - 1) * stride + kh - H, 0)
+        pw = max((ow - 1) * stride + kw - W, 0)
+        xc = F.pad(xc, (pw // 2, pw - pw // 2, ph // 2, ph - ph // 2))
+    return _nhwc(F.conv2d(xc, w_hwio.permute(3, 2, 0, 1), stride=stride))
+
+
+def dwconv3x3(x, w_33c):
+    """Depthwise 3x3, stride 1, SAME, no bias (tf.nn.depthwise_conv2d inside SeparableConv2D)."""
+    C = x.shape[3]
+    w = w_33c.permute(2, 0, 1).reshape(C, 1, 3, 3)
+    return _nhwc(F.conv2d(_nchw(x), w, padding=1, groups=C))
+
+
+def pwconv(x, w_io):
+    """Pointwise 1x1 conv == GEMM over the flattened pixels."""
+    return x @ w_io
+
+
+def maxpool3x3s2_same(x):
+    H, W = x.shape[1], x.shape[2]
+    oh, ow = -(-H // 2), -(-W // 2)
+    ph = max((oh - 1) * 2 + 3 - H, 0)
+    pw = max((ow - 1) * 2 + 3 - W, 0)
+    xc = F.pad(_nchw(x), (pw // 2, pw - pw // 2, ph // 2, ph - ph // 2), value=float("-inf"))
+    return _nhwc(F.max_pool2d(xc, 3, 2))
+
+
+def avgpool2(x):
+    return _nhwc(F.avg_pool2d(_nchw(x), 2))
+
+
+def batchnorm(x, gamma, beta, mean, var, training, update=True):
+    """Keras BatchNormalization(axis=-1): training -> batch mean / biased variance for the
+    normalisation; moving stats <- 0.99*moving + 0.01*batch (variance Bessel-corrected, as the TF
+    fused op reports it).  ``mean``/``var`` are updated in place when training and update."""
+    C = x.shape[-1]
+    if training:
+        flat = x.reshape(-1, C)
+        mu = flat.mean(0)
+        v = flat.var(0, unbiased=False)
+        if update:
+            n = flat.shape[0]
+            with torch.no_grad():
+                mean.mul_(BN_MOMENTUM).add_((1 - BN_MOMENTUM) * mu.detach())
+                var.mul_(BN_MOMENTUM).add_((1 - BN_MOMENTUM) * v.detach() * (n / max(n - 1, 1)))
+        return (x - mu) * torch.rsqrt(v + BN_EPS) * gamma + beta
+    return (x - mean) * torch.rsqrt(var + BN_EPS) * gamma + beta
+
+
+# ------------------------------------------------------------------ architecture description
+def xception_layers():
+    """Ordered description of keras.applications.Xception(include_top=False) as (kind, name, ...)."""
+    L = [("conv", "block1_conv1", 3, 32, 2, "valid"), ("bn", "block1_conv1_bn", 32), ("relu",),
+         ("conv", "block1_conv2", 32, 64, 1, "valid"), ("bn", "block1_conv2_bn", 64), ("relu",)]
+    res_id = [4]      # residual convs are auto-named conv2d_4.. after the stem's conv2d_1..3
+
+    def strided_block(b, cin, c1, c2, first_relu):
+        r = res_id[0]
+        res_id[0] += 1
+        blk = [("res_conv", "conv2d_%d" % r, "batch_normalization_%d" % r, cin, c2)]
+        if first_relu:
+            blk.append(("relu",))
+        blk += [("sep", "block%d_sepconv1" % b, cin, c1), ("bn", "block%d_sepconv1_bn" % b, c1), ("relu",),
+                ("sep", "block%d_sepconv2" % b, c1, c2), ("bn", "block%d_sepconv2_bn" % b, c2),
+                ("pool",), ("add_res",)]
+        return blk
+
+    L += strided_block(2, 64, 128, 128, False)
+    L += strided_block(3, 128, 256, 256, True)
+    L += strided_block(4, 256, 728, 728, True)
+    for b in range(5, 13):
+        L.append(("res_id",))
+        for k in (1, 2, 3):
+            L += [("relu",), ("sep", "block%d_sepconv%d" % (b, k), 728, 728), ("bn", "block%d_sepconv%d_bn" % (b, k), 728)]
+        L.append(("add_res",))
+    L += strided_block(13, 728, 728, 1024, True)
+    L += [("sep", "block14_sepconv1", 1024, 1536), ("bn", "block14_sepconv1_bn", 1536), ("relu",),
+          ("sep", "block14_sepconv2", 1536, 2048), ("bn", "block14_sepconv2_bn", 2048), ("relu",)]
+    return L
+
+
+def backbone_out_hw(H, W):
+    h, w = H // 2, W // 2                      # stem avgpool
+    h, w = (h - 3) // 2 + 1, (w - 3) // 2 + 1  # block1_conv1 3x3/s2 valid
+    h, w = h - 2, w - 2                        # block1_conv2 3x3 valid
+    for _ in range(4):                         # blocks 2,3,4,13: /2 SAME
+        h, w = -(-h // 2), -(-w // 2)
+    return h, w
+
+
+def _glorot(shape, fan_in, fan_out, gen, dtype):
+    lim = math.sqrt(6.0 / (fan_in + fan_out))
+    return ((torch.rand(shape, generator=gen, dtype=torch.float64) * 2 - 1) * lim).to(dtype)
+
+
+def init_params(H, W, n_out=576, seed=0, dtype=torch.float32):
+    """Keras default initialisers: glorot_uniform kernels, zero bias, BN gamma 1 / beta 0 /
+    moving_mean 0 / moving_variance 1.  Returns OrderedDict name -> tensor (Keras weight names)."""
+    g = torch.Generator().manual_seed(seed)
+    P = OrderedDict()
+
+    def bn(name, c):
+        P[name + "/gamma"] = torch.ones(c, dtype=dtype)
+        P[name + "/beta"] = torch.zeros(c, dtype=dtype)
+        P[name + "/moving_mean"] = torch.zeros(c, dtype=dtype)
+        P[name + "/moving_variance"] = torch.ones(c, dtype=dtype)
+
+    def conv(name, k, cin, cout):
+        P[name + "/kernel"] = _glorot((k, k, cin, cout), cin * k * k, cout * k * k, g, dtype)
+
+    conv("conv2d_1", 3, 1, 3)
+    bn("batch_normalization_1", 3)
+    conv("conv2d_2", 3, 3, 3)
+    bn("batch_normalization_2", 3)
+    conv("conv2d_3", 3, 3, 3)
+    bn("batch_normalization_3", 3)
+    for lay in xception_layers():
+        kind = lay[0]
+        if kind == "conv":
+            conv(lay[1], 3, lay[2], lay[3])
+        elif kind == "bn":
+            bn(lay[1], lay[2])
+        elif kind == "res_conv":
+            conv(lay[1], 1, lay[3], lay[4])
+            bn(lay[2], lay[4])
+        elif kind == "sep":
+            _, name, cin, cout = lay
+            P[name + "/depthwise_kernel"] = _glorot((3, 3, cin), cin * 9, 9, g, dtype)
+            P[name + "/pointwise_kernel"] = _glorot((cin, cout), cin, cout, g, dtype)
+    h, w = backbone_out_hw(H, W)
+    nin = h * w * 2048
+    P["FinalOutput/kernel"] = _glorot((nin, n_out), nin, n_out, g, dtype)
+    P["FinalOutput/bias"] = torch.zeros(n_out, dtype=dtype)
+    return P
+
+
+L2_KERNELS = ("conv2d_1", "conv2d_2", "conv2d_3", "block1_conv1", "block1_conv2",
+              "conv2d_4", "conv2d_5", "conv2d_6", "conv2d_7", "FinalOutput")
+
+
+def is_trainable(name):
+    return not (name.endswith("/moving_mean") or name.endswith("/moving_variance"))
+
+
+def count_params(P):
+    tr = sum(v.numel() for k, v in P.items() if is_trainable(k))
+    nt = sum(v.numel() for k, v in P.items() if not is_trainable(k))
+    return tr + nt, tr, nt
+
+
+# ------------------------------------------------------------------ forward
+def stem(P, x, training, drop_mask=None, taps=None):
+    """spnet/models.py:321-340.  x [B,H,W,1] -> [B,H/2,W/2,3]."""
+    def bn(name, t):
+        return batchnorm(t, P[name + "/gamma"], P[name + "/beta"], P[name + "/moving_mean"],
+                         P[name + "/moving_variance"], training)
+    t = conv2d(x, P["conv2d_1/kernel"], 1, "same")
+    t = avgpool2(t)
+    t = F.leaky_relu(bn("batch_normalization_1", t), 0.1)
+    t = conv2d(t, P["conv2d_2/kernel"], 1, "same")
+    t = F.leaky_relu(bn("batch_normalization_2", t), 0.1)
+    t = conv2d(t, P["conv2d_3/kernel"], 1, "same")
+    t = bn("batch_normalization_3", t)
+    t = t + avgpool2(x)                      # [.,.,.,1] broadcasts over the 3 channels
+    if training and drop_mask is not None:   # Dropout(0.1): mask holds 0 or 1/0.9
+        t = t * drop_mask
+    if taps is not None:
+        taps["stem"] = t
+    return t
+
+
+def backbone(P, x, training, taps=None):
+    res = None
+    for lay in xception_layers():
+        kind = lay[0]
+        if kind == "conv":
+            x = conv2d(x, P[lay[1] + "/kernel"], lay[4], lay[5])
+        elif kind == "bn":
+            n = lay[1]
+            x = batchnorm(x, P[n + "/gamma"], P[n + "/beta"], P[n + "/moving_mean"], P[n + "/moving_variance"], training)
+            if taps is not None:
+                taps[n] = x
+        elif kind == "relu":
+            x = F.relu(x)
+        elif kind == "res_conv":
+            _, cn, bnn, cin, cout = lay
+            r = conv2d(x, P[cn + "/kernel"], 2, "same")
+            res = batchnorm(r, P[bnn + "/gamma"], P[bnn + "/beta"], P[bnn + "/moving_mean"], P[bnn + "/moving_variance"], training)
+        elif kind == "res_id":
+            res = x
+        elif kind == "sep":
+            n = lay[1]
+            x = pwconv(dwconv3x3(x, P[n + "/depthwise_kernel"]), P[n + "/pointwise_kernel"])
+        elif kind == "pool":
+            x = maxpool3x3s2_same(x)
+        elif kind == "add_res":
+            x = x + res
+    if taps is not None:
+        taps["backbone"] = x
+    return x
+
+
+def forward(P, X, training=False, drop_mask=None, taps=None):
+    """X [B,H,W,1] -> [B,n_out] in normalised units (linear Dense output)."""
+    x = stem(P, X, training, drop_mask, taps)
+    x = backbone(P, x, training, taps)
+    flat = x.reshape(x.shape[0], -1)          # NHWC flatten order (Keras Flatten on channels_last)
+    return flat @ P["FinalOutput/kernel"] + P["FinalOutput/bias"]
+
+
+# ------------------------------------------------------------------ loss / optimiser
+def custom_loss(y_true, y_pred, loss_type="same"):
+    """spnet/models.py:564-589 on torch tensors (differentiable)."""
+    e = (y_true - y_pred) ** 2
+    o = 1 - y_true[:, 6::8]
+    if loss_type == "same":
+        loss = LAMBDAS["noobj"] * e[:, 6::8].sum(-1)
+    else:
+        z = y_pred[:, 6::8]
+        loss = LAMBDAS["noobj"] * (torch.clamp(z, min=0) - z * y_true[:, 6::8] + torch.log1p(torch.exp(-z.abs()))).sum(-1)
+    loss = loss + LAMBDAS["center"] * ((o * e[:, 0::8]).sum(-1) + (o * e[:, 1::8]).sum(-1))
+    loss = loss + LAMBDAS["size"] * ((o * e[:, 2::8]).sum(-1) + (o * e[:, 3::8]).sum(-1))
+    d2 = (y_true[:, 2::8] - y_true[:, 3::8]) ** 2
+    loss = loss + LAMBDAS["angle"] * ((o * e[:, 4::8] * d2).sum(-1) + (o * e[:, 5::8] * d2).sum(-1))
+    loss = loss + LAMBDAS["cls"] * (o * e[:, 7::8]).sum(-1)
+    return (loss / y_pred.shape[-1]).mean()
+
+
+def l2_penalty(P):
+    return sum(L2 * (P[n + "/kernel"] ** 2).sum() for n in L2_KERNELS)
+
+
+class Trainer:
+    """Keras-style training loop state: params, Adam moments, iteration counter."""
+
+    def __init__(self, P, loss_type="same", eps=1e-7):
+        self.P = P
+        self.loss_type = loss_type
+        self.eps = eps
+        self.t = 0
+        self.names = [k for k in P if is_trainable(k)]
+        self.m = {k: torch.zeros_like(P[k]) for k in self.names}
+        self.v = {k: torch.zeros_like(P[k]) for k in self.names}
+
+    def grads(self, X, Y, drop_mask=None):
+        """Returns (data_loss, total_loss_with_l2, {name: grad}) and updates BN moving stats."""
+        leaves = {k: self.P[k].detach().clone().requires_grad_(True) for k in self.names}
+        Pg = OrderedDict((k, leaves.get(k, self.P[k])) for k in self.P)
+        yp = forward(Pg, X, training=True, drop_mask=drop_mask)
+        data = custom_loss(Y, yp, self.loss_type)
+        total = data + l2_penalty(Pg)
+        gs = torch.autograd.grad(total, [leaves[k] for k in self.names])
+        return float(data.detach()), float(total.detach()), dict(zip(self.names, gs)), yp.detach()
+
+    def step(self, X, Y, lr, drop_mask=None):
+        data, total, gs, _ = self.grads(X, Y, drop_mask)
+        self.t += 1
+        b1, b2 = 0.9, 0.999
+        lr_t = lr * math.sqrt(1.0 - b2 ** self.t) / (1.0 - b1 ** self.t)
+        with torch.no_grad():
+            for k in self.names:
+                g = gs[k]
+                self.m[k].mul_(b1).add_((1 - b1) * g)
+                self.v[k].mul_(b2).add_((1 - b2) * g * g)
+                self.P[k].sub_(lr_t * self.m[k] / (self.v[k].sqrt() + self.eps))
+        return data, total
