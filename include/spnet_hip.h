@@ -1,0 +1,119 @@
+/* C ABI of libspnet_hip.so -- the MI355X (gfx950) kernels of the SPNet detection hot path.
+ *
+ * The reference (drscotthawley/SPNet) has no native code and no FFI: its hot path runs inside
+ * Keras 2.1.3 / TensorFlow 1.14 / numpy.  Each entry point below names the reference call site whose
+ * arithmetic it replaces (paths relative to the reference root).  A maintainer binds these with ctypes
+ * (see INTEGRATION.md and spnet_amd/_lib.py).
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer to fp32 data unless noted; tensors are NHWC, row-major
+ *   - pointers passed to vectorised kernels must be 16-byte aligned, channel counts multiples of 4
+ *     unless the entry says otherwise
+ *   - `stream` is a hipStream_t (NULL = default stream); calls only enqueue work, they never
+ *     synchronise, allocate or free, so a sequence of calls can be captured in a hipGraph
+ *   - return value: 0 on success, otherwise a hipError_t (hipErrorInvalidValue for shape/alignment
+ *     violations)
+ */
+#ifndef SPNET_HIP_H
+#define SPNET_HIP_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- dense contractions (MFMA fp32) ---------------------------------------------------------- */
+/* C[M,N] = sum_k A(m,k) B(k,n) (+ bias[n]).  Replaces the pointwise half of SeparableConv2D, the
+ * 1x1/stride-2 residual Conv2D, block1_conv2 (after spnet_im2col3x3) and Dense('FinalOutput')
+ * (spnet/models.py:357-359, 388), forward, data-gradient and weight-gradient forms.
+ * a_major / b_major: 0 = reduction index contiguous (A[m*lda+k], B[n*ldb+k]),
+ *                    1 = output index contiguous    (A[k*lda+m], B[k*ldb+n]).
+ * Supported pairs: (0,1) forward, (0,0) dgrad, (1,1) wgrad.
+ * split_k: 0 = choose automatically, >1 = that many K slices summed deterministically through
+ * `workspace` (>= split_k*M*N floats).  tile: 0 auto, 1 128x128, 2 128x64, 3 64x64, 4 32x128. */
+int spnet_gemm_f32(const float* A, int a_major, int lda, const float* B, int b_major, int ldb, float* C,
+                   int ldc, int M, int N, int K, int split_k, float* workspace, long ws_floats,
+                   const float* bias, int tile, void* stream);
+
+/* 3x3 VALID stride-1 patch matrix and its adjoint (block1_conv2 of keras Xception). */
+int spnet_im2col3x3(const float* x, float* col, int B, int H, int W, int C, void* stream);
+int spnet_col2im3x3(const float* dcol, float* dx, int B, int H, int W, int C, void* stream);
+/* Even-pixel gather / scatter-add: TF 'same' 1x1 stride-2 residual convs of Xception blocks 2,3,4,13. */
+int spnet_gather_s2(const float* x, float* xs, int B, int H, int W, int C, void* stream);
+int spnet_scatter_add_s2(const float* dxs, float* dx, int B, int H, int W, int C, void* stream);
+
+/* ---- depthwise 3x3 / stride 1 / SAME (34 per forward; keras SeparableConv2D depthwise step) ---- */
+/* w is [3][3][C].  relu_in applies the preceding Activation('relu') on load. */
+int spnet_dwconv3x3_fwd(const float* x, const float* w, float* y, int B, int H, int W, int C,
+                        int relu_in, void* stream);
+/* dx = dw3x3(dy, flip w) * (x_fwd > 0 if relu_in) (+ add, e.g. the residual branch's gradient) */
+int spnet_dwconv3x3_bwd_data(const float* dy, const float* w, float* dx, int B, int H, int W, int C,
+                             int relu_in, const float* x_fwd, const float* add, void* stream);
+long spnet_dwconv3x3_bwd_weight_ws(int B, int H, int W, int C);
+int spnet_dwconv3x3_bwd_weight(const float* x, const float* dy, float* dw, int B, int H, int W, int C,
+                               int relu_in, float* workspace, void* stream);
+int spnet_reduce_rows(const float* in, int P, int L, float* out, void* stream);
+
+/* ---- BatchNormalization(axis=-1, momentum .99, eps 1e-3) (spnet/models.py:326-336 + 40 in Xception) --- */
+/* act: 0 none, 1 ReLU, 2 LeakyReLU(0.1) fused behind the affine; residual (or NULL) added last;
+ * res_bcast=1 (C<=4 only): residual holds one value per pixel, broadcast over the channels (the
+ * stem's skip connection from the 1-channel input, spnet/models.py:337). */
+long spnet_bn_ws(long M, int C);
+int spnet_bn_fwd_train(const float* x, long M, int C, const float* gamma, const float* beta,
+                       float* moving_mean, float* moving_var, float* save_mean, float* save_invstd,
+                       float* scale_shift, int act, const float* residual, int res_bcast, float* y,
+                       float eps, float momentum, float* workspace, void* stream);
+int spnet_bn_fwd_infer(const float* x, long M, int C, const float* gamma, const float* beta,
+                       const float* moving_mean, const float* moving_var, float* scale_shift, int act,
+                       const float* residual, int res_bcast, float* y, float eps, void* stream);
+int spnet_bn_bwd(const float* x, const float* dy, long M, int C, const float* gamma, const float* beta,
+                 const float* save_mean, const float* save_invstd, int act, float* dx, float* dgamma,
+                 float* dbeta, float* coeffs, float* workspace, void* stream);
+
+/* ---- pooling --------------------------------------------------------------------------------- */
+/* MaxPooling2D(3, strides 2, 'same') + residual add (Xception blocks 2,3,4,13); idx4 packs the argmax
+ * tap of 4 channels per uint32 (B*OH*OW*C/4 words) for the backward pass. */
+int spnet_maxpool3x3s2_add_fwd(const float* x, const float* residual, float* y, uint32_t* idx4, int B,
+                               int H, int W, int C, void* stream);
+int spnet_maxpool3x3s2_bwd(const float* dy, const uint32_t* idx4, float* dx, int B, int H, int W, int C,
+                           void* stream);
+/* AveragePooling2D(2) of the stem (spnet/models.py:323,337); any C. */
+int spnet_avgpool2_fwd(const float* x, float* y, int B, int H, int W, int C, void* stream);
+int spnet_avgpool2_bwd(const float* dy, float* dx, int B, int H, int W, int C, void* stream);
+
+/* ---- small-channel direct 3x3 convs: stem conv2d_1..3 (models.py:321,330,335), block1_conv1 ---- */
+/* op 0 fwd (a=x,b=w,out=y) | 1 bwd-data (a=dy,b=w,out=dx) | 2 bwd-weight (a=x,b=dy,out=dw).
+ * (cin,cout,stride,same) in {(1,3,1,1), (3,3,1,1), (3,32,2,0)}; w is HWIO. */
+int spnet_conv3x3_small(int op, int cin, int cout, int stride, int same, const float* a, const float* b,
+                        float* out, int B, int H, int W, float* workspace, long ws_floats, void* stream);
+
+/* ---- loss / decode ---------------------------------------------------------------------------- */
+/* custom_loss + my_loss terms + d/dy_pred (spnet/models.py:557-633).  loss_out[6] =
+ * (center,size,angle,noobj,class,total); parts = B*5 floats scratch; grad may be NULL. */
+int spnet_ellipse_loss(const float* y_true, const float* y_pred, float* grad, float* parts,
+                       float* loss_out, int B, int ncols, int hybrid, void* stream);
+/* denorm_Y + cleanup_antinode_vars angle (spnet/utils.py:186-188,56-64; evaluate_spnet.py:70-73):
+ * out[B][ncols/8][7] = (cx,cy,a,b,angle_deg,noobj,rings). */
+int spnet_decode(const float* y_norm, const float* means, const float* ranges, float* out, int B,
+                 int ncols, int sigmoid_noobj, void* stream);
+
+/* ---- optimizer ---------------------------------------------------------------------------------- */
+/* Keras Adam + l2 on the first l2_n elements (spnet/models.py:494, 47-71).  sq_scratch >= 2048 floats. */
+int spnet_adam_step(float* p, const float* g, float* m, float* v, long n, long l2_n, float lr_t,
+                    float beta1, float beta2, float eps, float l2, float grad_scale, float* sq_scratch,
+                    float* l2_loss_out, void* stream);
+
+/* ---- augmentation (spnet/callbacks.py:272-341, spnet/augmentation.py) ---------------------------- */
+int spnet_minmax(const float* x, int N, long hw, float* mm, void* stream);
+int spnet_cutout(const float* src, const int* src_index, float* dst, int N, int H, int W,
+                 const int* rects, const float* vals, const int* nrect, void* stream);
+int spnet_saltpepper(float* x, int N, int H, int W, const int* coords, int n_salt, int n_pepper,
+                     const int* flag, const float* mm, void* stream);
+int spnet_warp_affine(const float* src, float* dst, int N, int H, int W, int C, const float* minv,
+                      void* stream);
+/* Dropout(0.1) of the stem (spnet/models.py:340); same call with dy regenerates the mask in backward. */
+int spnet_dropout(const float* x, float* y, long n, unsigned seed, float rate, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

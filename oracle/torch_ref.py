@@ -288,14 +288,16 @@ class Trainer:
         self.m = {k: torch.zeros_like(P[k]) for k in self.names}
         self.v = {k: torch.zeros_like(P[k]) for k in self.names}
 
-    def grads(self, X, Y, drop_mask=None):
-        """Returns (data_loss, total_loss_with_l2, {name: grad}) and updates BN moving stats."""
+    def grads(self, X, Y, drop_mask=None, include_l2=True):
+        """Returns (data_loss, total_loss_with_l2, {name: grad}, y_pred) and updates BN moving stats.
+        include_l2=False differentiates the data term only (the product folds the l2 gradient into
+        its optimizer kernel)."""
         leaves = {k: self.P[k].detach().clone().requires_grad_(True) for k in self.names}
         Pg = OrderedDict((k, leaves.get(k, self.P[k])) for k in self.P)
         yp = forward(Pg, X, training=True, drop_mask=drop_mask)
         data = custom_loss(Y, yp, self.loss_type)
         total = data + l2_penalty(Pg)
-        gs = torch.autograd.grad(total, [leaves[k] for k in self.names])
+        gs = torch.autograd.grad(total if include_l2 else data, [leaves[k] for k in self.names])
         return float(data.detach()), float(total.detach()), dict(zip(self.names, gs)), yp.detach()
 
     def step(self, X, Y, lr, drop_mask=None):

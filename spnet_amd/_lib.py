@@ -1,0 +1,80 @@
+"""ctypes binding of libspnet_hip.so (C ABI declared in include/spnet_hip.h).
+
+The product path has NO CPU fallback: importing this module without the built library raises, and
+every wrapper raises on a non-zero HIP status.
+"""
+import ctypes
+import os
+from ctypes import c_float, c_int, c_long, c_uint, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libspnet_hip.so")
+
+if not os.path.exists(LIB_PATH):
+    raise ImportError(
+        "spnet_amd: %s is missing -- build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+        "or `make -C spnet_amd/csrc` (hipcc, gfx950).  There is no CPU fallback." % LIB_PATH)
+
+_lib = ctypes.CDLL(LIB_PATH)
+
+P = c_void_p  # device pointers travel as integers
+
+_SIGS = {
+    "spnet_gemm_f32": (c_int, [P, c_int, c_int, P, c_int, c_int, P, c_int, c_int, c_int, c_int, c_int, P, c_long, P, c_int, P]),
+    "spnet_im2col3x3": (c_int, [P, P, c_int, c_int, c_int, c_int, P]),
+    "spnet_col2im3x3": (c_int, [P, P, c_int, c_int, c_int, c_int, P]),
+    "spnet_gather_s2": (c_int, [P, P, c_int, c_int, c_int, c_int, P]),
+    "spnet_scatter_add_s2": (c_int, [P, P, c_int, c_int, c_int, c_int, P]),
+    "spnet_dwconv3x3_fwd": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, P]),
+    "spnet_dwconv3x3_bwd_data": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, P, P, P]),
+    "spnet_dwconv3x3_bwd_weight_ws": (c_long, [c_int, c_int, c_int, c_int]),
+    "spnet_dwconv3x3_bwd_weight": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, P, P]),
+    "spnet_reduce_rows": (c_int, [P, c_int, c_int, P, P]),
+    "spnet_bn_ws": (c_long, [c_long, c_int]),
+    "spnet_bn_fwd_train": (c_int, [P, c_long, c_int, P, P, P, P, P, P, P, c_int, P, c_int, P, c_float, c_float, P, P]),
+    "spnet_bn_fwd_infer": (c_int, [P, c_long, c_int, P, P, P, P, P, c_int, P, c_int, P, c_float, P]),
+    "spnet_bn_bwd": (c_int, [P, P, c_long, c_int, P, P, P, P, c_int, P, P, P, P, P, P]),
+    "spnet_maxpool3x3s2_add_fwd": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, P]),
+    "spnet_maxpool3x3s2_bwd": (c_int, [P, P, P, c_int, c_int, c_int, c_int, P]),
+    "spnet_avgpool2_fwd": (c_int, [P, P, c_int, c_int, c_int, c_int, P]),
+    "spnet_avgpool2_bwd": (c_int, [P, P, c_int, c_int, c_int, c_int, P]),
+    "spnet_conv3x3_small": (c_int, [c_int, c_int, c_int, c_int, c_int, P, P, P, c_int, c_int, c_int, P, c_long, P]),
+    "spnet_ellipse_loss": (c_int, [P, P, P, P, P, c_int, c_int, c_int, P]),
+    "spnet_decode": (c_int, [P, P, P, P, c_int, c_int, c_int, P]),
+    "spnet_adam_step": (c_int, [P, P, P, P, c_long, c_long, c_float, c_float, c_float, c_float, c_float, c_float, P, P, P]),
+    "spnet_minmax": (c_int, [P, c_int, c_long, P, P]),
+    "spnet_cutout": (c_int, [P, P, P, c_int, c_int, c_int, P, P, P, P]),
+    "spnet_saltpepper": (c_int, [P, c_int, c_int, c_int, P, c_int, c_int, P, P, P]),
+    "spnet_warp_affine": (c_int, [P, P, c_int, c_int, c_int, c_int, P, P]),
+    "spnet_dropout": (c_int, [P, P, c_long, c_uint, c_float, P]),
+}
+
+EXPORTS = tuple(_SIGS)
+
+
+class HipError(RuntimeError):
+    pass
+
+
+def _bind(name, restype, argtypes):
+    fn = getattr(_lib, name)      # AttributeError here = the library does not export the symbol
+    fn.restype = restype
+    fn.argtypes = argtypes
+    if restype is not c_int:
+        return fn
+
+    def checked(*args):
+        rc = fn(*args)
+        if rc != 0:
+            raise HipError("%s failed with hipError_t %d" % (name, rc))
+    checked.__name__ = name
+    return checked
+
+
+for _n, (_r, _a) in _SIGS.items():
+    globals()[_n] = _bind(_n, _r, _a)
+
+
+def ptr(t):
+    """Device pointer of a torch tensor (or None -> NULL)."""
+    return None if t is None else t.data_ptr()

@@ -1,0 +1,176 @@
+// Train-time augmentation (AugmentOnTheFly, spnet/callbacks.py:272-341) and the offline warps
+// (spnet/augmentation.py:82-239) on device-resident frames.
+//
+// Parameter-driven form: the HOST draws the random parameters in exactly the reference's RNG call
+// order (cutout_inplace augmentation.py:117-134, salt_n_pepa_inplace :157-180, blur gate
+// callbacks.py:306-309); the device applies them to a pristine copy of the frames.  This keeps the
+// result bit-identical to the reference's numpy code while the per-pixel work runs at HBM speed and
+// the reference's X_orig.copy() host-RAM doubling (callbacks.py:291) disappears.
+//
+// Frames are [N][H][W] fp32 (single channel, values in [-1,1]).
+#include "common.h"
+
+#define MAX_RECTS 6
+
+// per-image min / max -> mm[n][2]
+__global__ __launch_bounds__(256) void minmax_kernel(const float* __restrict__ x, long hw,
+                                                     float* __restrict__ mm) {
+  __shared__ float rlo[4], rhi[4];
+  const float* p = x + (long)blockIdx.x * hw;
+  float lo = __builtin_huge_valf(), hi = -__builtin_huge_valf();
+  for (long i = threadIdx.x; i < hw; i += blockDim.x) {
+    const float v = p[i];
+    lo = fminf(lo, v);
+    hi = fmaxf(hi, v);
+  }
+  lo = wave_min(lo);
+  hi = wave_max(hi);
+  if ((threadIdx.x & 63) == 0) { rlo[threadIdx.x >> 6] = lo; rhi[threadIdx.x >> 6] = hi; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    mm[blockIdx.x * 2 + 0] = fminf(fminf(rlo[0], rlo[1]), fminf(rlo[2], rlo[3]));
+    mm[blockIdx.x * 2 + 1] = fmaxf(fmaxf(rhi[0], rhi[1]), fmaxf(rhi[2], rhi[3]));
+  }
+}
+
+// dst[n] = src[src_index[n]] with the image's rectangles painted in order (later ones win).
+// rects[n][MAX_RECTS][4] = (r0, r1, c0, c1) half-open; vals[n][MAX_RECTS]; nrect[n].
+__global__ __launch_bounds__(256) void cutout_kernel(const float* __restrict__ src,
+                                                     const int* __restrict__ src_index,
+                                                     float* __restrict__ dst, int H, int W,
+                                                     const int* __restrict__ rects,
+                                                     const float* __restrict__ vals,
+                                                     const int* __restrict__ nrect) {
+  const int n = blockIdx.y;
+  const long hw = (long)H * W;
+  const float* s = src + (long)(src_index ? src_index[n] : n) * hw;
+  float* d = dst + (long)n * hw;
+  const int nr = nrect[n];
+  int r0[MAX_RECTS], r1[MAX_RECTS], c0[MAX_RECTS], c1[MAX_RECTS];
+  float val[MAX_RECTS];
+#pragma unroll
+  for (int k = 0; k < MAX_RECTS; ++k) {
+    const int* q = rects + ((long)n * MAX_RECTS + k) * 4;
+    r0[k] = q[0]; r1[k] = q[1]; c0[k] = q[2]; c1[k] = q[3];
+    val[k] = vals[(long)n * MAX_RECTS + k];
+  }
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < hw; i += (long)gridDim.x * blockDim.x) {
+    const int r = (int)(i / W), c = (int)(i % W);
+    float v = s[i];
+#pragma unroll
+    for (int k = 0; k < MAX_RECTS; ++k)
+      if (k < nr && r >= r0[k] && r < r1[k] && c >= c0[k] && c < c1[k]) v = val[k];
+    d[i] = v;
+  }
+}
+
+// One workgroup per image: salt (= image max) first, then pepper (= image min) over it, as the
+// reference's two fancy-index assignments do.  coords[n][2][npts] = rows then cols (salt points
+// first, then pepper points); flag[n] = 0 skips the image.
+__global__ __launch_bounds__(256) void saltpepper_kernel(float* __restrict__ x, int H, int W,
+                                                         const int* __restrict__ coords, int n_salt,
+                                                         int n_pepper, const int* __restrict__ flag,
+                                                         const float* __restrict__ mm) {
+  const int n = blockIdx.x;
+  if (!flag[n]) return;
+  float* d = x + (long)n * H * W;
+  const int npts = n_salt + n_pepper;
+  const int* rows = coords + (long)n * 2 * npts;
+  const int* cols = rows + npts;
+  const float lo = mm[n * 2 + 0], hi = mm[n * 2 + 1];
+  for (int i = threadIdx.x; i < n_salt; i += blockDim.x) d[(long)rows[i] * W + cols[i]] = hi;
+  __threadfence_block();
+  __syncthreads();
+  for (int i = n_salt + threadIdx.x; i < npts; i += blockDim.x) d[(long)rows[i] * W + cols[i]] = lo;
+}
+
+// Inverse-affine bilinear gather with zero border: covers flip, rotate-about-centre and integer
+// translate (spnet/augmentation.py:82-112,184-207,216-239 through cv2.flip / cv2.warpAffine).
+// minv[n][6] maps DESTINATION pixel (x,y) to SOURCE coordinates: sx = a*x + b*y + c, sy = d*x + e*y + f.
+// Images are [N][H][W][C] fp32; weights are exact floats (OpenCV quantises them to 1/32 pixel).
+__global__ __launch_bounds__(256) void warp_affine_kernel(const float* __restrict__ src,
+                                                          float* __restrict__ dst, int H, int W, int C,
+                                                          const float* __restrict__ minv) {
+  const int n = blockIdx.y;
+  const float* m = minv + (long)n * 6;
+  const float a = m[0], b = m[1], c = m[2], d = m[3], e = m[4], f = m[5];
+  const long hw = (long)H * W;
+  const float* s = src + (long)n * hw * C;
+  float* o = dst + (long)n * hw * C;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < hw; i += (long)gridDim.x * blockDim.x) {
+    const int y = (int)(i / W), x = (int)(i % W);
+    const float sx = a * x + b * y + c, sy = d * x + e * y + f;
+    const float fx = floorf(sx), fy = floorf(sy);
+    const int x0 = (int)fx, y0 = (int)fy;
+    const float wx = sx - fx, wy = sy - fy;
+    for (int ch = 0; ch < C; ++ch) {
+      float v00 = 0.f, v01 = 0.f, v10 = 0.f, v11 = 0.f;
+      if (y0 >= 0 && y0 < H) {
+        if (x0 >= 0 && x0 < W) v00 = s[((long)y0 * W + x0) * C + ch];
+        if (x0 + 1 >= 0 && x0 + 1 < W) v01 = s[((long)y0 * W + x0 + 1) * C + ch];
+      }
+      if (y0 + 1 >= 0 && y0 + 1 < H) {
+        if (x0 >= 0 && x0 < W) v10 = s[((long)(y0 + 1) * W + x0) * C + ch];
+        if (x0 + 1 >= 0 && x0 + 1 < W) v11 = s[((long)(y0 + 1) * W + x0 + 1) * C + ch];
+      }
+      const float top = v00 + wx * (v01 - v00), bot = v10 + wx * (v11 - v10);
+      o[i * C + ch] = top + wy * (bot - top);
+    }
+  }
+}
+
+// Dropout(0.1) of the stem (spnet/models.py:340): y = x * keep/(1-rate) with a counter-based hash RNG
+// so that the mask is a pure function of (seed, element index) and can be regenerated in backward.
+__device__ __forceinline__ uint32_t hash_u32(uint32_t x) {
+  x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
+  return x;
+}
+__global__ __launch_bounds__(256) void dropout_kernel(const float* __restrict__ x,
+                                                      float* __restrict__ y, long n, uint32_t seed,
+                                                      uint32_t thresh, float scale) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const uint32_t h = hash_u32((uint32_t)i * 0x9e3779b9U + seed);
+    y[i] = (h >= thresh) ? x[i] * scale : 0.f;
+  }
+}
+
+extern "C" int spnet_minmax(const float* x, int N, long hw, float* mm, void* stream) {
+  hipLaunchKernelGGL(minmax_kernel, dim3(N), dim3(256), 0, (hipStream_t)stream, x, hw, mm);
+  SPNET_RETURN_LAUNCH_STATUS();
+}
+
+extern "C" int spnet_cutout(const float* src, const int* src_index, float* dst, int N, int H, int W,
+                            const int* rects, const float* vals, const int* nrect, void* stream) {
+  const long hw = (long)H * W;
+  int gx = (int)((hw + 255) / 256);
+  if (gx > 64) gx = 64;
+  hipLaunchKernelGGL(cutout_kernel, dim3(gx, N), dim3(256), 0, (hipStream_t)stream, src, src_index, dst,
+                     H, W, rects, vals, nrect);
+  SPNET_RETURN_LAUNCH_STATUS();
+}
+
+extern "C" int spnet_saltpepper(float* x, int N, int H, int W, const int* coords, int n_salt,
+                                int n_pepper, const int* flag, const float* mm, void* stream) {
+  hipLaunchKernelGGL(saltpepper_kernel, dim3(N), dim3(256), 0, (hipStream_t)stream, x, H, W, coords,
+                     n_salt, n_pepper, flag, mm);
+  SPNET_RETURN_LAUNCH_STATUS();
+}
+
+extern "C" int spnet_warp_affine(const float* src, float* dst, int N, int H, int W, int C,
+                                 const float* minv, void* stream) {
+  const long hw = (long)H * W;
+  int gx = (int)((hw + 255) / 256);
+  if (gx > 256) gx = 256;
+  hipLaunchKernelGGL(warp_affine_kernel, dim3(gx, N), dim3(256), 0, (hipStream_t)stream, src, dst, H, W,
+                     C, minv);
+  SPNET_RETURN_LAUNCH_STATUS();
+}
+
+// rate in [0,1): elements with hash < rate*2^32 are dropped, survivors scaled by 1/(1-rate).
+extern "C" int spnet_dropout(const float* x, float* y, long n, unsigned seed, float rate, void* stream) {
+  const double t = (double)rate * 4294967296.0;
+  const uint32_t thresh = (uint32_t)(t > 4294967295.0 ? 4294967295.0 : t);
+  hipLaunchKernelGGL(dropout_kernel, dim3(spnet_ew_grid(n, 256)), dim3(256), 0, (hipStream_t)stream, x,
+                     y, n, seed, thresh, 1.0f / (1.0f - rate));
+  SPNET_RETURN_LAUNCH_STATUS();
+}

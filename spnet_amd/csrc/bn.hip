@@ -1,0 +1,411 @@
+// BatchNormalization(axis=-1, momentum 0.99, eps 1e-3) forward / backward on [M][C] fp32 tensors
+// (M = batch*H*W pixels).  Keras semantics (call sites spnet/models.py:326-336 and the 40 BN layers
+// inside keras.applications.Xception): training normalises with the batch mean and the biased batch
+// variance; moving statistics are updated with the Bessel-corrected variance.
+//
+// All reductions are two-stage and deterministic: per-workgroup partial sums, then a finalize kernel
+// that combines them in a fixed order in double precision.
+//
+// Activation fused behind the affine: 0 none, 1 ReLU, 2 LeakyReLU(0.1).
+#include "common.h"
+
+#define BN_MAX_PARTS 256
+
+__device__ __forceinline__ float act_fwd(float v, int act) {
+  if (act == 1) return fmaxf(v, 0.f);
+  if (act == 2) return v > 0.f ? v : 0.1f * v;
+  return v;
+}
+__device__ __forceinline__ float act_grad(float out_pre, int act) {
+  if (act == 1) return out_pre > 0.f ? 1.f : 0.f;
+  if (act == 2) return out_pre > 0.f ? 1.f : 0.1f;
+  return 1.f;
+}
+
+// ---------------------------------------------------------------- vector path (C % 4 == 0)
+// blockDim = (CL, 256/CL); grid = (ceil(C4/CL), GY).  MODE 0: sum x, sum x^2.
+// MODE 1: sum g, sum g*xhat with g = dy * act'(xhat*gamma+beta).
+template <int MODE>
+__global__ __launch_bounds__(256) void bn_partial_vec_kernel(
+    const float* __restrict__ x, const float* __restrict__ dy, long M, int C,
+    const float* __restrict__ mean, const float* __restrict__ invstd,
+    const float* __restrict__ gamma, const float* __restrict__ beta, int act,
+    float* __restrict__ partial) {
+  extern __shared__ __attribute__((aligned(16))) float4 red4[];   // [blockDim.y][2][blockDim.x]
+  const int c4n = C >> 2;
+  const int c4 = blockIdx.x * blockDim.x + threadIdx.x;
+  const bool active = c4 < c4n;
+  const int c = c4 * 4;
+  float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0;
+  if (active) {
+    float4 mu = s0, is = s0, ga = s0, be = s0;
+    if (MODE == 1) {
+      mu = *reinterpret_cast<const float4*>(mean + c);
+      is = *reinterpret_cast<const float4*>(invstd + c);
+      ga = *reinterpret_cast<const float4*>(gamma + c);
+      be = *reinterpret_cast<const float4*>(beta + c);
+    }
+    for (long r = (long)blockIdx.y * blockDim.y + threadIdx.y; r < M;
+         r += (long)gridDim.y * blockDim.y) {
+      const float4 v = *reinterpret_cast<const float4*>(x + r * C + c);
+      if (MODE == 0) {
+        s0.x += v.x; s0.y += v.y; s0.z += v.z; s0.w += v.w;
+        s1.x = fmaf(v.x, v.x, s1.x); s1.y = fmaf(v.y, v.y, s1.y);
+        s1.z = fmaf(v.z, v.z, s1.z); s1.w = fmaf(v.w, v.w, s1.w);
+      } else {
+        float4 g = *reinterpret_cast<const float4*>(dy + r * C + c);
+        float4 xh;
+        xh.x = (v.x - mu.x) * is.x; xh.y = (v.y - mu.y) * is.y;
+        xh.z = (v.z - mu.z) * is.z; xh.w = (v.w - mu.w) * is.w;
+        if (act) {
+          g.x *= act_grad(fmaf(xh.x, ga.x, be.x), act);
+          g.y *= act_grad(fmaf(xh.y, ga.y, be.y), act);
+          g.z *= act_grad(fmaf(xh.z, ga.z, be.z), act);
+          g.w *= act_grad(fmaf(xh.w, ga.w, be.w), act);
+        }
+        s0.x += g.x; s0.y += g.y; s0.z += g.z; s0.w += g.w;
+        s1.x = fmaf(g.x, xh.x, s1.x); s1.y = fmaf(g.y, xh.y, s1.y);
+        s1.z = fmaf(g.z, xh.z, s1.z); s1.w = fmaf(g.w, xh.w, s1.w);
+      }
+    }
+  }
+  const int bx = blockDim.x, by = blockDim.y;
+  red4[(threadIdx.y * 2 + 0) * bx + threadIdx.x] = s0;
+  red4[(threadIdx.y * 2 + 1) * bx + threadIdx.x] = s1;
+  __syncthreads();
+  if (threadIdx.y == 0 && active) {
+    for (int q = 0; q < 2; ++q) {
+      float4 s = red4[q * bx + threadIdx.x];
+      for (int y = 1; y < by; ++y) {
+        const float4 v = red4[(y * 2 + q) * bx + threadIdx.x];
+        s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+      }
+      *reinterpret_cast<float4*>(partial + ((long)blockIdx.y * 2 + q) * C + c) = s;
+    }
+  }
+}
+
+// ---------------------------------------------------------------- scalar path (tiny C, e.g. the stem's 3)
+// blockDim = 64*C, grid-stride over the flat [M*C] array; a thread's channel is tid % C throughout.
+template <int MODE>
+__global__ void bn_partial_small_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                        long M, int C, const float* __restrict__ mean,
+                                        const float* __restrict__ invstd,
+                                        const float* __restrict__ gamma,
+                                        const float* __restrict__ beta, int act,
+                                        float* __restrict__ partial) {
+  extern __shared__ float red[];   // [2][blockDim.x]
+  const int ch = threadIdx.x % C;
+  float mu = 0.f, is = 0.f, ga = 0.f, be = 0.f;
+  if (MODE == 1) { mu = mean[ch]; is = invstd[ch]; ga = gamma[ch]; be = beta[ch]; }
+  float s0 = 0.f, s1 = 0.f;
+  const long n = M * C;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const float v = x[i];
+    if (MODE == 0) {
+      s0 += v;
+      s1 = fmaf(v, v, s1);
+    } else {
+      const float xh = (v - mu) * is;
+      const float g = dy[i] * act_grad(fmaf(xh, ga, be), act);
+      s0 += g;
+      s1 = fmaf(g, xh, s1);
+    }
+  }
+  red[threadIdx.x] = s0;
+  red[blockDim.x + threadIdx.x] = s1;
+  __syncthreads();
+  if (threadIdx.x < C) {
+    float a = 0.f, b = 0.f;
+    for (int t = threadIdx.x; t < blockDim.x; t += C) { a += red[t]; b += red[blockDim.x + t]; }
+    partial[((long)blockIdx.x * 2 + 0) * C + threadIdx.x] = a;
+    partial[((long)blockIdx.x * 2 + 1) * C + threadIdx.x] = b;
+  }
+}
+
+// Combine partial [P][2][C] in a fixed order: 256 threads = 64 channels x 4 interleaved groups of
+// partial rows, summed in double, then the 4 group sums are added in group order.  Returns the
+// channel owned by this thread (group 0 only) or -1.
+__device__ __forceinline__ int combine_partials(const float* __restrict__ partial, int P, int C,
+                                                double* s_out, double* q_out) {
+  __shared__ double cred[2][4][64];
+  const int lane = threadIdx.x & 63, g = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + lane;
+  double s = 0.0, q = 0.0;
+  if (c < C) {
+    for (int p = g; p < P; p += 4) {
+      s += (double)partial[((long)p * 2 + 0) * C + c];
+      q += (double)partial[((long)p * 2 + 1) * C + c];
+    }
+  }
+  cred[0][g][lane] = s;
+  cred[1][g][lane] = q;
+  __syncthreads();
+  if (g != 0 || c >= C) return -1;
+  *s_out = (cred[0][0][lane] + cred[0][1][lane]) + (cred[0][2][lane] + cred[0][3][lane]);
+  *q_out = (cred[1][0][lane] + cred[1][1][lane]) + (cred[1][2][lane] + cred[1][3][lane]);
+  return c;
+}
+
+// ---------------------------------------------------------------- finalize (64 channels per workgroup)
+// Forward: partial [P][2][C] -> batch mean / invstd, affine coefficients, moving-stat update.
+__global__ __launch_bounds__(256) void bn_fwd_finalize_kernel(
+    const float* __restrict__ partial, int P, int C, long M, const float* __restrict__ gamma,
+    const float* __restrict__ beta, float* __restrict__ moving_mean, float* __restrict__ moving_var,
+    float* __restrict__ save_mean, float* __restrict__ save_invstd, float* __restrict__ scale,
+    float* __restrict__ shift, float eps, float momentum) {
+  double s, q;
+  const int c = combine_partials(partial, P, C, &s, &q);
+  if (c < 0) return;
+  const double mean = s / (double)M;
+  double var = q / (double)M - mean * mean;
+  if (var < 0.0) var = 0.0;
+  const float invstd = (float)(1.0 / sqrt(var + (double)eps));
+  const float sc = gamma[c] * invstd;
+  save_mean[c] = (float)mean;
+  save_invstd[c] = invstd;
+  scale[c] = sc;
+  shift[c] = beta[c] - (float)mean * sc;
+  const double unbiased = (M > 1) ? var * ((double)M / (double)(M - 1)) : var;
+  moving_mean[c] = momentum * moving_mean[c] + (1.f - momentum) * (float)mean;
+  moving_var[c] = momentum * moving_var[c] + (1.f - momentum) * (float)unbiased;
+}
+
+// Inference: affine from the moving statistics.
+__global__ __launch_bounds__(256) void bn_infer_coeffs_kernel(
+    int C, const float* __restrict__ gamma, const float* __restrict__ beta,
+    const float* __restrict__ moving_mean, const float* __restrict__ moving_var,
+    float* __restrict__ scale, float* __restrict__ shift, float eps) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const float sc = gamma[c] * rsqrtf(moving_var[c] + eps);
+  scale[c] = sc;
+  shift[c] = beta[c] - moving_mean[c] * sc;
+}
+
+// Backward: partial [P][2][C] -> dgamma, dbeta and the three per-channel coefficients of
+//   dx = k1 * g + k2 * xhat + k3,  g = dy * act'(.)
+__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(
+    const float* __restrict__ partial, int P, int C, long M, const float* __restrict__ gamma,
+    const float* __restrict__ invstd, float* __restrict__ dgamma, float* __restrict__ dbeta,
+    float* __restrict__ k1, float* __restrict__ k2, float* __restrict__ k3) {
+  double sg, sgx;
+  const int c = combine_partials(partial, P, C, &sg, &sgx);
+  if (c < 0) return;
+  dbeta[c] = (float)sg;
+  dgamma[c] = (float)sgx;
+  const double a = (double)gamma[c] * (double)invstd[c];
+  k1[c] = (float)a;
+  k2[c] = (float)(-a * sgx / (double)M);
+  k3[c] = (float)(-a * sg / (double)M);
+}
+
+// ---------------------------------------------------------------- apply kernels
+// y = act(x*scale + shift) (+ residual)
+__global__ __launch_bounds__(256) void bn_apply_vec_kernel(const float* __restrict__ x, long M, int C,
+                                                           const float* __restrict__ scale,
+                                                           const float* __restrict__ shift, int act,
+                                                           const float* __restrict__ residual,
+                                                           float* __restrict__ y) {
+  const int c4n = C >> 2;
+  const long total = M * c4n;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % c4n) * 4;
+    const float4 v = *reinterpret_cast<const float4*>(x + i * 4);
+    const float4 sc = *reinterpret_cast<const float4*>(scale + c);
+    const float4 sh = *reinterpret_cast<const float4*>(shift + c);
+    float4 o;
+    o.x = act_fwd(fmaf(v.x, sc.x, sh.x), act);
+    o.y = act_fwd(fmaf(v.y, sc.y, sh.y), act);
+    o.z = act_fwd(fmaf(v.z, sc.z, sh.z), act);
+    o.w = act_fwd(fmaf(v.w, sc.w, sh.w), act);
+    if (residual) {
+      const float4 r = *reinterpret_cast<const float4*>(residual + i * 4);
+      o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
+    }
+    *reinterpret_cast<float4*>(y + i * 4) = o;
+  }
+}
+
+__global__ __launch_bounds__(256) void bn_apply_scalar_kernel(const float* __restrict__ x, long n,
+                                                              int C, const float* __restrict__ scale,
+                                                              const float* __restrict__ shift, int act,
+                                                              const float* __restrict__ residual,
+                                                              int res_bcast, float* __restrict__ y) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C);
+    float o = act_fwd(fmaf(x[i], scale[c], shift[c]), act);
+    if (residual) o += residual[res_bcast ? i / C : i];   // res_bcast: one residual value per pixel
+    y[i] = o;
+  }
+}
+
+// dx = k1*g + k2*xhat + k3
+__global__ __launch_bounds__(256) void bn_bwd_apply_vec_kernel(
+    const float* __restrict__ x, const float* __restrict__ dy, long M, int C,
+    const float* __restrict__ mean, const float* __restrict__ invstd,
+    const float* __restrict__ gamma, const float* __restrict__ beta, int act,
+    const float* __restrict__ k1, const float* __restrict__ k2, const float* __restrict__ k3,
+    float* __restrict__ dx) {
+  const int c4n = C >> 2;
+  const long total = M * c4n;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % c4n) * 4;
+    const float4 v = *reinterpret_cast<const float4*>(x + i * 4);
+    float4 g = *reinterpret_cast<const float4*>(dy + i * 4);
+    const float4 mu = *reinterpret_cast<const float4*>(mean + c);
+    const float4 is = *reinterpret_cast<const float4*>(invstd + c);
+    float4 xh;
+    xh.x = (v.x - mu.x) * is.x; xh.y = (v.y - mu.y) * is.y;
+    xh.z = (v.z - mu.z) * is.z; xh.w = (v.w - mu.w) * is.w;
+    if (act) {
+      const float4 ga = *reinterpret_cast<const float4*>(gamma + c);
+      const float4 be = *reinterpret_cast<const float4*>(beta + c);
+      g.x *= act_grad(fmaf(xh.x, ga.x, be.x), act);
+      g.y *= act_grad(fmaf(xh.y, ga.y, be.y), act);
+      g.z *= act_grad(fmaf(xh.z, ga.z, be.z), act);
+      g.w *= act_grad(fmaf(xh.w, ga.w, be.w), act);
+    }
+    const float4 a = *reinterpret_cast<const float4*>(k1 + c);
+    const float4 b = *reinterpret_cast<const float4*>(k2 + c);
+    const float4 d = *reinterpret_cast<const float4*>(k3 + c);
+    float4 o;
+    o.x = fmaf(a.x, g.x, fmaf(b.x, xh.x, d.x));
+    o.y = fmaf(a.y, g.y, fmaf(b.y, xh.y, d.y));
+    o.z = fmaf(a.z, g.z, fmaf(b.z, xh.z, d.z));
+    o.w = fmaf(a.w, g.w, fmaf(b.w, xh.w, d.w));
+    *reinterpret_cast<float4*>(dx + i * 4) = o;
+  }
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_apply_scalar_kernel(
+    const float* __restrict__ x, const float* __restrict__ dy, long n, int C,
+    const float* __restrict__ mean, const float* __restrict__ invstd,
+    const float* __restrict__ gamma, const float* __restrict__ beta, int act,
+    const float* __restrict__ k1, const float* __restrict__ k2, const float* __restrict__ k3,
+    float* __restrict__ dx) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C);
+    const float xh = (x[i] - mean[c]) * invstd[c];
+    const float g = dy[i] * act_grad(fmaf(xh, gamma[c], beta[c]), act);
+    dx[i] = fmaf(k1[c], g, fmaf(k2[c], xh, k3[c]));
+  }
+}
+
+// ---------------------------------------------------------------- host side
+static int bn_chan_lanes(int c4n) {
+  int cl = 8;
+  while (cl < c4n && cl < 64) cl <<= 1;
+  return cl;
+}
+
+static int bn_parts(long M, int C) {
+  if (C & 3) {
+    long g = (M * C + (64L * C) * 8 - 1) / ((64L * C) * 8);
+    if (g > BN_MAX_PARTS) g = BN_MAX_PARTS;
+    return g < 1 ? 1 : (int)g;
+  }
+  const int cl = bn_chan_lanes(C / 4);
+  const int by = 256 / cl;
+  const int gx = (C / 4 + cl - 1) / cl;
+  long gy = (M + (long)by * 8 - 1) / ((long)by * 8);   // >= 8 rows per thread
+  long cap = 2048 / gx;
+  if (cap > BN_MAX_PARTS) cap = BN_MAX_PARTS;
+  if (cap < 1) cap = 1;
+  if (gy > cap) gy = cap;
+  return gy < 1 ? 1 : (int)gy;
+}
+
+// floats of scratch needed by spnet_bn_fwd_train / spnet_bn_bwd for an [M][C] tensor
+extern "C" long spnet_bn_ws(long M, int C) { return (long)bn_parts(M, C) * 2 * C; }
+
+template <int MODE>
+static void launch_partial(const float* x, const float* dy, long M, int C, const float* mean,
+                           const float* invstd, const float* gamma, const float* beta, int act,
+                           float* partial, int parts, hipStream_t st) {
+  if (C & 3) {
+    const int bd = 64 * C;
+    hipLaunchKernelGGL(bn_partial_small_kernel<MODE>, dim3(parts), dim3(bd), 2 * bd * sizeof(float),
+                       st, x, dy, M, C, mean, invstd, gamma, beta, act, partial);
+  } else {
+    const int cl = bn_chan_lanes(C / 4);
+    const int by = 256 / cl;
+    dim3 grid((C / 4 + cl - 1) / cl, parts), block(cl, by);
+    hipLaunchKernelGGL(bn_partial_vec_kernel<MODE>, grid, block, (size_t)by * 2 * cl * sizeof(float4),
+                       st, x, dy, M, C, mean, invstd, gamma, beta, act, partial);
+  }
+}
+
+static void launch_apply(const float* x, long M, int C, const float* scale, const float* shift,
+                         int act, const float* residual, int res_bcast, float* y, hipStream_t st) {
+  if (C & 3) {
+    const long n = M * C;
+    hipLaunchKernelGGL(bn_apply_scalar_kernel, dim3(spnet_ew_grid(n, 256)), dim3(256), 0, st, x, n, C,
+                       scale, shift, act, residual, res_bcast, y);
+  } else {
+    const long n4 = M * (C / 4);
+    hipLaunchKernelGGL(bn_apply_vec_kernel, dim3(spnet_ew_grid(n4, 256)), dim3(256), 0, st, x, M, C,
+                       scale, shift, act, residual, y);
+  }
+}
+
+// Training forward.  Outputs: y, save_mean[C], save_invstd[C] (for backward), moving stats updated
+// in place.  scale_shift: 2*C floats of scratch.  workspace: spnet_bn_ws(M,C) floats.
+extern "C" int spnet_bn_fwd_train(const float* x, long M, int C, const float* gamma,
+                                  const float* beta, float* moving_mean, float* moving_var,
+                                  float* save_mean, float* save_invstd, float* scale_shift, int act,
+                                  const float* residual, int res_bcast, float* y, float eps,
+                                  float momentum, float* workspace, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  if ((C & 3) && C > 4) return (int)hipErrorInvalidValue;
+  if (res_bcast && !(C & 3)) return (int)hipErrorInvalidValue;
+  const int parts = bn_parts(M, C);
+  launch_partial<0>(x, nullptr, M, C, nullptr, nullptr, nullptr, nullptr, 0, workspace, parts, st);
+  hipLaunchKernelGGL(bn_fwd_finalize_kernel, dim3((C + 63) / 64), dim3(256), 0, st, workspace, parts,
+                     C, M, gamma, beta, moving_mean, moving_var, save_mean, save_invstd, scale_shift,
+                     scale_shift + C, eps, momentum);
+  launch_apply(x, M, C, scale_shift, scale_shift + C, act, residual, res_bcast, y, st);
+  SPNET_RETURN_LAUNCH_STATUS();
+}
+
+// Inference forward from the moving statistics.
+extern "C" int spnet_bn_fwd_infer(const float* x, long M, int C, const float* gamma, const float* beta,
+                                  const float* moving_mean, const float* moving_var,
+                                  float* scale_shift, int act, const float* residual, int res_bcast,
+                                  float* y, float eps, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  if ((C & 3) && C > 4) return (int)hipErrorInvalidValue;
+  if (res_bcast && !(C & 3)) return (int)hipErrorInvalidValue;
+  hipLaunchKernelGGL(bn_infer_coeffs_kernel, dim3((C + 255) / 256), dim3(256), 0, st, C, gamma, beta,
+                     moving_mean, moving_var, scale_shift, scale_shift + C, eps);
+  launch_apply(x, M, C, scale_shift, scale_shift + C, act, residual, res_bcast, y, st);
+  SPNET_RETURN_LAUNCH_STATUS();
+}
+
+// Backward of y = act(BN(x)): dx, dgamma[C], dbeta[C].  x is the BN *input* saved by the forward.
+// coeffs: 3*C floats of scratch.  workspace: spnet_bn_ws(M,C) floats.  dx may alias dy.
+extern "C" int spnet_bn_bwd(const float* x, const float* dy, long M, int C, const float* gamma,
+                            const float* beta, const float* save_mean, const float* save_invstd,
+                            int act, float* dx, float* dgamma, float* dbeta, float* coeffs,
+                            float* workspace, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  if ((C & 3) && C > 4) return (int)hipErrorInvalidValue;
+  const int parts = bn_parts(M, C);
+  launch_partial<1>(x, dy, M, C, save_mean, save_invstd, gamma, beta, act, workspace, parts, st);
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 63) / 64), dim3(256), 0, st, workspace, parts,
+                     C, M, gamma, save_invstd, dgamma, dbeta, coeffs, coeffs + C, coeffs + 2 * C);
+  if (C & 3) {
+    const long n = M * C;
+    hipLaunchKernelGGL(bn_bwd_apply_scalar_kernel, dim3(spnet_ew_grid(n, 256)), dim3(256), 0, st, x,
+                       dy, n, C, save_mean, save_invstd, gamma, beta, act, coeffs, coeffs + C,
+                       coeffs + 2 * C, dx);
+  } else {
+    const long n4 = M * (C / 4);
+    hipLaunchKernelGGL(bn_bwd_apply_vec_kernel, dim3(spnet_ew_grid(n4, 256)), dim3(256), 0, st, x, dy,
+                       M, C, save_mean, save_invstd, gamma, beta, act, coeffs, coeffs + C,
+                       coeffs + 2 * C, dx);
+  }
+  SPNET_RETURN_LAUNCH_STATUS();
+}

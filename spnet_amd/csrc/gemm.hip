@@ -1,0 +1,433 @@
+// fp32 MFMA GEMM for the pointwise (1x1) convolutions, the stride-2 residual convs, block1_conv2
+// (through im2col) and the Dense head:  C[M,N] = sum_k A(m,k) * B(k,n)
+//
+// Replaces the TensorFlow/cuDNN kernels behind keras SeparableConv2D's pointwise step, Conv2D(1x1)
+// and Dense (call sites spnet/models.py:357-359, 388).  Arithmetic is exact f32: the
+// v_mfma_f32_32x32x2_f32 instruction is a k-ordered fmaf chain (one rounding per product), so the
+// result equals a plain f32 dot product evaluated in k order.
+//
+// Operand layouts ("major" = which index is contiguous in memory):
+//   A  K_MAJOR   : A(m,k) = A[m*lda + k]      (activations [pixels][Cin]: forward, dgrad)
+//      OUT_MAJOR : A(m,k) = A[k*lda + m]      (wgrad: A = X^T, read without a transpose pass)
+//   B  OUT_MAJOR : B(k,n) = B[k*ldb + n]      (weights [Cin][Cout]: forward; dY in wgrad)
+//      K_MAJOR   : B(k,n) = B[n*ldb + k]      (dgrad: B = W^T read in place)
+// LDS image of both operands is [k][row] with row contiguous, so that the 32 lanes of an MFMA
+// operand fetch read 32 consecutive dwords (conflict-free ds_read_b32).
+//
+// Split-K: grid.z slices write fp32 slabs to a workspace, a second kernel sums them in slice order
+// (deterministic; no float atomics).
+#include "common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+enum { SP_K_MAJOR = 0, SP_OUT_MAJOR = 1 };
+
+template <int BR, int BK, int MAJ>
+struct TileStage {
+  static constexpr int TOTAL = BR * BK / 4;            // float4 per tile
+  static constexpr int NV = (TOTAL + 255) / 256;       // float4 per thread
+  static constexpr int LD = BR + 4;
+  float4 v[NV];
+
+  __device__ __forceinline__ void load(const float* __restrict__ P, int ld, int r0, int R, int k0,
+                                       int kend, int tid) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int f = tid + i * 256;
+      float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
+      if ((TOTAL % 256 == 0) || f < TOTAL) {
+        if (MAJ == SP_OUT_MAJOR) {
+          const int k = f / (BR / 4), r4 = f % (BR / 4);
+          const int gk = k0 + k, gr = r0 + r4 * 4;
+          if (gk < kend && gr < R) val = *reinterpret_cast<const float4*>(P + (long)gk * ld + gr);
+        } else {
+          const int r = f / (BK / 4), kq = f % (BK / 4);
+          const int gr = r0 + r, gk = k0 + kq * 4;
+          if (gr < R && gk < kend) val = *reinterpret_cast<const float4*>(P + (long)gr * ld + gk);
+        }
+      }
+      v[i] = val;
+    }
+  }
+
+  __device__ __forceinline__ void store(float* __restrict__ S, int tid) const {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int f = tid + i * 256;
+      if ((TOTAL % 256 == 0) || f < TOTAL) {
+        if (MAJ == SP_OUT_MAJOR) {
+          const int k = f / (BR / 4), r4 = f % (BR / 4);
+          *reinterpret_cast<float4*>(S + k * LD + r4 * 4) = v[i];
+        } else {
+          const int r = f / (BK / 4), kq = f % (BK / 4);
+          float* s = S + (kq * 4) * LD + r;
+          s[0] = v[i].x;
+          s[LD] = v[i].y;
+          s[2 * LD] = v[i].z;
+          s[3 * LD] = v[i].w;
+        }
+      }
+    }
+  }
+};
+
+template <int BM, int BN, int BK, int WM, int WN, int AMAJ, int BMAJ>
+__global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__ A, int lda,
+                                                       const float* __restrict__ B, int ldb,
+                                                       float* __restrict__ C, int ldc, int M, int N,
+                                                       int K, int k_chunk, long slab_stride,
+                                                       int tiles_m, int tiles_n, int nsplit,
+                                                       const float* __restrict__ bias) {
+  static_assert(WM * WN == 4, "4 waves per workgroup");
+  constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+  static_assert(TM >= 1 && TN >= 1, "wave tile");
+  constexpr int LDA = BM + 4, LDB = BN + 4;
+  constexpr int STAGE = BK * (LDA + LDB);
+  __shared__ __attribute__((aligned(16))) float smem[2 * STAGE];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN, wn = wave % WN;
+
+  const int nblk = tiles_m * tiles_n * nsplit;
+  int lid = xcd_remap(blockIdx.x, nblk);
+  const int tn = lid % tiles_n;
+  lid /= tiles_n;
+  const int tm = lid % tiles_m;
+  const int z = lid / tiles_m;
+
+  const int m0 = tm * BM, n0 = tn * BN;
+  const int kbeg = z * k_chunk;
+  const int kend = min(K, kbeg + k_chunk);
+  const int nt = (kend - kbeg + BK - 1) / BK;
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  TileStage<BM, BK, AMAJ> sa;
+  TileStage<BN, BK, BMAJ> sb;
+
+  if (nt > 0) {
+    sa.load(A, lda, m0, M, kbeg, kend, tid);
+    sb.load(B, ldb, n0, N, kbeg, kend, tid);
+    sa.store(smem, tid);
+    sb.store(smem + BK * LDA, tid);
+  }
+  __syncthreads();
+
+  for (int t = 0; t < nt; ++t) {
+    float* cur = smem + (t & 1) * STAGE;
+    float* nxt = smem + ((t + 1) & 1) * STAGE;
+    const bool more = (t + 1 < nt);
+    if (more) {
+      sa.load(A, lda, m0, M, kbeg + (t + 1) * BK, kend, tid);
+      sb.load(B, ldb, n0, N, kbeg + (t + 1) * BK, kend, tid);
+    }
+    const float* as = cur + wm * (TM * 32) + (lane & 31);
+    const float* bs = cur + BK * LDA + wn * (TN * 32) + (lane & 31);
+#pragma unroll
+    for (int kk = 0; kk < BK; kk += 2) {
+      const int ka = kk + (lane >> 5);
+      float a[TM], b[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) a[i] = as[ka * LDA + i * 32];
+#pragma unroll
+      for (int j = 0; j < TN; ++j) b[j] = bs[ka * LDB + j * 32];
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+    if (more) {
+      sa.store(nxt, tid);
+      sb.store(nxt + BK * LDA, tid);
+    }
+    __syncthreads();
+  }
+
+  float* Cz = C + (long)z * slab_stride;
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int col = n0 + wn * (TN * 32) + j * 32 + (lane & 31);
+      const int rbase = m0 + wm * (TM * 32) + i * 32 + 4 * (lane >> 5);
+      if (col < N) {
+        const float bv = bias ? bias[col] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = rbase + (r & 3) + 8 * (r >> 2);
+          if (row < M) Cz[(long)row * ldc + col] = acc[i][j][r] + bv;
+        }
+      }
+    }
+  }
+}
+
+// out[row*ldc + col] = sum_z ws[z*M*N + row*N + col] (+ bias[col]); N % 4 == 0, ldc % 4 == 0.
+__global__ __launch_bounds__(256) void reduce_slabs_kernel(const float* __restrict__ ws, int nslab,
+                                                           int M, int N, float* __restrict__ out,
+                                                           int ldc, const float* __restrict__ bias) {
+  const long total4 = (long)M * N / 4;
+  const long mn = (long)M * N;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total4;
+       i += (long)gridDim.x * blockDim.x) {
+    const long e = i * 4;
+    const int row = (int)(e / N), col = (int)(e % N);
+    float4 s = *reinterpret_cast<const float4*>(ws + e);
+    for (int zz = 1; zz < nslab; ++zz) {
+      const float4 t = *reinterpret_cast<const float4*>(ws + (long)zz * mn + e);
+      s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
+    }
+    if (bias) {
+      const float4 b = *reinterpret_cast<const float4*>(bias + col);
+      s.x += b.x; s.y += b.y; s.z += b.z; s.w += b.w;
+    }
+    *reinterpret_cast<float4*>(out + (long)row * ldc + col) = s;
+  }
+}
+
+template <int BM, int BN, int WM, int WN>
+static int launch_tile(const float* A, int amaj, int lda, const float* B, int bmaj, int ldb, float* C,
+                       int ldc, int M, int N, int K, int nsplit, int k_chunk, long slab_stride,
+                       const float* bias, hipStream_t st) {
+  constexpr int BK = 16;
+  const int tm = spnet_cdiv(M, BM), tn = spnet_cdiv(N, BN);
+  dim3 grid(tm * tn * nsplit), block(256);
+#define SP_LAUNCH(AM, BMJ)                                                                          \
+  hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, BK, WM, WN, AM, BMJ>), grid, block, 0, st, A, lda, B, \
+                     ldb, C, ldc, M, N, K, k_chunk, slab_stride, tm, tn, nsplit, bias)
+  if (amaj == SP_K_MAJOR && bmaj == SP_OUT_MAJOR) SP_LAUNCH(SP_K_MAJOR, SP_OUT_MAJOR);
+  else if (amaj == SP_K_MAJOR && bmaj == SP_K_MAJOR) SP_LAUNCH(SP_K_MAJOR, SP_K_MAJOR);
+  else if (amaj == SP_OUT_MAJOR && bmaj == SP_OUT_MAJOR) SP_LAUNCH(SP_OUT_MAJOR, SP_OUT_MAJOR);
+  else return (int)hipErrorInvalidValue;
+#undef SP_LAUNCH
+  return 0;
+}
+
+// Tile ids: 0 = auto, 1 = 128x128, 2 = 128x64, 3 = 64x64, 4 = 32x128
+static void tile_dims(int tile, int* bm, int* bn) {
+  switch (tile) {
+    case 1: *bm = 128; *bn = 128; break;
+    case 2: *bm = 128; *bn = 64; break;
+    case 3: *bm = 64; *bn = 64; break;
+    default: *bm = 32; *bn = 128; break;
+  }
+}
+
+static int pick_tile(int M, int N) {
+  if (M <= 32) return 4;
+  // cost ~ (rounds over 2 resident workgroups per CU) x tile area / tile efficiency
+  const double eff[4] = {0.0, 1.00, 0.92, 0.80};
+  int best = 1;
+  double best_cost = 1e300;
+  for (int t = 1; t <= 3; ++t) {
+    int bm, bn;
+    tile_dims(t, &bm, &bn);
+    const double blocks = (double)spnet_cdiv(M, bm) * spnet_cdiv(N, bn);
+    double rounds = blocks / 512.0;
+    rounds = rounds < 1.0 ? 1.0 : (double)(long)(rounds + 0.999);
+    const double cost = rounds * bm * bn / eff[t];
+    if (cost < best_cost) { best_cost = cost; best = t; }
+  }
+  return best;
+}
+
+extern "C" int spnet_gemm_f32(const float* A, int a_major, int lda, const float* B, int b_major,
+                              int ldb, float* C, int ldc, int M, int N, int K, int split_k,
+                              float* workspace, long ws_floats, const float* bias, int tile,
+                              void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  if (M <= 0 || N <= 0 || K <= 0) return (int)hipErrorInvalidValue;
+  if ((lda & 3) || (ldb & 3) || (N & 3) || (ldc & 3)) return (int)hipErrorInvalidValue;
+  if ((a_major == SP_K_MAJOR || b_major == SP_K_MAJOR) && (K & 3)) return (int)hipErrorInvalidValue;
+  if (a_major == SP_OUT_MAJOR && (M & 3)) return (int)hipErrorInvalidValue;
+  if (((uintptr_t)A | (uintptr_t)B | (uintptr_t)C) & 15) return (int)hipErrorInvalidValue;
+  if (tile <= 0 || tile > 4) tile = pick_tile(M, N);
+  int bm, bn;
+  tile_dims(tile, &bm, &bn);
+  const long tiles = (long)spnet_cdiv(M, bm) * spnet_cdiv(N, bn);
+  const int BK = 16;
+  int nsplit = split_k;
+  if (nsplit <= 0) {  // auto: enough workgroups for ~2 per CU, each slice at least 4 K-tiles deep
+    nsplit = 1;
+    if (tiles < 512 && workspace) {
+      long want = (512 + tiles - 1) / tiles;
+      long maxk = K / (BK * 4);
+      if (maxk < 1) maxk = 1;
+      if (want > maxk) want = maxk;
+      long fit = ws_floats / ((long)M * N);
+      if (want > fit) want = fit;
+      if (want > 1) nsplit = (int)want;
+    }
+  }
+  int k_chunk = ((K + nsplit - 1) / nsplit + BK - 1) / BK * BK;
+  nsplit = (K + k_chunk - 1) / k_chunk;
+  float* out = C;
+  int out_ld = ldc;
+  long slab = 0;
+  const float* kbias = bias;
+  if (nsplit > 1) {
+    if (!workspace || (long)nsplit * M * N > ws_floats) return (int)hipErrorInvalidValue;
+    if (((uintptr_t)workspace) & 15) return (int)hipErrorInvalidValue;
+    out = workspace;
+    out_ld = N;
+    slab = (long)M * N;
+    kbias = nullptr;
+  }
+  int rc;
+  switch (tile) {
+    case 1: rc = launch_tile<128, 128, 2, 2>(A, a_major, lda, B, b_major, ldb, out, out_ld, M, N, K, nsplit, k_chunk, slab, kbias, st); break;
+    case 2: rc = launch_tile<128, 64, 2, 2>(A, a_major, lda, B, b_major, ldb, out, out_ld, M, N, K, nsplit, k_chunk, slab, kbias, st); break;
+    case 3: rc = launch_tile<64, 64, 2, 2>(A, a_major, lda, B, b_major, ldb, out, out_ld, M, N, K, nsplit, k_chunk, slab, kbias, st); break;
+    default: rc = launch_tile<32, 128, 1, 4>(A, a_major, lda, B, b_major, ldb, out, out_ld, M, N, K, nsplit, k_chunk, slab, kbias, st); break;
+  }
+  if (rc) return rc;
+  if (nsplit > 1) {
+    const long total4 = (long)M * N / 4;
+    hipLaunchKernelGGL(reduce_slabs_kernel, dim3(spnet_ew_grid(total4, 256)), dim3(256), 0, st,
+                       workspace, nsplit, M, N, C, ldc, bias);
+  }
+  SPNET_RETURN_LAUNCH_STATUS();
+}
+
+// ------------------------------------------------------------------------------------------------
+// im2col / col2im for block1_conv2 (3x3, stride 1, VALID, Cin % 4 == 0) and the stride-2 row
+// gather / scatter of the 1x1 residual convs (TF SAME on a 1x1/s2 conv samples the even pixels).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void im2col3x3_kernel(const float* __restrict__ x,
+                                                        float* __restrict__ col, int Bn, int H, int W,
+                                                        int C, int OH, int OW) {
+  const int c4n = C / 4;
+  const long total = (long)Bn * OH * OW * 9 * c4n;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (long)gridDim.x * blockDim.x) {
+    const int c4 = (int)(i % c4n);
+    long t = i / c4n;
+    const int tap = (int)(t % 9);
+    t /= 9;
+    const int ow = (int)(t % OW);
+    t /= OW;
+    const int oh = (int)(t % OH);
+    const int b = (int)(t / OH);
+    const int kh = tap / 3, kw = tap % 3;
+    const float4 v = *reinterpret_cast<const float4*>(
+        x + (((long)b * H + oh + kh) * W + ow + kw) * C + c4 * 4);
+    *reinterpret_cast<float4*>(col + i * 4) = v;
+  }
+}
+
+__global__ __launch_bounds__(256) void col2im3x3_kernel(const float* __restrict__ dcol,
+                                                        float* __restrict__ dx, int Bn, int H, int W,
+                                                        int C, int OH, int OW) {
+  const int c4n = C / 4;
+  const long total = (long)Bn * H * W * c4n;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (long)gridDim.x * blockDim.x) {
+    const int c4 = (int)(i % c4n);
+    long t = i / c4n;
+    const int w = (int)(t % W);
+    t /= W;
+    const int h = (int)(t % H);
+    const int b = (int)(t / H);
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh) {
+      const int oh = h - kh;
+      if (oh < 0 || oh >= OH) continue;
+#pragma unroll
+      for (int kw = 0; kw < 3; ++kw) {
+        const int ow = w - kw;
+        if (ow < 0 || ow >= OW) continue;
+        const float4 v = *reinterpret_cast<const float4*>(
+            dcol + (((long)b * OH + oh) * OW + ow) * (9L * C) + (kh * 3 + kw) * C + c4 * 4);
+        s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+      }
+    }
+    *reinterpret_cast<float4*>(dx + i * 4) = s;
+  }
+}
+
+__global__ __launch_bounds__(256) void gather_s2_kernel(const float* __restrict__ x,
+                                                        float* __restrict__ xs, int Bn, int H, int W,
+                                                        int C, int OH, int OW) {
+  const int c4n = C / 4;
+  const long total = (long)Bn * OH * OW * c4n;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (long)gridDim.x * blockDim.x) {
+    const int c4 = (int)(i % c4n);
+    long t = i / c4n;
+    const int ow = (int)(t % OW);
+    t /= OW;
+    const int oh = (int)(t % OH);
+    const int b = (int)(t / OH);
+    *reinterpret_cast<float4*>(xs + i * 4) = *reinterpret_cast<const float4*>(
+        x + (((long)b * H + 2 * oh) * W + 2 * ow) * C + c4 * 4);
+  }
+}
+
+// dx[b, 2oh, 2ow, :] += dxs[b, oh, ow, :]   (each destination touched by exactly one thread)
+__global__ __launch_bounds__(256) void scatter_add_s2_kernel(const float* __restrict__ dxs,
+                                                             float* __restrict__ dx, int Bn, int H,
+                                                             int W, int C, int OH, int OW) {
+  const int c4n = C / 4;
+  const long total = (long)Bn * OH * OW * c4n;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (long)gridDim.x * blockDim.x) {
+    const int c4 = (int)(i % c4n);
+    long t = i / c4n;
+    const int ow = (int)(t % OW);
+    t /= OW;
+    const int oh = (int)(t % OH);
+    const int b = (int)(t / OH);
+    float4* d = reinterpret_cast<float4*>(dx + (((long)b * H + 2 * oh) * W + 2 * ow) * C + c4 * 4);
+    const float4 g = *reinterpret_cast<const float4*>(dxs + i * 4);
+    float4 v = *d;
+    v.x += g.x; v.y += g.y; v.z += g.z; v.w += g.w;
+    *d = v;
+  }
+}
+
+extern "C" int spnet_im2col3x3(const float* x, float* col, int B, int H, int W, int C, void* stream) {
+  if (C & 3) return (int)hipErrorInvalidValue;
+  const int OH = H - 2, OW = W - 2;
+  const long total = (long)B * OH * OW * 9 * (C / 4);
+  hipLaunchKernelGGL(im2col3x3_kernel, dim3(spnet_ew_grid(total, 256)), dim3(256), 0,
+                     (hipStream_t)stream, x, col, B, H, W, C, OH, OW);
+  SPNET_RETURN_LAUNCH_STATUS();
+}
+
+extern "C" int spnet_col2im3x3(const float* dcol, float* dx, int B, int H, int W, int C, void* stream) {
+  if (C & 3) return (int)hipErrorInvalidValue;
+  const int OH = H - 2, OW = W - 2;
+  const long total = (long)B * H * W * (C / 4);
+  hipLaunchKernelGGL(col2im3x3_kernel, dim3(spnet_ew_grid(total, 256)), dim3(256), 0,
+                     (hipStream_t)stream, dcol, dx, B, H, W, C, OH, OW);
+  SPNET_RETURN_LAUNCH_STATUS();
+}
+
+extern "C" int spnet_gather_s2(const float* x, float* xs, int B, int H, int W, int C, void* stream) {
+  if (C & 3) return (int)hipErrorInvalidValue;
+  const int OH = (H + 1) / 2, OW = (W + 1) / 2;
+  const long total = (long)B * OH * OW * (C / 4);
+  hipLaunchKernelGGL(gather_s2_kernel, dim3(spnet_ew_grid(total, 256)), dim3(256), 0,
+                     (hipStream_t)stream, x, xs, B, H, W, C, OH, OW);
+  SPNET_RETURN_LAUNCH_STATUS();
+}
+
+extern "C" int spnet_scatter_add_s2(const float* dxs, float* dx, int B, int H, int W, int C,
+                                    void* stream) {
+  if (C & 3) return (int)hipErrorInvalidValue;
+  const int OH = (H + 1) / 2, OW = (W + 1) / 2;
+  const long total = (long)B * OH * OW * (C / 4);
+  hipLaunchKernelGGL(scatter_add_s2_kernel, dim3(spnet_ew_grid(total, 256)), dim3(256), 0,
+                     (hipStream_t)stream, dxs, dx, B, H, W, C, OH, OW);
+  SPNET_RETURN_LAUNCH_STATUS();
+}

@@ -1,0 +1,169 @@
+// Pooling layers of the hot path, NHWC fp32.
+//   * MaxPooling2D((3,3), strides 2, padding 'same') of Xception blocks 2/3/4/13, fused with the
+//     residual add that follows it (keras.applications.Xception, call site spnet/models.py:357-359).
+//     TF SAME: pad_total = max((out-1)*2+3-in, 0), floor(pad_total/2) before, the rest after
+//     (so an even extent pads 0 before / 1 after), padding value -inf.
+//   * AveragePooling2D((2,2)) of the stem (spnet/models.py:323,337): VALID, floor(in/2).
+#include "common.h"
+
+// y = maxpool(x) + residual ; idx = argmax tap (kh*3+kw), one byte per element, first max wins.
+__global__ __launch_bounds__(256) void maxpool_add_fwd_kernel(const float* __restrict__ x,
+                                                              const float* __restrict__ residual,
+                                                              float* __restrict__ y,
+                                                              uint32_t* __restrict__ idx4, int Bn,
+                                                              int H, int W, int C, int OH, int OW,
+                                                              int pt, int pl) {
+  const int c4n = C >> 2;
+  const long total = (long)Bn * OH * OW * c4n;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (long)gridDim.x * blockDim.x) {
+    const int c4 = (int)(i % c4n);
+    long t = i / c4n;
+    const int ow = (int)(t % OW);
+    t /= OW;
+    const int oh = (int)(t % OH);
+    const int b = (int)(t / OH);
+    const float ninf = -__builtin_huge_valf();
+    float4 m = make_float4(ninf, ninf, ninf, ninf);
+    uint32_t ix = 0, iy = 0, iz = 0, iw = 0;
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh) {
+      const int h = oh * 2 - pt + kh;
+      if (h < 0 || h >= H) continue;
+#pragma unroll
+      for (int kw = 0; kw < 3; ++kw) {
+        const int w = ow * 2 - pl + kw;
+        if (w < 0 || w >= W) continue;
+        const float4 v = *reinterpret_cast<const float4*>(x + (((long)b * H + h) * W + w) * C + c4 * 4);
+        const uint32_t tap = kh * 3 + kw;
+        if (v.x > m.x) { m.x = v.x; ix = tap; }
+        if (v.y > m.y) { m.y = v.y; iy = tap; }
+        if (v.z > m.z) { m.z = v.z; iz = tap; }
+        if (v.w > m.w) { m.w = v.w; iw = tap; }
+      }
+    }
+    if (residual) {
+      const float4 r = *reinterpret_cast<const float4*>(residual + i * 4);
+      m.x += r.x; m.y += r.y; m.z += r.z; m.w += r.w;
+    }
+    *reinterpret_cast<float4*>(y + i * 4) = m;
+    if (idx4) idx4[i] = ix | (iy << 8) | (iz << 16) | (iw << 24);
+  }
+}
+
+// dx[b,h,w,c] = sum over the (<=4) windows that contain (h,w) and whose argmax is (h,w) of dy.
+__global__ __launch_bounds__(256) void maxpool_bwd_kernel(const float* __restrict__ dy,
+                                                          const uint32_t* __restrict__ idx4,
+                                                          float* __restrict__ dx, int Bn, int H, int W,
+                                                          int C, int OH, int OW, int pt, int pl) {
+  const int c4n = C >> 2;
+  const long total = (long)Bn * H * W * c4n;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (long)gridDim.x * blockDim.x) {
+    const int c4 = (int)(i % c4n);
+    long t = i / c4n;
+    const int w = (int)(t % W);
+    t /= W;
+    const int h = (int)(t % H);
+    const int b = (int)(t / H);
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    // windows: oh*2 - pt <= h <= oh*2 - pt + 2
+    const int oh_lo = max(0, (h + pt - 2 + 1) >> 1), oh_hi = min(OH - 1, (h + pt) >> 1);
+    const int ow_lo = max(0, (w + pl - 2 + 1) >> 1), ow_hi = min(OW - 1, (w + pl) >> 1);
+    for (int oh = oh_lo; oh <= oh_hi; ++oh) {
+      const uint32_t kh = h - (oh * 2 - pt);
+      for (int ow = ow_lo; ow <= ow_hi; ++ow) {
+        const uint32_t tap = kh * 3 + (w - (ow * 2 - pl));
+        const long o = (((long)b * OH + oh) * OW + ow) * c4n + c4;
+        const uint32_t id = idx4[o];
+        const float4 g = *reinterpret_cast<const float4*>(dy + o * 4);
+        if ((id & 0xffu) == tap) s.x += g.x;
+        if (((id >> 8) & 0xffu) == tap) s.y += g.y;
+        if (((id >> 16) & 0xffu) == tap) s.z += g.z;
+        if ((id >> 24) == tap) s.w += g.w;
+      }
+    }
+    *reinterpret_cast<float4*>(dx + i * 4) = s;
+  }
+}
+
+__global__ __launch_bounds__(256) void avgpool2_fwd_kernel(const float* __restrict__ x,
+                                                           float* __restrict__ y, int Bn, int H, int W,
+                                                           int C, int OH, int OW) {
+  const long total = (long)Bn * OH * OW * C;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C);
+    long t = i / C;
+    const int ow = (int)(t % OW);
+    t /= OW;
+    const int oh = (int)(t % OH);
+    const int b = (int)(t / OH);
+    const float* p = x + (((long)b * H + 2 * oh) * W + 2 * ow) * C + c;
+    y[i] = ((p[0] + p[C]) + (p[(long)W * C] + p[(long)W * C + C])) * 0.25f;
+  }
+}
+
+__global__ __launch_bounds__(256) void avgpool2_bwd_kernel(const float* __restrict__ dy,
+                                                           float* __restrict__ dx, int Bn, int H, int W,
+                                                           int C, int OH, int OW) {
+  const long total = (long)Bn * H * W * C;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C);
+    long t = i / C;
+    const int w = (int)(t % W);
+    t /= W;
+    const int h = (int)(t % H);
+    const int b = (int)(t / H);
+    const int oh = h >> 1, ow = w >> 1;
+    dx[i] = (oh < OH && ow < OW) ? 0.25f * dy[(((long)b * OH + oh) * OW + ow) * C + c] : 0.f;
+  }
+}
+
+static void same_pool_geom(int in, int* out, int* pad_before) {
+  *out = (in + 1) / 2;
+  int total = (*out - 1) * 2 + 3 - in;
+  if (total < 0) total = 0;
+  *pad_before = total / 2;
+}
+
+extern "C" int spnet_maxpool3x3s2_add_fwd(const float* x, const float* residual, float* y,
+                                          uint32_t* idx4, int B, int H, int W, int C, void* stream) {
+  if (C & 3) return (int)hipErrorInvalidValue;
+  int OH, OW, pt, pl;
+  same_pool_geom(H, &OH, &pt);
+  same_pool_geom(W, &OW, &pl);
+  const long total = (long)B * OH * OW * (C / 4);
+  hipLaunchKernelGGL(maxpool_add_fwd_kernel, dim3(spnet_ew_grid(total, 256)), dim3(256), 0,
+                     (hipStream_t)stream, x, residual, y, idx4, B, H, W, C, OH, OW, pt, pl);
+  SPNET_RETURN_LAUNCH_STATUS();
+}
+
+extern "C" int spnet_maxpool3x3s2_bwd(const float* dy, const uint32_t* idx4, float* dx, int B, int H,
+                                      int W, int C, void* stream) {
+  if (C & 3) return (int)hipErrorInvalidValue;
+  int OH, OW, pt, pl;
+  same_pool_geom(H, &OH, &pt);
+  same_pool_geom(W, &OW, &pl);
+  const long total = (long)B * H * W * (C / 4);
+  hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(spnet_ew_grid(total, 256)), dim3(256), 0,
+                     (hipStream_t)stream, dy, idx4, dx, B, H, W, C, OH, OW, pt, pl);
+  SPNET_RETURN_LAUNCH_STATUS();
+}
+
+extern "C" int spnet_avgpool2_fwd(const float* x, float* y, int B, int H, int W, int C, void* stream) {
+  const int OH = H / 2, OW = W / 2;
+  const long total = (long)B * OH * OW * C;
+  hipLaunchKernelGGL(avgpool2_fwd_kernel, dim3(spnet_ew_grid(total, 256)), dim3(256), 0,
+                     (hipStream_t)stream, x, y, B, H, W, C, OH, OW);
+  SPNET_RETURN_LAUNCH_STATUS();
+}
+
+extern "C" int spnet_avgpool2_bwd(const float* dy, float* dx, int B, int H, int W, int C, void* stream) {
+  const int OH = H / 2, OW = W / 2;
+  const long total = (long)B * H * W * C;
+  hipLaunchKernelGGL(avgpool2_bwd_kernel, dim3(spnet_ew_grid(total, 256)), dim3(256), 0,
+                     (hipStream_t)stream, dy, dx, B, H, W, C, OH, OW);
+  SPNET_RETURN_LAUNCH_STATUS();
+}

@@ -1,0 +1,633 @@
+"""Execution engine of the SPNet hot path on one MI355X: a static plan of HIP kernel launches.
+
+The network the reference assembles through Keras (stem spnet/models.py:315-342, Xception backbone
+:357-359, Flatten+Dense head :378-388) has a fixed shape once the frame size and batch are known, so
+instead of a tracing framework the engine lays the whole forward/backward out ONCE as an ordered list
+of nodes, each owning its device buffers, and replays it: every `fwd()` / `bwd()` is a handful of
+launches of the hand-written kernels in csrc/ through the C ABI (include/spnet_hip.h) on the current
+HIP stream.  torch is used for device memory and streams only.
+
+Data layout in HBM
+  activations  NHWC fp32, one buffer per node output (kept for backward when training)
+  parameters   ONE flat fp32 buffer `theta` (+ same-shaped grad / Adam m / Adam v): the ten
+               l2-regularised kernels first (so the fused optimizer applies weight decay to a prefix),
+               every tensor aligned to 64 floats; Keras layouts (conv HWIO, depthwise [3,3,C],
+               pointwise [Cin,Cout], dense [in,out]) so checkpoints map 1:1 onto Keras weight names
+  BN moving statistics in a second flat buffer (non-trainable, not touched by the optimizer)
+"""
+import math
+from collections import OrderedDict
+
+import numpy as np
+import torch
+
+from . import _lib as L
+
+BN_EPS = 1e-3
+BN_MOMENTUM = 0.99
+L2_COEF = 1e-4
+ACT_NONE, ACT_RELU, ACT_LRELU = 0, 1, 2
+K_MAJOR, OUT_MAJOR = 0, 1
+WS_FLOATS = 48 * 1024 * 1024       # shared split-K / partial-sum workspace (192 MiB)
+ALIGN = 64
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def xception_plan():
+    """Keras-2.1.3 Xception(include_top=False) as a list of block descriptions."""
+    blocks = [("entry",)]
+    blocks.append(("strided", 2, 64, 128, 128, False, "conv2d_4", "batch_normalization_4"))
+    blocks.append(("strided", 3, 128, 256, 256, True, "conv2d_5", "batch_normalization_5"))
+    blocks.append(("strided", 4, 256, 728, 728, True, "conv2d_6", "batch_normalization_6"))
+    for b in range(5, 13):
+        blocks.append(("middle", b, 728))
+    blocks.append(("strided", 13, 728, 728, 1024, True, "conv2d_7", "batch_normalization_7"))
+    blocks.append(("exit", 14, 1024, 1536, 2048))
+    return blocks
+
+
+def backbone_out_hw(H, W):
+    h, w = H // 2, W // 2
+    h, w = (h - 3) // 2 + 1, (w - 3) // 2 + 1
+    h, w = h - 2, w - 2
+    for _ in range(4):
+        h, w = (h + 1) // 2, (w + 1) // 2
+    return h, w
+
+
+def param_specs(H, W, n_out=576):
+    """[(keras_name, shape, trainable, l2)] -- l2-regularised kernels first (run-log line 98 of the
+    reference: conv2d_1..3, block1_conv1, block1_conv2, conv2d_4..7, FinalOutput)."""
+    specs = []
+
+    def bn(name, c):
+        specs.append((name + "/gamma", (c,), True, False))
+        specs.append((name + "/beta", (c,), True, False))
+        specs.append((name + "/moving_mean", (c,), False, False))
+        specs.append((name + "/moving_variance", (c,), False, False))
+
+    specs.append(("conv2d_1/kernel", (3, 3, 1, 3), True, True))
+    bn("batch_normalization_1", 3)
+    specs.append(("conv2d_2/kernel", (3, 3, 3, 3), True, True))
+    bn("batch_normalization_2", 3)
+    specs.append(("conv2d_3/kernel", (3, 3, 3, 3), True, True))
+    bn("batch_normalization_3", 3)
+    specs.append(("block1_conv1/kernel", (3, 3, 3, 32), True, True))
+    bn("block1_conv1_bn", 32)
+    specs.append(("block1_conv2/kernel", (3, 3, 32, 64), True, True))
+    bn("block1_conv2_bn", 64)
+
+    def sep(name, cin, cout):
+        specs.append((name + "/depthwise_kernel", (3, 3, cin), True, False))
+        specs.append((name + "/pointwise_kernel", (cin, cout), True, False))
+        bn(name + "_bn", cout)
+
+    for blk in xception_plan():
+        if blk[0] == "strided":
+            _, b, cin, c1, c2, _, cn, bnn = blk
+            specs.append((cn + "/kernel", (1, 1, cin, c2), True, True))
+            bn(bnn, c2)
+            sep("block%d_sepconv1" % b, cin, c1)
+            sep("block%d_sepconv2" % b, c1, c2)
+        elif blk[0] == "middle":
+            for k in (1, 2, 3):
+                sep("block%d_sepconv%d" % (blk[1], k), 728, 728)
+        elif blk[0] == "exit":
+            sep("block14_sepconv1", blk[2], blk[3])
+            sep("block14_sepconv2", blk[3], blk[4])
+    h, w = backbone_out_hw(H, W)
+    specs.append(("FinalOutput/kernel", (h * w * 2048, n_out), True, True))
+    specs.append(("FinalOutput/bias", (n_out,), True, False))
+    return specs
+
+
+def _glorot_fans(name, shape):
+    if name.endswith("depthwise_kernel"):
+        return shape[2] * 9, 9
+    if len(shape) == 4:
+        rf = shape[0] * shape[1]
+        return shape[2] * rf, shape[3] * rf
+    return shape[0], shape[1]
+
+
+class Engine:
+    def __init__(self, H, W, batch, n_out=576, device="cuda:0", loss_type="same", seed=0,
+                 train=True, adam_eps=1e-7):
+        if not torch.cuda.is_available():
+            raise RuntimeError("spnet_amd.Engine needs a HIP device (no CPU fallback)")
+        self.H, self.W, self.B, self.n_out = int(H), int(W), int(batch), int(n_out)
+        self.dev = torch.device(device)
+        self.loss_type = loss_type
+        self.train_capable = bool(train)
+        self.adam_eps = adam_eps
+        self.t = 0                      # optimizer iterations done
+        self.drop_seed = 12345
+        torch.cuda.set_device(self.dev)
+        self._build_params(seed)
+        self._build_graph()
+
+    # ------------------------------------------------------------------ parameters
+    def _build_params(self, seed):
+        specs = param_specs(self.H, self.W, self.n_out)
+        order = [s for s in specs if s[2] and s[3]] + [s for s in specs if s[2] and not s[3]]
+        off = 0
+        self.p_off = OrderedDict()
+        for name, shape, _, l2 in order:
+            n = int(np.prod(shape))
+            self.p_off[name] = (off, n, shape)
+            off += (n + ALIGN - 1) // ALIGN * ALIGN
+            if l2:
+                self.l2_n = off          # prefix (incl. alignment padding, which stays zero)
+        self.n_theta = off
+        s_off = 0
+        self.s_off = OrderedDict()
+        for name, shape, tr, _ in specs:
+            if not tr:
+                n = int(np.prod(shape))
+                self.s_off[name] = (s_off, n, shape)
+                s_off += (n + ALIGN - 1) // ALIGN * ALIGN
+        z = lambda n: torch.zeros(n, device=self.dev, dtype=torch.float32)
+        self.theta = z(self.n_theta)
+        self.stats = z(s_off)
+        if self.train_capable:
+            self.grad, self.m, self.v = z(self.n_theta), z(self.n_theta), z(self.n_theta)
+        self.spec_order = [s[0] for s in specs]
+        self.init_weights(seed)
+
+    def init_weights(self, seed=0):
+        """Keras defaults: glorot_uniform kernels, zeros bias/beta, ones gamma, moving stats 0/1."""
+        g = torch.Generator().manual_seed(seed)
+        host = torch.zeros(self.n_theta, dtype=torch.float32)
+        for name, (off, n, shape) in self.p_off.items():
+            if name.endswith("/gamma"):
+                host[off:off + n] = 1.0
+            elif name.endswith("kernel"):
+                fi, fo = _glorot_fans(name, shape)
+                lim = math.sqrt(6.0 / (fi + fo))
+                host[off:off + n] = ((torch.rand(n, generator=g, dtype=torch.float64) * 2 - 1) * lim).float()
+        self.theta.copy_(host)
+        hs = torch.zeros(self.stats.numel(), dtype=torch.float32)
+        for name, (off, n, _) in self.s_off.items():
+            if name.endswith("moving_variance"):
+                hs[off:off + n] = 1.0
+        self.stats.copy_(hs)
+        if self.train_capable:
+            self.m.zero_()
+            self.v.zero_()
+        self.t = 0
+
+    def P(self, name):
+        off, n, shape = self.p_off[name]
+        return self.theta[off:off + n]
+
+    def G(self, name):
+        off, n, shape = self.p_off[name]
+        return self.grad[off:off + n]
+
+    def S(self, name):
+        off, n, shape = self.s_off[name]
+        return self.stats[off:off + n]
+
+    def state_dict(self):
+        """name -> CPU tensor in Keras layout (trainable + moving statistics)."""
+        out = OrderedDict()
+        for name in self.spec_order:
+            if name in self.p_off:
+                off, n, shape = self.p_off[name]
+                out[name] = self.theta[off:off + n].reshape(shape).cpu().clone()
+            else:
+                off, n, shape = self.s_off[name]
+                out[name] = self.stats[off:off + n].reshape(shape).cpu().clone()
+        return out
+
+    def load_state_dict(self, sd):
+        for name in self.spec_order:
+            t = torch.as_tensor(np.asarray(sd[name]), dtype=torch.float32).reshape(-1)
+            if name in self.p_off:
+                off, n, _ = self.p_off[name]
+                dst = self.theta
+            else:
+                off, n, _ = self.s_off[name]
+                dst = self.stats
+            if t.numel() != n:
+                raise ValueError("shape mismatch for %s: got %d values, need %d" % (name, t.numel(), n))
+            dst[off:off + n].copy_(t.to(self.dev))
+
+    def grad_dict(self):
+        return OrderedDict((name, self.grad[off:off + n].reshape(shape).cpu().clone())
+                           for name, (off, n, shape) in self.p_off.items())
+
+    # ------------------------------------------------------------------ graph construction
+    def new(self, *shape):
+        return torch.empty(shape, device=self.dev, dtype=torch.float32)
+
+    def _build_graph(self):
+        B, H, W = self.B, self.H, self.W
+        tr = self.train_capable
+        self.ws = self.new(WS_FLOATS)
+        self.small = self.new(8 * 4096)          # BN scale/shift + backward coefficient scratch
+        self.nodes = []
+        self.x_in = self.new(B, H, W, 1)
+
+        # ---- stem (spnet/models.py:321-340)
+        H2, W2 = H // 2, W // 2
+        n = self.nodes
+        c1 = SmallConv(self, self.x_in, 1, 3, 1, True, "conv2d_1", need_dx=False); n.append(c1)
+        p1 = AvgPool(self, c1.y, 3); n.append(p1)
+        a1 = BatchNorm(self, p1.y, 3, "batch_normalization_1", ACT_LRELU); n.append(a1)
+        c2 = SmallConv(self, a1.y, 3, 3, 1, True, "conv2d_2"); n.append(c2)
+        a2 = BatchNorm(self, c2.y, 3, "batch_normalization_2", ACT_LRELU); n.append(a2)
+        c3 = SmallConv(self, a2.y, 3, 3, 1, True, "conv2d_3"); n.append(c3)
+        px = AvgPool(self, self.x_in, 1, need_dx=False); n.append(px)
+        s = BatchNorm(self, c3.y, 3, "batch_normalization_3", ACT_NONE, residual=px.y, res_bcast=True); n.append(s)
+        d = Dropout(self, s.y, 0.1); n.append(d)
+        self.stem_out = d.y
+        # ---- Xception entry flow, block 1
+        e1 = SmallConv(self, d.y, 3, 32, 2, False, "block1_conv1"); n.append(e1)
+        b1 = BatchNorm(self, e1.y, 32, "block1_conv1_bn", ACT_RELU); n.append(b1)
+        e2 = Conv3x3Gemm(self, b1.y, 32, 64, "block1_conv2"); n.append(e2)
+        b2 = BatchNorm(self, e2.y, 64, "block1_conv2_bn", ACT_RELU); n.append(b2)
+        x = b2.y
+        for blk in xception_plan():
+            if blk[0] == "strided":
+                _, b, cin, c1_, c2_, first_relu, cn, bnn = blk
+                node = StridedBlock(self, x, b, cin, c1_, c2_, first_relu, cn, bnn)
+            elif blk[0] == "middle":
+                node = MiddleBlock(self, x, blk[1], blk[2])
+            elif blk[0] == "exit":
+                node = ExitBlock(self, x, blk[2], blk[3], blk[4])
+            else:
+                continue
+            n.append(node)
+            x = node.y
+        self.backbone_out = x
+        head = Dense(self, x, self.n_out, "FinalOutput"); n.append(head)
+        self.out = head.y
+        if tr:
+            self.y_true = self.new(B, self.n_out)
+            self.dout = self.new(B, self.n_out)
+            self.loss_parts = self.new(B, 5)
+            self.loss_out = self.new(8)            # center,size,angle,noobj,class,total, l2, total+l2
+            self.sq_scratch = self.new(2048)
+
+    # ------------------------------------------------------------------ execution
+    def forward(self, X=None, training=False):
+        """X: [B,H,W,1] fp32 tensor on the device (or None if self.x_in was filled in place)."""
+        if training and not self.train_capable:
+            raise RuntimeError("engine was built with train=False")
+        if X is not None:
+            self.x_in.copy_(X.reshape(self.x_in.shape))
+        for node in self.nodes:
+            node.fwd(training)
+        return self.out
+
+    def backward(self):
+        """Back-propagates self.dout (filled by loss()) into self.grad."""
+        g = self.dout
+        for node in reversed(self.nodes):
+            g = node.bwd(g)
+
+    def loss(self, Y=None, with_grad=True):
+        if Y is not None:
+            self.y_true.copy_(Y.reshape(self.y_true.shape))
+        L.spnet_ellipse_loss(L.ptr(self.y_true), L.ptr(self.out), L.ptr(self.dout) if with_grad else None,
+                             L.ptr(self.loss_parts), L.ptr(self.loss_out), self.B, self.n_out,
+                             0 if self.loss_type == "same" else 1, _stream())
+        return self.loss_out
+
+    def adam_step(self, lr, grad_scale=1.0):
+        self.t += 1
+        b1, b2 = 0.9, 0.999
+        lr_t = lr * math.sqrt(1.0 - b2 ** self.t) / (1.0 - b1 ** self.t)
+        L.spnet_adam_step(L.ptr(self.theta), L.ptr(self.grad), L.ptr(self.m), L.ptr(self.v), self.n_theta,
+                          self.l2_n, lr_t, b1, b2, self.adam_eps, L2_COEF, grad_scale,
+                          L.ptr(self.sq_scratch), self.loss_out[6:].data_ptr(), _stream())
+
+    def train_step(self, X, Y, lr, grad_hook=None):
+        """augmented batch X -> forward -> custom_loss -> backward -> Adam(+l2).  Returns the device
+        tensor loss_out (no host sync): [center,size,angle,noobj,class,data_total,l2_penalty,_]."""
+        self.drop_seed = (self.drop_seed * 1664525 + 1013904223) & 0xFFFFFFFF
+        self.forward(X, training=True)
+        self.loss(Y)
+        self.backward()
+        scale = 1.0
+        if grad_hook is not None:
+            scale = grad_hook(self.grad)
+        self.adam_step(lr, scale)
+        return self.loss_out
+
+
+# ======================================================================================= nodes
+class Node:
+    def fwd(self, training):
+        raise NotImplementedError
+
+    def bwd(self, g):
+        raise NotImplementedError
+
+
+def _gemm(A, a_major, lda, Bm, b_major, ldb, C, ldc, M, N, K, eng, bias=None, split_k=0, tile=0):
+    L.spnet_gemm_f32(L.ptr(A), a_major, lda, L.ptr(Bm), b_major, ldb, L.ptr(C), ldc, M, N, K, split_k,
+                     L.ptr(eng.ws), WS_FLOATS, L.ptr(bias), tile, _stream())
+
+
+class SmallConv(Node):
+    """Direct 3x3 conv with <=3 input channels (stem convs, block1_conv1)."""
+
+    def __init__(self, eng, x, cin, cout, stride, same, name, need_dx=True):
+        self.e, self.x, self.cin, self.cout, self.stride, self.same = eng, x, cin, cout, stride, int(same)
+        B, H, W, _ = x.shape
+        self.Hin, self.Win = H, W
+        self.OH = H if same else (H - 3) // stride + 1
+        self.OW = W if same else (W - 3) // stride + 1
+        self.y = eng.new(B, self.OH, self.OW, cout)
+        self.w = eng.P(name + "/kernel")
+        self.need_dx = need_dx
+        if eng.train_capable:
+            self.gw = eng.G(name + "/kernel")
+            self.dx = eng.new(*x.shape) if need_dx else None
+
+    def _call(self, op, a, b, out):
+        e = self.e
+        L.spnet_conv3x3_small(op, self.cin, self.cout, self.stride, self.same, L.ptr(a), L.ptr(b), L.ptr(out),
+                              e.B, self.Hin, self.Win, L.ptr(e.ws), WS_FLOATS, _stream())
+
+    def fwd(self, training):
+        self._call(0, self.x, self.w, self.y)
+
+    def bwd(self, g):
+        self._call(2, self.x, g, self.gw)
+        if self.need_dx:
+            self._call(1, g, self.w, self.dx)
+            return self.dx
+        return None
+
+
+class AvgPool(Node):
+    def __init__(self, eng, x, C, need_dx=True):
+        self.e, self.x, self.C = eng, x, C
+        B, H, W, _ = x.shape
+        self.H, self.W = H, W
+        self.y = eng.new(B, H // 2, W // 2, C)
+        self.need_dx = need_dx
+        self.dx = eng.new(*x.shape) if (eng.train_capable and need_dx) else None
+
+    def fwd(self, training):
+        L.spnet_avgpool2_fwd(L.ptr(self.x), L.ptr(self.y), self.e.B, self.H, self.W, self.C, _stream())
+
+    def bwd(self, g):
+        if not self.need_dx:
+            return g      # side branch (the avg-pooled input): nothing upstream needs a gradient
+        L.spnet_avgpool2_bwd(L.ptr(g), L.ptr(self.dx), self.e.B, self.H, self.W, self.C, _stream())
+        return self.dx
+
+
+class BatchNorm(Node):
+    """y = act(BN(x)) (+ residual).  Backward runs in place on the incoming gradient buffer."""
+
+    def __init__(self, eng, x, C, name, act, residual=None, res_bcast=False, bwd_inplace=True):
+        self.e, self.x, self.C, self.act = eng, x, C, act
+        self.M = x.numel() // C
+        self.gamma, self.beta = eng.P(name + "/gamma"), eng.P(name + "/beta")
+        self.mm, self.mv = eng.S(name + "/moving_mean"), eng.S(name + "/moving_variance")
+        self.residual, self.res_bcast = residual, res_bcast
+        self.y = eng.new(*x.shape)
+        if eng.train_capable:
+            self.ggamma, self.gbeta = eng.G(name + "/gamma"), eng.G(name + "/beta")
+            self.save = eng.new(2 * C)
+            self.dx = None if bwd_inplace else eng.new(*x.shape)
+
+    def fwd(self, training):
+        e, C = self.e, self.C
+        ss = e.small[:2 * C]
+        if training:
+            L.spnet_bn_fwd_train(L.ptr(self.x), self.M, C, L.ptr(self.gamma), L.ptr(self.beta), L.ptr(self.mm),
+                                 L.ptr(self.mv), L.ptr(self.save), self.save[C:].data_ptr(), L.ptr(ss), self.act,
+                                 L.ptr(self.residual), int(self.res_bcast), L.ptr(self.y), BN_EPS, BN_MOMENTUM,
+                                 L.ptr(e.ws), _stream())
+        else:
+            L.spnet_bn_fwd_infer(L.ptr(self.x), self.M, C, L.ptr(self.gamma), L.ptr(self.beta), L.ptr(self.mm),
+                                 L.ptr(self.mv), L.ptr(ss), self.act, L.ptr(self.residual), int(self.res_bcast),
+                                 L.ptr(self.y), BN_EPS, _stream())
+
+    def bwd(self, g):
+        e, C = self.e, self.C
+        co = e.small[:3 * C]
+        out = g if self.dx is None else self.dx
+        L.spnet_bn_bwd(L.ptr(self.x), L.ptr(g), self.M, C, L.ptr(self.gamma), L.ptr(self.beta), L.ptr(self.save),
+                       self.save[C:].data_ptr(), self.act, L.ptr(out), L.ptr(self.ggamma), L.ptr(self.gbeta),
+                       L.ptr(co), L.ptr(e.ws), _stream())
+        return out
+
+
+class Dropout(Node):
+    def __init__(self, eng, x, rate):
+        self.e, self.x, self.rate = eng, x, rate
+        self.y = eng.new(*x.shape)
+        self.seed = 0
+
+    def fwd(self, training):
+        if training:
+            self.seed = self.e.drop_seed
+            L.spnet_dropout(L.ptr(self.x), L.ptr(self.y), self.x.numel(), self.seed, self.rate, _stream())
+        else:
+            self.y.copy_(self.x)
+
+    def bwd(self, g):
+        L.spnet_dropout(L.ptr(g), L.ptr(g), g.numel(), self.seed, self.rate, _stream())
+        return g
+
+
+class Pointwise:
+    """1x1 conv as GEMM over flattened pixels: y[M,cout] = x[M,cin] @ W[cin,cout]."""
+
+    def __init__(self, eng, M, cin, cout, wname):
+        self.e, self.M, self.cin, self.cout = eng, M, cin, cout
+        self.w = eng.P(wname)
+        self.gw = eng.G(wname) if eng.train_capable else None
+
+    def fwd(self, x, y):
+        _gemm(x, K_MAJOR, self.cin, self.w, OUT_MAJOR, self.cout, y, self.cout, self.M, self.cout, self.cin, self.e)
+
+    def bwd(self, x, dy, dx):
+        # dW[cin,cout] = x^T dy ; dx[M,cin] = dy W^T
+        _gemm(x, OUT_MAJOR, self.cin, dy, OUT_MAJOR, self.cout, self.gw, self.cout, self.cin, self.cout, self.M, self.e)
+        if dx is not None:
+            _gemm(dy, K_MAJOR, self.cout, self.w, K_MAJOR, self.cout, dx, self.cin, self.M, self.cin, self.cout, self.e)
+
+
+class Conv3x3Gemm(Node):
+    """block1_conv2: 3x3 VALID conv (cin%4==0) as im2col + MFMA GEMM."""
+
+    def __init__(self, eng, x, cin, cout, name):
+        self.e, self.x, self.cin, self.cout = eng, x, cin, cout
+        B, H, W, _ = x.shape
+        self.H, self.W = H, W
+        self.OH, self.OW = H - 2, W - 2
+        self.M = B * self.OH * self.OW
+        self.col = eng.new(self.M, 9 * cin)
+        self.y = eng.new(B, self.OH, self.OW, cout)
+        self.pw = Pointwise(eng, self.M, 9 * cin, cout, name + "/kernel")
+        if eng.train_capable:
+            self.dcol = eng.new(self.M, 9 * cin)
+            self.dx = eng.new(*x.shape)
+
+    def fwd(self, training):
+        L.spnet_im2col3x3(L.ptr(self.x), L.ptr(self.col), self.e.B, self.H, self.W, self.cin, _stream())
+        self.pw.fwd(self.col, self.y)
+
+    def bwd(self, g):
+        self.pw.bwd(self.col, g, self.dcol)
+        L.spnet_col2im3x3(L.ptr(self.dcol), L.ptr(self.dx), self.e.B, self.H, self.W, self.cin, _stream())
+        return self.dx
+
+
+class SepConvBN:
+    """relu? -> depthwise 3x3 -> pointwise -> BN(act) (+residual): one Xception 'sepconv' unit."""
+
+    def __init__(self, eng, x, cin, cout, name, relu_in, act=ACT_NONE, residual=None, bwd_inplace=True):
+        self.e, self.x, self.cin, self.cout, self.relu_in = eng, x, cin, cout, int(relu_in)
+        B, H, W, _ = x.shape
+        self.H, self.W = H, W
+        self.M = B * H * W
+        self.wd = eng.P(name + "/depthwise_kernel")
+        self.z = eng.new(B, H, W, cin)
+        self.yp = eng.new(B, H, W, cout)
+        self.pw = Pointwise(eng, self.M, cin, cout, name + "/pointwise_kernel")
+        self.bn = BatchNorm(eng, self.yp, cout, name + "_bn", act, residual=residual, bwd_inplace=bwd_inplace)
+        self.y = self.bn.y
+        if eng.train_capable:
+            self.gwd = eng.G(name + "/depthwise_kernel")
+            self.dz = eng.new(B, H, W, cin)
+            self.dx = eng.new(B, H, W, cin)
+
+    def fwd(self, training):
+        e = self.e
+        L.spnet_dwconv3x3_fwd(L.ptr(self.x), L.ptr(self.wd), L.ptr(self.z), e.B, self.H, self.W, self.cin,
+                              self.relu_in, _stream())
+        self.pw.fwd(self.z, self.yp)
+        self.bn.fwd(training)
+
+    def bwd(self, g, add=None):
+        """g: gradient wrt this unit's output (overwritten).  Returns gradient wrt the unit's input
+        (pre-ReLU), plus `add` if given."""
+        e = self.e
+        g = self.bn.bwd(g)
+        self.pw.bwd(self.z, g, self.dz)
+        L.spnet_dwconv3x3_bwd_weight(L.ptr(self.x), L.ptr(self.dz), L.ptr(self.gwd), e.B, self.H, self.W,
+                                     self.cin, self.relu_in, L.ptr(e.ws), _stream())
+        L.spnet_dwconv3x3_bwd_data(L.ptr(self.dz), L.ptr(self.wd), L.ptr(self.dx), e.B, self.H, self.W, self.cin,
+                                   self.relu_in, L.ptr(self.x) if self.relu_in else None, L.ptr(add), _stream())
+        return self.dx
+
+
+class MiddleBlock(Node):
+    """Xception blocks 5-12: x + [relu, sepconv, BN] x 3."""
+
+    def __init__(self, eng, x, b, C):
+        self.x = x
+        self.u1 = SepConvBN(eng, x, C, C, "block%d_sepconv1" % b, True)
+        self.u2 = SepConvBN(eng, self.u1.y, C, C, "block%d_sepconv2" % b, True)
+        # u3's BN backward writes to its own buffer: the incoming gradient is also the identity
+        # branch's gradient and is added back in u1's depthwise backward.
+        self.u3 = SepConvBN(eng, self.u2.y, C, C, "block%d_sepconv3" % b, True, residual=x, bwd_inplace=False)
+        self.y = self.u3.y
+
+    def fwd(self, training):
+        self.u1.fwd(training)
+        self.u2.fwd(training)
+        self.u3.fwd(training)
+
+    def bwd(self, g):
+        d = self.u3.bwd(g)                  # g itself survives (out-of-place BN backward)
+        d = self.u2.bwd(d)
+        return self.u1.bwd(d, add=g)
+
+
+class StridedBlock(Node):
+    """Xception blocks 2,3,4,13: maxpool(sepconv x2) + BN(conv1x1/s2)."""
+
+    def __init__(self, eng, x, b, cin, c1, c2, first_relu, conv_name, bn_name):
+        self.e, self.x, self.cin, self.c2 = eng, x, cin, c2
+        B, H, W, _ = x.shape
+        self.H, self.W = H, W
+        OH, OW = (H + 1) // 2, (W + 1) // 2
+        self.OH, self.OW = OH, OW
+        self.Ms = B * OH * OW
+        self.xs = eng.new(B, OH, OW, cin)
+        self.yr = eng.new(B, OH, OW, c2)
+        self.pwr = Pointwise(eng, self.Ms, cin, c2, conv_name + "/kernel")
+        self.bnr = BatchNorm(eng, self.yr, c2, bn_name, ACT_NONE)
+        self.u1 = SepConvBN(eng, x, cin, c1, "block%d_sepconv1" % b, first_relu)
+        self.u2 = SepConvBN(eng, self.u1.y, c1, c2, "block%d_sepconv2" % b, True)
+        self.y = eng.new(B, OH, OW, c2)
+        if eng.train_capable:
+            self.idx = torch.empty(B * OH * OW * (c2 // 4), device=eng.dev, dtype=torch.int32)
+            self.dxs = eng.new(B, OH, OW, cin)
+            self.dpool = eng.new(B, H, W, c2)
+        else:
+            self.idx = None
+
+    def fwd(self, training):
+        e = self.e
+        L.spnet_gather_s2(L.ptr(self.x), L.ptr(self.xs), e.B, self.H, self.W, self.cin, _stream())
+        self.pwr.fwd(self.xs, self.yr)
+        self.bnr.fwd(training)
+        self.u1.fwd(training)
+        self.u2.fwd(training)
+        L.spnet_maxpool3x3s2_add_fwd(L.ptr(self.u2.y), L.ptr(self.bnr.y), L.ptr(self.y),
+                                     L.ptr(self.idx) if training else None, e.B, self.H, self.W, self.c2, _stream())
+
+    def bwd(self, g):
+        e = self.e
+        L.spnet_maxpool3x3s2_bwd(L.ptr(g), L.ptr(self.idx), L.ptr(self.dpool), e.B, self.H, self.W, self.c2, _stream())
+        gr = self.bnr.bwd(g)                # in place: g is dead after the pool backward above
+        self.pwr.bwd(self.xs, gr, self.dxs)
+        d = self.u2.bwd(self.dpool)
+        dx = self.u1.bwd(d)
+        L.spnet_scatter_add_s2(L.ptr(self.dxs), L.ptr(dx), e.B, self.H, self.W, self.cin, _stream())
+        return dx
+
+
+class ExitBlock(Node):
+    """Xception block 14: sepconv-BN-relu x 2 (no pre-activation)."""
+
+    def __init__(self, eng, x, cin, c1, c2):
+        self.u1 = SepConvBN(eng, x, cin, c1, "block14_sepconv1", False, act=ACT_RELU)
+        self.u2 = SepConvBN(eng, self.u1.y, c1, c2, "block14_sepconv2", False, act=ACT_RELU)
+        self.y = self.u2.y
+
+    def fwd(self, training):
+        self.u1.fwd(training)
+        self.u2.fwd(training)
+
+    def bwd(self, g):
+        return self.u1.bwd(self.u2.bwd(g))
+
+
+class Dense(Node):
+    """Flatten (NHWC order) + Dense(n_out) with bias (spnet/models.py:378,388)."""
+
+    def __init__(self, eng, x, n_out, name):
+        self.e, self.x, self.n_out = eng, x, n_out
+        self.K = x.numel() // eng.B
+        self.w, self.b = eng.P(name + "/kernel"), eng.P(name + "/bias")
+        self.y = eng.new(eng.B, n_out)
+        if eng.train_capable:
+            self.gw, self.gb = eng.G(name + "/kernel"), eng.G(name + "/bias")
+            self.dx = eng.new(*x.shape)
+
+    def fwd(self, training):
+        e = self.e
+        _gemm(self.x, K_MAJOR, self.K, self.w, OUT_MAJOR, self.n_out, self.y, self.n_out, e.B, self.n_out, self.K,
+              e, bias=self.b)
+
+    def bwd(self, g):
+        e = self.e
+        _gemm(self.x, OUT_MAJOR, self.K, g, OUT_MAJOR, self.n_out, self.gw, self.n_out, self.K, self.n_out, e.B, e)
+        L.spnet_reduce_rows(L.ptr(g), e.B, self.n_out, L.ptr(self.gb), _stream())
+        _gemm(g, K_MAJOR, self.n_out, self.w, K_MAJOR, self.n_out, self.dx, self.K, e.B, self.K, self.n_out, e)
+        return self.dx

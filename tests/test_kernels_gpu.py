@@ -1,0 +1,350 @@
+"""Per-kernel parity: every HIP kernel, called through the C ABI, against the CPU oracle on the same
+seeded inputs.  fp32 tolerances are written next to each check (the kernels and the oracle sum in
+different orders, so agreement is to rounding, not bitwise, except where noted)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import numpy_ref as R
+from oracle import torch_ref as T
+
+
+@pytest.fixture(scope="module")
+def L():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from spnet_amd import _lib
+    return _lib
+
+
+def dev(a):
+    return torch.as_tensor(np.ascontiguousarray(a), dtype=torch.float32).cuda()
+
+
+def st():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def close(got, want, rtol, atol):
+    np.testing.assert_allclose(got.detach().cpu().double().numpy(), np.asarray(want, np.float64), rtol=rtol, atol=atol)
+
+
+WS = 8 * 1024 * 1024
+
+
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (6144, 728, 728), (100, 728, 256), (37, 64, 288), (32, 576, 4096),
+                                   (1000, 128, 64), (4, 12, 8)])
+@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4])
+def test_gemm_forward_form(L, M, N, K, tile):
+    rs = np.random.RandomState(M + N + K)
+    A, B = rs.randn(M, K).astype(np.float32), rs.randn(K, N).astype(np.float32)
+    bias = rs.randn(N).astype(np.float32)
+    a, b, bi = dev(A), dev(B), dev(bias)
+    c = torch.full((M, N), float("nan"), device="cuda")
+    ws = torch.empty(WS, device="cuda")
+    L.spnet_gemm_f32(a.data_ptr(), 0, K, b.data_ptr(), 1, N, c.data_ptr(), N, M, N, K, 0, ws.data_ptr(), WS,
+                     bi.data_ptr(), tile, st())
+    want = A.astype(np.float64) @ B.astype(np.float64) + bias
+    # f32 fma chain over K terms of magnitude ~1: error ~ 1e-7*sqrt(K)*|terms|
+    close(c, want, rtol=2e-5, atol=2e-5 * np.sqrt(K))
+
+
+@pytest.mark.parametrize("split", [1, 2, 7])
+def test_gemm_split_k_is_deterministic_and_correct(L, split):
+    rs = np.random.RandomState(3)
+    M, N, K = 96, 64, 1000
+    A, B = rs.randn(M, K).astype(np.float32), rs.randn(K, N).astype(np.float32)
+    a, b = dev(A), dev(B)
+    ws = torch.empty(WS, device="cuda")
+    outs = []
+    for _ in range(2):
+        c = torch.empty(M, N, device="cuda")
+        L.spnet_gemm_f32(a.data_ptr(), 0, K, b.data_ptr(), 1, N, c.data_ptr(), N, M, N, K, split, ws.data_ptr(), WS,
+                         None, 3, st())
+        outs.append(c.cpu())
+    assert torch.equal(outs[0], outs[1])
+    close(outs[0], A.astype(np.float64) @ B.astype(np.float64), rtol=2e-5, atol=1e-3)
+
+
+@pytest.mark.parametrize("M,N,K", [(6144, 728, 728), (200, 64, 128), (32, 4096, 576)])
+def test_gemm_dgrad_form(L, M, N, K):
+    # dX[M,N=cin] = dY[M,K=cout] @ W[N,K]^T, W read in place (K-major B)
+    rs = np.random.RandomState(1)
+    dY, W = rs.randn(M, K).astype(np.float32), rs.randn(N, K).astype(np.float32)
+    a, b = dev(dY), dev(W)
+    c = torch.empty(M, N, device="cuda")
+    ws = torch.empty(WS, device="cuda")
+    L.spnet_gemm_f32(a.data_ptr(), 0, K, b.data_ptr(), 0, K, c.data_ptr(), N, M, N, K, 0, ws.data_ptr(), WS, None, 0, st())
+    close(c, dY.astype(np.float64) @ W.astype(np.float64).T, rtol=2e-5, atol=2e-5 * np.sqrt(K))
+
+
+@pytest.mark.parametrize("M,N,K", [(728, 728, 6144), (64, 128, 23250), (4096, 576, 32), (288, 64, 5000)])
+def test_gemm_wgrad_form(L, M, N, K):
+    # dW[M=cin,N=cout] = X[K,M]^T @ dY[K,N]; K (pixels) need not be a multiple of 4
+    rs = np.random.RandomState(2)
+    X, dY = rs.randn(K, M).astype(np.float32), rs.randn(K, N).astype(np.float32)
+    a, b = dev(X), dev(dY)
+    c = torch.empty(M, N, device="cuda")
+    ws = torch.empty(WS, device="cuda")
+    L.spnet_gemm_f32(a.data_ptr(), 1, M, b.data_ptr(), 1, N, c.data_ptr(), N, M, N, K, 0, ws.data_ptr(), WS, None, 0, st())
+    close(c, X.astype(np.float64).T @ dY.astype(np.float64), rtol=2e-5, atol=3e-5 * np.sqrt(K))
+
+
+def test_gemm_rejects_misaligned(L):
+    a = torch.zeros(64, 6, device="cuda")
+    with pytest.raises(L.HipError):
+        L.spnet_gemm_f32(a.data_ptr(), 0, 6, a.data_ptr(), 1, 6, a.data_ptr(), 6, 8, 6, 6, 0, None, 0, None, 0, st())
+
+
+@pytest.mark.parametrize("B,H,W,C", [(2, 12, 16, 728), (3, 7, 5, 64), (1, 93, 125, 128), (2, 6, 8, 1536), (1, 1, 1, 8)])
+@pytest.mark.parametrize("relu_in", [0, 1])
+def test_dwconv(L, B, H, W, C, relu_in):
+    rs = np.random.RandomState(C + H)
+    x = torch.tensor(rs.randn(B, H, W, C), dtype=torch.float32, requires_grad=True)
+    w = torch.tensor(rs.randn(3, 3, C) * 0.3, dtype=torch.float32, requires_grad=True)
+    add = torch.tensor(rs.randn(B, H, W, C), dtype=torch.float32)
+    xin = torch.relu(x) if relu_in else x
+    y = T.dwconv3x3(xin, w)
+    dy = torch.tensor(rs.randn(B, H, W, C), dtype=torch.float32)
+    y.backward(dy)
+    xd, wd, dyd = x.detach().cuda(), w.detach().cuda(), dy.cuda()
+    yd = torch.empty_like(xd)
+    L.spnet_dwconv3x3_fwd(xd.data_ptr(), wd.data_ptr(), yd.data_ptr(), B, H, W, C, relu_in, st())
+    close(yd, y.detach(), rtol=1e-5, atol=1e-5)
+    dxd = torch.empty_like(xd)
+    addd = add.cuda()
+    L.spnet_dwconv3x3_bwd_data(dyd.data_ptr(), wd.data_ptr(), dxd.data_ptr(), B, H, W, C, relu_in,
+                               xd.data_ptr() if relu_in else None, addd.data_ptr(), st())
+    close(dxd, x.grad + add, rtol=1e-5, atol=1e-5)
+    ws = torch.empty(L.spnet_dwconv3x3_bwd_weight_ws(B, H, W, C), device="cuda")
+    dwd = torch.empty(3, 3, C, device="cuda")
+    L.spnet_dwconv3x3_bwd_weight(xd.data_ptr(), dyd.data_ptr(), dwd.data_ptr(), B, H, W, C, relu_in, ws.data_ptr(), st())
+    close(dwd, w.grad, rtol=1e-4, atol=1e-4 * np.sqrt(B * H * W))
+
+
+@pytest.mark.parametrize("M,C", [(6144, 728), (50, 64), (23250, 128), (4096, 3), (7, 2048), (3000, 32)])
+@pytest.mark.parametrize("act", [0, 1, 2])
+def test_batchnorm_train_and_backward(L, M, C, act):
+    rs = np.random.RandomState(M + C + act)
+    x = torch.tensor(rs.randn(M, C) * 1.5 + 0.3, dtype=torch.float32, requires_grad=True)
+    gamma = torch.tensor(rs.rand(C) + 0.5, dtype=torch.float32, requires_grad=True)
+    beta = torch.tensor(rs.randn(C) * 0.2, dtype=torch.float32, requires_grad=True)
+    mm, mv = torch.tensor(rs.randn(C), dtype=torch.float32), torch.tensor(rs.rand(C) + 0.5, dtype=torch.float32)
+    res = torch.tensor(rs.randn(M, C), dtype=torch.float32)
+    mm_o, mv_o = mm.clone(), mv.clone()
+    yb = T.batchnorm(x, gamma, beta, mm_o, mv_o, training=True)
+    y = {0: lambda t: t, 1: torch.relu, 2: lambda t: torch.nn.functional.leaky_relu(t, 0.1)}[act](yb) + res
+    dy = torch.tensor(rs.randn(M, C), dtype=torch.float32)
+    y.backward(dy)
+
+    xd, gd, bd, mmd, mvd, resd, dyd = (t.detach().cuda() for t in (x, gamma, beta, mm, mv, res, dy))
+    save = torch.empty(2 * C + 8, device="cuda")
+    ss = torch.empty(2 * C + 8, device="cuda")
+    ws = torch.empty(L.spnet_bn_ws(M, C), device="cuda")
+    yd = torch.empty_like(xd)
+    L.spnet_bn_fwd_train(xd.data_ptr(), M, C, gd.data_ptr(), bd.data_ptr(), mmd.data_ptr(), mvd.data_ptr(),
+                         save.data_ptr(), save[C:].data_ptr(), ss.data_ptr(), act, resd.data_ptr(), 0, yd.data_ptr(),
+                         1e-3, 0.99, ws.data_ptr(), st())
+    close(yd, y.detach(), rtol=2e-5, atol=2e-5)
+    close(mmd, mm_o, rtol=1e-5, atol=1e-6)
+    close(mvd, mv_o, rtol=1e-5, atol=1e-6)
+    co = torch.empty(3 * C + 8, device="cuda")
+    dxd, dgd, dbd = torch.empty_like(xd), torch.empty(C, device="cuda"), torch.empty(C, device="cuda")
+    L.spnet_bn_bwd(xd.data_ptr(), dyd.data_ptr(), M, C, gd.data_ptr(), bd.data_ptr(), save.data_ptr(),
+                   save[C:].data_ptr(), act, dxd.data_ptr(), dgd.data_ptr(), dbd.data_ptr(), co.data_ptr(),
+                   ws.data_ptr(), st())
+    close(dxd, x.grad, rtol=1e-4, atol=2e-5)
+    close(dgd, gamma.grad, rtol=1e-4, atol=1e-4 * np.sqrt(M))
+    close(dbd, beta.grad, rtol=1e-4, atol=1e-4 * np.sqrt(M))
+    # inference form
+    yi = T.batchnorm(x.detach(), gamma.detach(), beta.detach(), mm, mv, training=False)
+    mm2, mv2 = dev(mm), dev(mv)          # keep the device copies alive across the launch
+    L.spnet_bn_fwd_infer(xd.data_ptr(), M, C, gd.data_ptr(), bd.data_ptr(), mm2.data_ptr(), mv2.data_ptr(),
+                         ss.data_ptr(), 0, None, 0, yd.data_ptr(), 1e-3, st())
+    close(yd, yi, rtol=2e-5, atol=2e-5)
+
+
+def test_batchnorm_broadcast_residual(L):
+    rs = np.random.RandomState(0)
+    M, C = 1000, 3
+    x, res = dev(rs.randn(M, C)), dev(rs.randn(M))
+    g, b = dev(np.ones(C)), dev(np.zeros(C))
+    mm, mv = dev(np.zeros(C)), dev(np.ones(C))
+    ss = torch.empty(16, device="cuda")
+    y = torch.empty_like(x)
+    L.spnet_bn_fwd_infer(x.data_ptr(), M, C, g.data_ptr(), b.data_ptr(), mm.data_ptr(), mv.data_ptr(), ss.data_ptr(),
+                         0, res.data_ptr(), 1, y.data_ptr(), 1e-3, st())
+    want = x.cpu() / np.sqrt(1 + 1e-3) + res.cpu()[:, None]
+    close(y, want, rtol=1e-6, atol=1e-6)
+
+
+@pytest.mark.parametrize("B,H,W,C", [(2, 12, 16, 728), (1, 93, 125, 128), (2, 5, 5, 64), (1, 4, 4, 8), (2, 47, 63, 256)])
+def test_maxpool_add(L, B, H, W, C):
+    rs = np.random.RandomState(H * W)
+    x = torch.tensor(rs.randn(B, H, W, C), dtype=torch.float32, requires_grad=True)
+    OH, OW = (H + 1) // 2, (W + 1) // 2
+    res = torch.tensor(rs.randn(B, OH, OW, C), dtype=torch.float32)
+    y = T.maxpool3x3s2_same(x) + res
+    dy = torch.tensor(rs.randn(B, OH, OW, C), dtype=torch.float32)
+    y.backward(dy)
+    xd = x.detach().cuda()
+    yd = torch.empty(B, OH, OW, C, device="cuda")
+    idx = torch.empty(B * OH * OW * C // 4, dtype=torch.int32, device="cuda")
+    resd, dyd = res.cuda(), dy.cuda()
+    L.spnet_maxpool3x3s2_add_fwd(xd.data_ptr(), resd.data_ptr(), yd.data_ptr(), idx.data_ptr(), B, H, W, C, st())
+    assert torch.equal(yd.cpu(), y.detach())          # max + one add: bit-exact
+    dxd = torch.empty_like(xd)
+    L.spnet_maxpool3x3s2_bwd(dyd.data_ptr(), idx.data_ptr(), dxd.data_ptr(), B, H, W, C, st())
+    close(dxd, x.grad, rtol=1e-6, atol=1e-6)
+
+
+@pytest.mark.parametrize("C", [1, 3])
+def test_avgpool(L, C):
+    rs = np.random.RandomState(C)
+    B, H, W = 2, 9, 14
+    x = torch.tensor(rs.randn(B, H, W, C), dtype=torch.float32, requires_grad=True)
+    y = T.avgpool2(x)
+    dy = torch.tensor(rs.randn(*y.shape), dtype=torch.float32)
+    y.backward(dy)
+    yd = torch.empty(*y.shape, device="cuda")
+    xd, dyd = x.detach().cuda(), dy.cuda()
+    L.spnet_avgpool2_fwd(xd.data_ptr(), yd.data_ptr(), B, H, W, C, st())
+    close(yd, y.detach(), rtol=1e-6, atol=1e-6)
+    dxd = torch.empty(B, H, W, C, device="cuda")
+    L.spnet_avgpool2_bwd(dyd.data_ptr(), dxd.data_ptr(), B, H, W, C, st())
+    close(dxd, x.grad, rtol=1e-6, atol=1e-7)
+
+
+@pytest.mark.parametrize("cin,cout,stride,same,H,W", [(1, 3, 1, 1, 20, 28), (3, 3, 1, 1, 20, 28), (3, 32, 2, 0, 21, 28),
+                                                      (3, 32, 2, 0, 48, 64), (1, 3, 1, 1, 96, 128)])
+def test_small_conv(L, cin, cout, stride, same, H, W):
+    rs = np.random.RandomState(cin * cout + H)
+    B = 2
+    x = torch.tensor(rs.randn(B, H, W, cin), dtype=torch.float32, requires_grad=True)
+    w = torch.tensor(rs.randn(3, 3, cin, cout) * 0.3, dtype=torch.float32, requires_grad=True)
+    y = T.conv2d(x, w, stride, "same" if same else "valid")
+    dy = torch.tensor(rs.randn(*y.shape), dtype=torch.float32)
+    y.backward(dy)
+    ws = torch.empty(WS, device="cuda")
+    xd, wd, dyd = x.detach().cuda(), w.detach().cuda(), dy.cuda()
+    yd = torch.empty(*y.shape, device="cuda")
+    L.spnet_conv3x3_small(0, cin, cout, stride, same, xd.data_ptr(), wd.data_ptr(), yd.data_ptr(), B, H, W, ws.data_ptr(), WS, st())
+    close(yd, y.detach(), rtol=1e-5, atol=1e-5)
+    dxd = torch.empty_like(xd)
+    L.spnet_conv3x3_small(1, cin, cout, stride, same, dyd.data_ptr(), wd.data_ptr(), dxd.data_ptr(), B, H, W, ws.data_ptr(), WS, st())
+    close(dxd, x.grad, rtol=1e-5, atol=2e-5)
+    dwd = torch.empty_like(wd)
+    L.spnet_conv3x3_small(2, cin, cout, stride, same, xd.data_ptr(), dyd.data_ptr(), dwd.data_ptr(), B, H, W, ws.data_ptr(), WS, st())
+    close(dwd, w.grad, rtol=1e-4, atol=1e-4 * np.sqrt(B * H * W))
+
+
+def test_im2col_col2im_gather_scatter(L):
+    rs = np.random.RandomState(9)
+    B, H, W, C = 2, 9, 11, 32
+    x = torch.tensor(rs.randn(B, H, W, C), dtype=torch.float32, requires_grad=True)
+    w = torch.tensor(rs.randn(3, 3, C, 64) * 0.1, dtype=torch.float32)
+    y = T.conv2d(x, w, 1, "valid")
+    dy = torch.tensor(rs.randn(*y.shape), dtype=torch.float32)
+    y.backward(dy)
+    M = B * (H - 2) * (W - 2)
+    col = torch.empty(M, 9 * C, device="cuda")
+    xd = x.detach().cuda()
+    L.spnet_im2col3x3(xd.data_ptr(), col.data_ptr(), B, H, W, C, st())
+    got = (col.cpu().double() @ w.reshape(9 * C, 64).double()).reshape(y.shape)
+    close(got, y.detach(), rtol=1e-5, atol=1e-5)
+    dcol = (dy.reshape(M, 64).double() @ w.reshape(9 * C, 64).double().T).float().cuda()
+    dx = torch.empty(B, H, W, C, device="cuda")
+    L.spnet_col2im3x3(dcol.data_ptr(), dx.data_ptr(), B, H, W, C, st())
+    close(dx, x.grad, rtol=1e-5, atol=1e-5)
+    for (h, w_) in [(9, 11), (8, 6)]:
+        xx = dev(rs.randn(B, h, w_, C))
+        xs = torch.empty(B, (h + 1) // 2, (w_ + 1) // 2, C, device="cuda")
+        L.spnet_gather_s2(xx.data_ptr(), xs.data_ptr(), B, h, w_, C, st())
+        assert torch.equal(xs.cpu(), xx.cpu()[:, ::2, ::2, :])
+        acc = dev(rs.randn(B, h, w_, C))
+        want = acc.cpu().clone()
+        want[:, ::2, ::2, :] += xs.cpu()
+        L.spnet_scatter_add_s2(xs.data_ptr(), acc.data_ptr(), B, h, w_, C, st())
+        assert torch.equal(acc.cpu(), want)
+
+
+@pytest.mark.parametrize("loss_type", ["same", "hybrid"])
+def test_ellipse_loss(L, golden, loss_type):
+    for tag in ("loss", "loss2"):
+        yt, yp = golden[f"{tag}_yt"], golden[f"{tag}_yp"]
+        B = yt.shape[0]
+        g = torch.empty(B, 576, device="cuda")
+        parts, out = torch.empty(B, 5, device="cuda"), torch.empty(6, device="cuda")
+        ytd, ypd = dev(yt), dev(yp)
+        L.spnet_ellipse_loss(ytd.data_ptr(), ypd.data_ptr(), g.data_ptr(), parts.data_ptr(), out.data_ptr(), B, 576,
+                             0 if loss_type == "same" else 1, st())
+        # against the reference's own my_loss output (golden) ...
+        close(out[:5], golden[f"{tag}_{loss_type}_parts"], rtol=1e-5, atol=1e-9)
+        close(out[5], golden[f"{tag}_{loss_type}_total"], rtol=1e-5, atol=1e-9)
+        # ... and the closed-form gradient of the oracle
+        close(g, R.loss_grad(yt, yp, loss_type), rtol=1e-5, atol=1e-9)
+
+
+def test_decode(L):
+    rs = np.random.RandomState(4)
+    Yn = (rs.randn(5, 576) * 0.5).astype(np.float32)
+    gc = R.grid_constants()
+    ynd, md, rd = dev(Yn), dev(gc["means"]), dev(gc["ranges"])
+    for sig in (0, 1):
+        out = torch.empty(5, 72, 7, device="cuda")
+        L.spnet_decode(ynd.data_ptr(), md.data_ptr(), rd.data_ptr(), out.data_ptr(), 5, 576, sig, st())
+        want = R.decode(Yn, "hybrid" if sig else "same")
+        # angle: atan2 in f32 on both sides, allow a few ulp of 180 degrees
+        close(out, want, rtol=1e-5, atol=2e-4)
+
+
+def test_adam_matches_keras_form(L):
+    rs = np.random.RandomState(5)
+    n, l2n = 4096 + 64, 1024
+    p, g = rs.randn(n).astype(np.float32), (rs.randn(n) * 0.1).astype(np.float32)
+    m, v = (rs.randn(n) * 0.01).astype(np.float32), (rs.rand(n) * 0.01).astype(np.float32)
+    pd, gd, md, vd = dev(p), dev(g), dev(m), dev(v)
+    sq, l2out = torch.empty(2048, device="cuda"), torch.empty(2, device="cuda")
+    t, lr = 7, 3e-4
+    import math
+    lr_t = lr * math.sqrt(1 - 0.999 ** t) / (1 - 0.9 ** t)
+    L.spnet_adam_step(pd.data_ptr(), gd.data_ptr(), md.data_ptr(), vd.data_ptr(), n, l2n, lr_t, 0.9, 0.999, 1e-7, 1e-4, 0.5,
+                      sq.data_ptr(), l2out.data_ptr(), st())
+    wp, wm, wv = p.copy(), m.copy(), v.copy()
+    wp[:l2n], wm[:l2n], wv[:l2n] = R.adam_step(p[:l2n], g[:l2n] * 0.5, m[:l2n], v[:l2n], t, lr, l2=1e-4)
+    wp[l2n:], wm[l2n:], wv[l2n:] = R.adam_step(p[l2n:], g[l2n:] * 0.5, m[l2n:], v[l2n:], t, lr)
+    close(pd, wp, rtol=1e-6, atol=1e-7)
+    close(md, wm, rtol=1e-6, atol=1e-8)
+    close(vd, wv, rtol=1e-6, atol=1e-9)
+    close(l2out[0], 1e-4 * np.sum(p[:l2n].astype(np.float64) ** 2), rtol=1e-5, atol=0)
+
+
+def test_dropout_mask_is_reproducible(L):
+    x = torch.ones(100000, device="cuda")
+    y1, y2 = torch.empty_like(x), torch.empty_like(x)
+    L.spnet_dropout(x.data_ptr(), y1.data_ptr(), x.numel(), 77, 0.1, st())
+    L.spnet_dropout(x.data_ptr(), y2.data_ptr(), x.numel(), 77, 0.1, st())
+    assert torch.equal(y1, y2)
+    keep = (y1 > 0).float().mean().item()
+    assert abs(keep - 0.9) < 0.01
+    vals = torch.unique(y1).cpu().numpy()
+    np.testing.assert_allclose(sorted(vals), [0.0, 1.0 / 0.9], rtol=1e-6)
+
+
+def test_warp_affine_identity_flip_translate(L):
+    rs = np.random.RandomState(6)
+    N, H, W, C = 2, 12, 16, 3
+    x = dev(rs.rand(N, H, W, C))
+    out = torch.empty_like(x)
+    ident = dev(np.tile(np.array([1, 0, 0, 0, 1, 0], np.float32), (N, 1)))
+    L.spnet_warp_affine(x.data_ptr(), out.data_ptr(), N, H, W, C, ident.data_ptr(), st())
+    assert torch.equal(out, x)
+    # horizontal flip: sx = (W-1) - x ; translate by (+3,-2): dst(x,y) = src(x-3, y+2)
+    m = dev(np.array([[-1, 0, W - 1, 0, 1, 0], [1, 0, -3, 0, 1, 2]], np.float32))
+    L.spnet_warp_affine(x.data_ptr(), out.data_ptr(), N, H, W, C, m.data_ptr(), st())
+    assert torch.equal(out[0].cpu(), x[0].cpu().flip(1))
+    want = torch.zeros(H, W, C)
+    want[:H - 2, 3:, :] = x[1].cpu()[2:, :W - 3, :]
+    assert torch.equal(out[1].cpu(), want)
