@@ -97,10 +97,11 @@ int spnet_decode(const float* y_norm, const float* means, const float* ranges, f
                  int ncols, int sigmoid_noobj, void* stream);
 
 /* ---- optimizer ---------------------------------------------------------------------------------- */
-/* Keras Adam + l2 on the first l2_n elements (spnet/models.py:494, 47-71).  sq_scratch >= 2048 floats. */
+/* Keras Adam + l2 on the first l2_n elements (spnet/models.py:494, 47-71).  sq_scratch >= 2048 floats.
+ * mask (or NULL): n floats, 0 = frozen element (layer.trainable=False, spnet/models.py:361-373). */
 int spnet_adam_step(float* p, const float* g, float* m, float* v, long n, long l2_n, float lr_t,
-                    float beta1, float beta2, float eps, float l2, float grad_scale, float* sq_scratch,
-                    float* l2_loss_out, void* stream);
+                    float beta1, float beta2, float eps, float l2, float grad_scale, const float* mask,
+                    float* sq_scratch, float* l2_loss_out, void* stream);
 
 /* ---- augmentation (spnet/callbacks.py:272-341, spnet/augmentation.py) ---------------------------- */
 int spnet_minmax(const float* x, int N, long hw, float* mm, void* stream);

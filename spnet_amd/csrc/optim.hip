@@ -7,6 +7,8 @@
 //                                 are the 10 regularised kernels; their penalty gradient 2*l2*w is folded
 //                                 into g, and sum(w^2) over them is reduced on the fly for the logged loss.
 //   grad_scale                    1/world_size after the RCCL all-reduce(sum) of the gradients.
+//   mask (optional)               flat 0/1 array: elements with 0 are frozen (layer.trainable=False,
+//                                 spnet/models.py:361-373), their p/m/v are left untouched.
 // 7 x 4 bytes of HBM traffic per parameter (read p,g,m,v; write p,m,v): pure bandwidth.
 #include "common.h"
 
@@ -14,7 +16,8 @@ __global__ __launch_bounds__(256) void adam_l2_kernel(float* __restrict__ p, con
                                                       float* __restrict__ m, float* __restrict__ v,
                                                       long n, long l2_n, float lr_t, float beta1,
                                                       float beta2, float eps, float l2,
-                                                      float grad_scale, float* __restrict__ sq_partial) {
+                                                      float grad_scale, const float* __restrict__ mask,
+                                                      float* __restrict__ sq_partial) {
   __shared__ float red[4];
   const long n4 = n >> 2;
   float sq = 0.f;
@@ -37,6 +40,13 @@ __global__ __launch_bounds__(256) void adam_l2_kernel(float* __restrict__ p, con
       ma[j] = beta1 * ma[j] + (1.f - beta1) * gj;
       va[j] = beta2 * va[j] + (1.f - beta2) * gj * gj;
       pa[j] = pa[j] - lr_t * ma[j] / (sqrtf(va[j]) + eps);
+    }
+    if (mask) {   // frozen layers (trainable=False): leave p, m, v untouched where mask == 0
+      const float4 k = *reinterpret_cast<const float4*>(mask + e);
+      if (k.x == 0.f) { pa[0] = pv.x; ma[0] = mv.x; va[0] = vv.x; }
+      if (k.y == 0.f) { pa[1] = pv.y; ma[1] = mv.y; va[1] = vv.y; }
+      if (k.z == 0.f) { pa[2] = pv.z; ma[2] = mv.z; va[2] = vv.z; }
+      if (k.w == 0.f) { pa[3] = pv.w; ma[3] = mv.w; va[3] = vv.w; }
     }
     *reinterpret_cast<float4*>(p + e) = make_float4(pa[0], pa[1], pa[2], pa[3]);
     *reinterpret_cast<float4*>(m + e) = make_float4(ma[0], ma[1], ma[2], ma[3]);
@@ -66,13 +76,14 @@ __global__ __launch_bounds__(256) void sum_partials_kernel(const float* __restri
 // l2_loss_out[0] = l2 * sum_{i<l2_n} p_i^2 evaluated BEFORE the update (the penalty of this step's loss).
 extern "C" int spnet_adam_step(float* p, const float* g, float* m, float* v, long n, long l2_n,
                                float lr_t, float beta1, float beta2, float eps, float l2,
-                               float grad_scale, float* sq_scratch, float* l2_loss_out, void* stream) {
+                               float grad_scale, const float* mask, float* sq_scratch,
+                               float* l2_loss_out, void* stream) {
   if (n & 3) return (int)hipErrorInvalidValue;
   hipStream_t st = (hipStream_t)stream;
   long g4 = (n / 4 + 255) / 256;
   int grid = (int)(g4 > ADAM_BLOCKS ? ADAM_BLOCKS : (g4 < 1 ? 1 : g4));
   hipLaunchKernelGGL(adam_l2_kernel, dim3(grid), dim3(256), 0, st, p, g, m, v, n, l2_n, lr_t, beta1,
-                     beta2, eps, l2, grad_scale, sq_scratch);
+                     beta2, eps, l2, grad_scale, mask, sq_scratch);
   if (sq_scratch && l2_loss_out)
     hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, st, sq_scratch, grid, l2, l2_loss_out);
   SPNET_RETURN_LAUNCH_STATUS();

@@ -36,6 +36,32 @@ def _stream():
     return torch.cuda.current_stream().cuda_stream
 
 
+class KernelTimer:
+    """HIP-event timing of selected kernel families on the launch stream (bench.py's roofline leg).
+    Records (family, start, end, algorithmic work) per launch; totals are read after a sync."""
+
+    def __init__(self):
+        self.records = []
+
+    def start(self):
+        e = torch.cuda.Event(enable_timing=True)
+        e.record()
+        return e
+
+    def stop(self, family, start, work):
+        e = torch.cuda.Event(enable_timing=True)
+        e.record()
+        self.records.append((family, start, e, work))
+
+    def totals(self):
+        """{family: (launches, total_ms, total_work)} -- call after torch.cuda.synchronize()."""
+        out = {}
+        for fam, s, e, w in self.records:
+            n, ms, tw = out.get(fam, (0, 0.0, 0.0))
+            out[fam] = (n + 1, ms + s.elapsed_time(e), tw + w)
+        return out
+
+
 def xception_plan():
     """Keras-2.1.3 Xception(include_top=False) as a list of block descriptions."""
     blocks = [("entry",)]
@@ -115,7 +141,7 @@ def _glorot_fans(name, shape):
 
 class Engine:
     def __init__(self, H, W, batch, n_out=576, device="cuda:0", loss_type="same", seed=0,
-                 train=True, adam_eps=1e-7):
+                 train=True, adam_eps=1e-7, share_from=None):
         if not torch.cuda.is_available():
             raise RuntimeError("spnet_amd.Engine needs a HIP device (no CPU fallback)")
         self.H, self.W, self.B, self.n_out = int(H), int(W), int(batch), int(n_out)
@@ -124,9 +150,18 @@ class Engine:
         self.train_capable = bool(train)
         self.adam_eps = adam_eps
         self.t = 0                      # optimizer iterations done
+        self.prof = None                # KernelTimer or None
         self.drop_seed = 12345
         torch.cuda.set_device(self.dev)
-        self._build_params(seed)
+        if share_from is not None:      # second plan (other batch size / inference) over the SAME weights
+            for a in ("p_off", "s_off", "l2_n", "n_theta", "theta", "stats", "spec_order"):
+                setattr(self, a, getattr(share_from, a))
+            if self.train_capable:
+                for a in ("grad", "m", "v"):
+                    setattr(self, a, getattr(share_from, a))
+        else:
+            self._build_params(seed)
+        self.update_mask = None         # optional flat 0/1 tensor: frozen parameters are skipped by Adam
         self._build_graph()
 
     # ------------------------------------------------------------------ parameters
@@ -284,11 +319,14 @@ class Engine:
             node.fwd(training)
         return self.out
 
-    def backward(self):
-        """Back-propagates self.dout (filled by loss()) into self.grad."""
+    def backward(self, on_node_done=None):
+        """Back-propagates self.dout (filled by loss()) into self.grad.  on_node_done(node) is called
+        after each node's launches are enqueued (used to start the gradient all-reduce early)."""
         g = self.dout
         for node in reversed(self.nodes):
             g = node.bwd(g)
+            if on_node_done is not None:
+                on_node_done(node)
 
     def loss(self, Y=None, with_grad=True):
         if Y is not None:
@@ -303,21 +341,32 @@ class Engine:
         b1, b2 = 0.9, 0.999
         lr_t = lr * math.sqrt(1.0 - b2 ** self.t) / (1.0 - b1 ** self.t)
         L.spnet_adam_step(L.ptr(self.theta), L.ptr(self.grad), L.ptr(self.m), L.ptr(self.v), self.n_theta,
-                          self.l2_n, lr_t, b1, b2, self.adam_eps, L2_COEF, grad_scale,
+                          self.l2_n, lr_t, b1, b2, self.adam_eps, L2_COEF, grad_scale, L.ptr(self.update_mask),
                           L.ptr(self.sq_scratch), self.loss_out[6:].data_ptr(), _stream())
 
-    def train_step(self, X, Y, lr, grad_hook=None):
-        """augmented batch X -> forward -> custom_loss -> backward -> Adam(+l2).  Returns the device
-        tensor loss_out (no host sync): [center,size,angle,noobj,class,data_total,l2_penalty,_]."""
+    def train_step(self, X, Y, lr, reducer=None):
+        """augmented batch X -> forward -> custom_loss -> backward -> (all-reduce) -> Adam(+l2).
+        X / Y may be None when self.x_in / self.y_true were filled in place.  `reducer` is a
+        parallel.GradReducer (data parallel) or None.  Returns the device tensor loss_out (no host
+        sync): [center,size,angle,noobj,class,data_total,l2_penalty,_]."""
         self.drop_seed = (self.drop_seed * 1664525 + 1013904223) & 0xFFFFFFFF
         self.forward(X, training=True)
         self.loss(Y)
-        self.backward()
         scale = 1.0
-        if grad_hook is not None:
-            scale = grad_hook(self.grad)
+        if reducer is None:
+            self.backward()
+        else:
+            head = self.nodes[-1]
+            self.backward(on_node_done=lambda n: reducer.launch_head() if n is head else None)
+            scale = reducer.finish()
         self.adam_step(lr, scale)
         return self.loss_out
+
+    def head_grad_range(self):
+        """[lo,hi) of FinalOutput/kernel inside the flat gradient: produced first in backward and 73 %
+        of all gradient bytes, so its all-reduce overlaps the whole backbone backward."""
+        off, n, _ = self.p_off["FinalOutput/kernel"]
+        return off, off + n
 
 
 # ======================================================================================= nodes
@@ -330,8 +379,13 @@ class Node:
 
 
 def _gemm(A, a_major, lda, Bm, b_major, ldb, C, ldc, M, N, K, eng, bias=None, split_k=0, tile=0):
+    prof = eng.prof
+    if prof is not None:
+        t0 = prof.start()
     L.spnet_gemm_f32(L.ptr(A), a_major, lda, L.ptr(Bm), b_major, ldb, L.ptr(C), ldc, M, N, K, split_k,
                      L.ptr(eng.ws), WS_FLOATS, L.ptr(bias), tile, _stream())
+    if prof is not None:
+        prof.stop("gemm", t0, 2.0 * M * N * K)
 
 
 class SmallConv(Node):
@@ -506,8 +560,13 @@ class SepConvBN:
 
     def fwd(self, training):
         e = self.e
+        prof = e.prof
+        if prof is not None:
+            t0 = prof.start()
         L.spnet_dwconv3x3_fwd(L.ptr(self.x), L.ptr(self.wd), L.ptr(self.z), e.B, self.H, self.W, self.cin,
                               self.relu_in, _stream())
+        if prof is not None:
+            prof.stop("dw", t0, 2.0 * 4 * self.M * self.cin)        # read x + write z
         self.pw.fwd(self.z, self.yp)
         self.bn.fwd(training)
 
@@ -517,10 +576,15 @@ class SepConvBN:
         e = self.e
         g = self.bn.bwd(g)
         self.pw.bwd(self.z, g, self.dz)
+        prof = e.prof
+        if prof is not None:
+            t0 = prof.start()
         L.spnet_dwconv3x3_bwd_weight(L.ptr(self.x), L.ptr(self.dz), L.ptr(self.gwd), e.B, self.H, self.W,
                                      self.cin, self.relu_in, L.ptr(e.ws), _stream())
         L.spnet_dwconv3x3_bwd_data(L.ptr(self.dz), L.ptr(self.wd), L.ptr(self.dx), e.B, self.H, self.W, self.cin,
                                    self.relu_in, L.ptr(self.x) if self.relu_in else None, L.ptr(add), _stream())
+        if prof is not None:
+            prof.stop("dw", t0, 3.0 * 4 * self.M * self.cin)        # read dz, read x, write dx
         return self.dx
 
 

@@ -1,0 +1,145 @@
+"""Synthetic 'fake-ESPI' frames + labels: the benchmark / test input distribution.
+
+Follows the reference generator gen_fake_espi.py:60-279 up to, but excluding, the band-pass mix-up
+with the author's private real images (augmentation.py:10-62): 512x384 grey canvas at 128, wavy dark
+bands (draw_waves :60-80), 1..7 non-overlapping ringed ellipses (draw_antinodes :145-206, draw_rings
+:101-114), additive clipped N(40,40) noise, 50 % Bernoulli pixel dropout.  Rasterisation uses PIL
+(OpenCV is not available), the RNG is one numpy RandomState per frame -- frames are statistically,
+not bitwise, those of the reference.  Exactly one PNG per CSV is written (the reference also writes
+a *_bp.png that would trip build_dataset's file-count assertion, utils.py:455-459).
+"""
+import os
+from multiprocessing import Pool
+
+import numpy as np
+from PIL import Image, ImageDraw
+
+IM_W, IM_H = 512, 384
+MIN_LINE_WIDTH = 4
+
+
+def _ellipse_pts(center, axes, angle_deg, n=90):
+    t = np.linspace(0, 2 * np.pi, n, endpoint=False)
+    th = np.deg2rad(-angle_deg)            # the reference passes -angle to cv2.ellipse (utils.py:50)
+    x, y = axes[0] * np.cos(t), axes[1] * np.sin(t)
+    return [(float(center[0] + u * np.cos(th) - v * np.sin(th)), float(center[1] + u * np.sin(th) + v * np.cos(th)))
+            for u, v in zip(x, y)]
+
+
+def _ellipse_box(center, axes, angle):
+    rad = np.radians(angle)
+    dx = np.sqrt(axes[0] ** 2 * np.cos(rad) ** 2 + axes[1] ** 2 * np.sin(rad) ** 2)
+    dy = np.sqrt(axes[0] ** 2 * np.sin(rad) ** 2 + axes[1] ** 2 * np.cos(rad) ** 2)
+    return [center[0] - dx, center[1] - dy, center[0] + dx, center[1] + dy]
+
+
+def _overlaps(a, b):
+    return not (a[2] < b[0] or a[0] > b[2] or a[3] < b[1] or a[1] > b[3])
+
+
+def _draw_waves(d, rs):
+    amp = rs.randint(10, 201)
+    wavelength = rs.randint(100, IM_W // 2 + 1)
+    thick = rs.randint(15, 41)
+    slope = 3 * (rs.rand() - .5)
+    lo = thick + thick * int(abs(1.5 * slope))
+    spacing = rs.randint(lo, max(lo, IM_H // 3) + 1)
+    xs = np.arange(IM_W)
+    base = slope * xs + amp * np.cos(xs / wavelength)
+    for j in range(60 + IM_H // spacing):
+        y0 = j * spacing - IM_W * abs(slope)
+        ys = (y0 + base).astype(np.int64)
+        if ys.max() < -thick or ys.min() > IM_H + thick:
+            continue
+        d.line(list(zip(xs.tolist(), ys.tolist())), fill=0, width=thick, joint="curve")
+
+
+def _draw_rings(d, rs, center, axes, angle, rings):
+    nwb = max(2 * rings, 1)
+    thick = max(int(round(min(axes) / nwb)), 1)
+    start = rs.randint(0, 2)
+    for j in range(nwb):
+        col = 0 if (start + j) % 2 == 0 else 138
+        ax = [a * (j + 1) / (nwb + 1) for a in axes]
+        pts = _ellipse_pts(center, ax, angle)
+        d.line(pts + [pts[0]], fill=col, width=thick, joint="curve")
+
+
+def _draw_antinodes(d, rs, count):
+    boxes, rows = [], []
+    for _ in range(count):
+        axes = sorted((rs.randint(15, int(IM_W / 3.5) + 1), rs.randint(15, int(IM_H / 3.5) + 1)), reverse=True)
+        rings = rs.randint(1, min(axes[1] // 8, 11) + 1)
+        if axes[1] / rings < MIN_LINE_WIDTH:
+            rings = axes[1] // MIN_LINE_WIDTH
+        center = (rs.randint(axes[0], IM_W - axes[0] + 1), rs.randint(axes[1], IM_H - axes[1] + 1))
+        angle = rs.randint(1, 180)
+        box = _ellipse_box(center, axes, angle)
+        tries = 0
+        while (any(_overlaps(box, b) for b in boxes) or box[0] < 0 or box[2] > IM_W or box[1] < 0 or box[3] > IM_H) \
+                and tries < 2000:
+            tries += 1
+            axes = sorted((rs.randint(25, IM_W // 3 + 1), rs.randint(25, IM_H // 3 + 1)), reverse=True)
+            if axes[1] / rings < MIN_LINE_WIDTH:
+                rings = axes[1] // MIN_LINE_WIDTH
+            center = (rs.randint(axes[0], IM_W - axes[0] + 1), rs.randint(axes[1], IM_H - axes[1] + 1))
+            angle = rs.randint(1, 181)
+            box = _ellipse_box(center, axes, angle)
+        if tries < 2000:
+            _draw_rings(d, rs, center, axes, angle, rings)
+            rows.append((center[0], center[1], axes[0], axes[1], angle, rings))
+            boxes.append(box)
+    return rows
+
+
+def gen_frame(seed):
+    """One frame: (uint8 [384,512] image, [(cx,cy,a,b,angle,rings), ...])."""
+    rs = np.random.RandomState(seed)
+    img = Image.new("L", (IM_W, IM_H), 128)
+    d = ImageDraw.Draw(img)
+    _draw_waves(d, rs)
+    rows = _draw_antinodes(d, rs, rs.randint(1, 8))
+    a = np.asarray(img, dtype=np.float32)
+    noise = np.clip(np.rint(rs.normal(40, 40, a.shape)), 0, 255)      # cv2.randn into a uint8 image saturates
+    a = np.minimum(a + noise, 255)
+    a *= rs.randint(0, 2, a.shape)                                      # drop half of the pixels
+    return a.astype(np.uint8), rows
+
+
+def rows_to_csv(rows):
+    if not rows:
+        return "0,0,0,0,0,0.0"
+    return "\n".join("{0},{1},{2},{3},{4},{5}".format(*r) for r in rows)
+
+
+def generate(n, seed=0, workers=None):
+    """n frames -> (uint8 [n,384,512], list of label rows).  Deterministic in (n, seed)."""
+    seeds = [seed * 1000003 + i for i in range(n)]
+    workers = workers or min(os.cpu_count() or 1, 16)
+    if workers > 1 and n >= 16:
+        with Pool(workers) as p:
+            res = p.map(gen_frame, seeds, chunksize=max(1, n // (workers * 4)))
+    else:
+        res = [gen_frame(s) for s in seeds]
+    X = np.stack([r[0] for r in res])
+    return X, [r[1] for r in res]
+
+
+def to_network_input(X_u8):
+    """uint8 [n,H,W] -> float32 [n,H,W,1] in [-1,1] exactly as load_X_one_proc scales (utils.py:340-342)."""
+    x = X_u8.astype(np.float32) / 255.0
+    x -= 0.5
+    x *= 2.0
+    return x[..., None]
+
+
+def write_dataset(path, n, seed=0, start=0):
+    """steelpan_NNNNNNN.png + .csv pairs under `path` (the layout build_dataset reads)."""
+    os.makedirs(path, exist_ok=True)
+    X, labels = generate(n, seed)
+    for i in range(n):
+        stem = os.path.join(path, "steelpan_" + str(start + i).zfill(7))
+        Image.fromarray(X[i]).save(stem + ".png")
+        with open(stem + ".csv", "w") as f:
+            f.write(rows_to_csv(labels[i]))
+    return X, labels

@@ -1,0 +1,440 @@
+"""Model construction, loss and the Keras-like model object -- the surface of the reference's
+spnet/models.py, backed by the HIP engine (spnet_amd/engine.py).
+
+  setup_model(X, Y0size, try_checkpoint, no_cp_fatal, weights_file, freeze_fac, parallel, quick_setup)
+      -> (model, serial_model)                                          models.py:461-507
+  create_model_functional(X, Y0size, freeze_fac, quick_setup)          models.py:302-424
+  build_model(...)          north-star alias of create_model_functional (not in the reference)
+  unfreeze_model(model, X, Y, parallel)                                 models.py:510-552
+  custom_loss(y_true, y_pred), my_loss(y_true, y_pred)                  models.py:557-633
+  SelectiveSigmoid, InterleaveColumns                                    models.py:223-298
+  Model: fit / predict / evaluate / save_weights / load_weights / save / get_weights / set_weights /
+         optimizer.lr / layers / trainable                              (Keras Model protocol used by
+                                                                         train/predict/evaluate_spnet.py)
+Checkpoints: h5py is not available on the target image, so weight files are safetensors containers
+keyed by the Keras weight names (conv2d_1/kernel, block5_sepconv2/pointwise_kernel, ...), written to
+the same file names the reference uses (weights.hdf5, spnet.model, full_model.h5, ...).
+"""
+import json
+import os
+import time
+from os.path import isfile
+
+import numpy as np
+
+from . import config as cf
+from . import multi_gpu, utils  # noqa: F401  (same import surface as the reference module)
+
+lambda_center = 2.0
+lambda_size = 1.0
+lambda_angle = 3.0
+lambda_noobj = 0.3
+lambda_class = 5.0
+logeps = 1e-10
+
+
+def _torch():
+    import torch
+    return torch
+
+
+def _require_gpu():
+    torch = _torch()
+    if not torch.cuda.is_available():
+        raise RuntimeError("spnet_amd.models needs a HIP device: the hot path has no CPU fallback")
+    return torch
+
+
+# ----------------------------------------------------------------------------- loss functions
+def _loss_on_device(y_true, y_pred):
+    torch = _require_gpu()
+    from . import _lib as L
+    dev = torch.device("cuda", torch.cuda.current_device())
+    yt = torch.as_tensor(np.ascontiguousarray(y_true) if isinstance(y_true, np.ndarray) else y_true, dtype=torch.float32).to(dev).contiguous()
+    yp = torch.as_tensor(np.ascontiguousarray(y_pred) if isinstance(y_pred, np.ndarray) else y_pred, dtype=torch.float32).to(dev).contiguous()
+    B, n = yp.shape
+    parts = torch.empty(B, 5, device=dev)
+    out = torch.empty(6, device=dev)
+    L.spnet_ellipse_loss(yt.data_ptr(), yp.data_ptr(), None, parts.data_ptr(), out.data_ptr(), B, n,
+                         0 if cf.loss_type == 'same' else 1, torch.cuda.current_stream().cuda_stream)
+    return out.cpu().numpy().astype(np.float64)
+
+
+def custom_loss(y_true, y_pred):
+    """lambda-weighted MSE over the predictor grid, angle term weighted by (a-b)^2, optional
+    BCE-with-logits on noobj when cf.loss_type != 'same' (models.py:564-589).  Scalar."""
+    return float(_loss_on_device(y_true, y_pred)[5])
+
+
+def my_loss(y_true, y_pred, verbosity=0):
+    """(total, [center, size, angle, noobj, class]) -- models.py:594-633."""
+    o = _loss_on_device(y_true, y_pred)
+    return float(o[5]), o[:5].copy()
+
+
+# ----------------------------------------------------------------------------- output layers (legacy heads)
+class SelectiveSigmoid:
+    """Sigmoid on columns start::skip, identity elsewhere (models.py:277-298)."""
+
+    def __init__(self, **kwargs):
+        self.start = kwargs.get('start', cf.ind_noobj)
+        self.end = kwargs.get('end', None)
+        self.skip = kwargs.get('skip', cf.vars_per_pred)
+        self.sigmoid_stretch = 1
+
+    def __call__(self, x):
+        y = np.array(x, dtype=np.float32, copy=True)
+        sl = slice(self.start, self.end, self.skip)
+        y[:, sl] = self.sigmoid_stretch / (1.0 + np.exp(-y[:, sl]))
+        return y
+
+    call = __call__
+
+
+class InterleaveColumns:
+    """[n_preds sigmoid columns | remaining columns] -> per-predictor order with the first group at
+    `start_index` inside each group of vars_per_pred (models.py:223-274; the reference's bare
+    `vars_per_pred` NameError at :242 is not reproduced)."""
+
+    def __init__(self, start_index=6, **kwargs):
+        self.start_index = start_index
+
+    def column_map(self, n_vars):
+        v = cf.vars_per_pred
+        if n_vars % v != 0:
+            raise ValueError("n_vars (=%d) must be a multiple of vars_per_pred (=%d)" % (n_vars, v))
+        n_preds = n_vars // v
+        cml = [self.start_index + x * v for x in range(n_preds)]
+        for i in range(n_preds):
+            cml += [x + i * v for x in range(self.start_index)]
+            cml += [1 + x + i * v + self.start_index for x in range(v - self.start_index - 1)]
+        return cml
+
+    def __call__(self, x):
+        x = np.asarray(x)
+        out = np.empty_like(x)
+        out[:, self.column_map(x.shape[-1])] = x
+        return out
+
+    call = __call__
+
+
+# ----------------------------------------------------------------------------- model object
+class _Optimizer:
+    def __init__(self, lr=1e-5):
+        self.lr = lr
+
+
+def keras_layer_table():
+    """Ordered (layer_name, [weight-name prefixes]) list approximating base_model.layers of the
+    reference (144 entries: 13 stem layers incl. the input + 131 Xception layers; run log
+    'Freezing 0 / 144 layers').  Used only to translate freeze_fac into a set of frozen tensors."""
+    from .engine import xception_plan
+    t = [("input_1", []), ("conv2d_1", ["conv2d_1"]), ("average_pooling2d_1", []),
+         ("batch_normalization_1", ["batch_normalization_1"]), ("leaky_re_lu_1", []), ("conv2d_2", ["conv2d_2"]),
+         ("batch_normalization_2", ["batch_normalization_2"]), ("leaky_re_lu_2", []), ("conv2d_3", ["conv2d_3"]),
+         ("batch_normalization_3", ["batch_normalization_3"]), ("average_pooling2d_2", []), ("add_1", []),
+         ("dropout_1", [])]
+    for n in ("block1_conv1", "block1_conv2"):
+        t += [(n, [n]), (n + "_bn", [n + "_bn"]), (n + "_act", [])]
+
+    def sep(name, act_before):
+        out = [(name + "_act", [])] if act_before else []
+        return out + [(name, [name]), (name + "_bn", [name + "_bn"])]
+
+    for blk in xception_plan():
+        if blk[0] == "strided":
+            _, b, cin, c1, c2, first_relu, cn, bnn = blk
+            t += sep("block%d_sepconv1" % b, first_relu) + sep("block%d_sepconv2" % b, True)
+            t += [(cn, [cn]), ("block%d_pool" % b, []), (bnn, [bnn]), ("add_b%d" % b, [])]
+        elif blk[0] == "middle":
+            for k in (1, 2, 3):
+                t += sep("block%d_sepconv%d" % (blk[1], k), True)
+            t += [("add_b%d" % blk[1], [])]
+        elif blk[0] == "exit":
+            t += [("block14_sepconv1", ["block14_sepconv1"]), ("block14_sepconv1_bn", ["block14_sepconv1_bn"]),
+                  ("block14_sepconv1_act", []), ("block14_sepconv2", ["block14_sepconv2"]),
+                  ("block14_sepconv2_bn", ["block14_sepconv2_bn"]), ("block14_sepconv2_act", [])]
+    return t
+
+
+class Model:
+    """Keras-Model-like handle over the HIP engine.  Frames are [N,H,W,1] float32 in [-1,1]."""
+
+    def __init__(self, input_shape, Y0size=576, freeze_fac=0.0, seed=None, device=None):
+        torch = _require_gpu()
+        from .engine import Engine
+        if cf.basemodel != 'Xception':
+            raise NotImplementedError("this build implements the Xception backbone (cf.basemodel=%r)" % cf.basemodel)
+        self.input_shape = tuple(int(v) for v in input_shape)
+        H, W = self.input_shape[0], self.input_shape[1]
+        self.H, self.W, self.Y0size = H, W, int(Y0size)
+        self.device = device or "cuda:%d" % torch.cuda.current_device()
+        self.seed = int(np.random.randint(0, 2 ** 31 - 1)) if seed is None else seed
+        self.optimizer = _Optimizer(1e-5)
+        self.trainable = True
+        self.stop_training = False
+        self.layers = [name for name, _ in keras_layer_table()] + ["flatten_1", "FinalOutput"]
+        self.freeze_fac = freeze_fac
+        self._Engine = Engine
+        self._engines = {}
+        self._root = None
+        self._train_frames = None          # (id of host array, device tensor) registered by AugmentOnTheFly
+        self._uploaded = {}
+        self._reducer = None
+        self._base = self._engine(1, train=False)      # owns the weights
+        self._apply_freeze(freeze_fac)
+
+    # -- engines ---------------------------------------------------------------------------------
+    def _engine(self, batch, train):
+        """One launch plan per (batch size, train?) -- all plans share the first one's weight buffers."""
+        key = (int(batch), bool(train))
+        if key not in self._engines:
+            root = self._root
+            if root is not None and train and not hasattr(root, "grad"):
+                torch = _torch()
+                for a in ("grad", "m", "v"):       # optimizer state lives beside the weights it updates
+                    setattr(root, a, torch.zeros(root.n_theta, device=root.dev, dtype=torch.float32))
+            eng = self._Engine(self.H, self.W, batch, n_out=self.Y0size, device=self.device, loss_type=cf.loss_type,
+                               seed=self.seed, train=train, share_from=root)
+            if root is None:
+                self._root = eng
+            self._engines[key] = eng
+        eng = self._engines[key]
+        eng.loss_type = cf.loss_type
+        return eng
+
+    def _apply_freeze(self, freeze_fac):
+        torch = _torch()
+        self._frozen_prefixes = []
+        table = keras_layer_table()
+        n_freeze = int(len(table) * freeze_fac)
+        if freeze_fac == 1.0:
+            n_freeze = len(table)
+        for _, prefixes in table[:n_freeze]:
+            self._frozen_prefixes += prefixes
+        self._mask = None
+        if self._frozen_prefixes:
+            r = self._root
+            mask = torch.ones(r.n_theta, device=r.dev, dtype=torch.float32)
+            for name, (off, n, _) in r.p_off.items():
+                if name.split("/")[0] in self._frozen_prefixes:
+                    mask[off:off + n] = 0
+            self._mask = mask
+
+    # -- weights ----------------------------------------------------------------------------------
+    def get_weights(self):
+        return [v.numpy() for v in self._root.state_dict().values()]
+
+    def set_weights(self, weights):
+        names = self._root.spec_order
+        self._root.load_state_dict(dict(zip(names, weights)))
+
+    def state_dict(self):
+        return self._root.state_dict()
+
+    def load_state_dict(self, sd):
+        self._root.load_state_dict(sd)
+
+    def count_params(self):
+        sd = self._root.state_dict()
+        tr = sum(v.numel() for k, v in sd.items() if not ("moving_" in k))
+        return tr + sum(v.numel() for k, v in sd.items() if "moving_" in k), tr
+
+    def save_weights(self, path):
+        from safetensors.torch import save_file
+        meta = {"format": "spnet_amd-weights-v1", "input_shape": json.dumps(self.input_shape), "Y0size": str(self.Y0size),
+                "basemodel": cf.basemodel}
+        save_file({k: v.contiguous() for k, v in self._root.state_dict().items()}, path, metadata=meta)
+
+    def load_weights(self, path, by_name=False):
+        from safetensors.torch import load_file
+        self._root.load_state_dict(load_file(path))
+
+    def save(self, path):
+        """'Whole model' file = weights + the configuration needed to rebuild the plan."""
+        from safetensors.torch import save_file
+        meta = {"format": "spnet_amd-model-v1", "input_shape": json.dumps(self.input_shape), "Y0size": str(self.Y0size),
+                "basemodel": cf.basemodel, "model_type": cf.model_type, "loss_type": cf.loss_type,
+                "optimizer_iterations": str(self._root.t if hasattr(self._root, "t") else 0)}
+        save_file({k: v.contiguous() for k, v in self._root.state_dict().items()}, path, metadata=meta)
+
+    # -- data plumbing ----------------------------------------------------------------------------
+    def set_train_frames(self, host_array, device_tensor):
+        """AugmentOnTheFly registers the device tensor that shadows the host training array."""
+        self._train_frames = (id(host_array), device_tensor)
+
+    def set_reducer(self, reducer_factory):
+        self._reducer = reducer_factory
+
+    def _device_frames(self, X):
+        torch = _torch()
+        if isinstance(X, torch.Tensor):
+            return X if X.is_cuda else X.to(self.device)
+        if self._train_frames is not None and self._train_frames[0] == id(X):
+            return self._train_frames[1]
+        key = id(X)
+        if key not in self._uploaded:
+            self._uploaded = {key: torch.from_numpy(np.ascontiguousarray(X, dtype=np.float32)).to(self.device)}
+        return self._uploaded[key]
+
+    # -- inference --------------------------------------------------------------------------------
+    def predict(self, X, batch_size=32, verbose=0):
+        torch = _torch()
+        Xd = self._device_frames(X)
+        N = Xd.shape[0]
+        bs = max(1, min(int(batch_size), N))
+        eng = self._engine(bs, train=False)
+        out = torch.empty(N, self.Y0size, device=Xd.device)
+        for lo in range(0, N, bs):
+            hi = min(N, lo + bs)
+            if hi - lo == bs:
+                eng.x_in.copy_(Xd[lo:hi].reshape(eng.x_in.shape))
+            else:                                   # ragged tail: pad with the last frame, drop the extras
+                eng.x_in[:hi - lo].copy_(Xd[lo:hi].reshape(hi - lo, self.H, self.W, 1))
+                eng.x_in[hi - lo:].copy_(Xd[hi - 1:hi].reshape(1, self.H, self.W, 1).expand(bs - (hi - lo), -1, -1, -1))
+            y = eng.forward(None, training=False)
+            out[lo:hi].copy_(y[:hi - lo])
+        return out.cpu().numpy()
+
+    def evaluate(self, X, Y, batch_size=32, verbose=0):
+        return custom_loss(Y, self.predict(X, batch_size=batch_size))
+
+    # -- training ---------------------------------------------------------------------------------
+    def fit(self, X, Y, batch_size=32, epochs=1, shuffle=True, verbose=1, validation_data=None, callbacks=None,
+            initial_epoch=0):
+        torch = _torch()
+        import torch.distributed as dist
+        from . import parallel
+        callbacks = list(callbacks or [])
+        for cb in callbacks:
+            cb.set_model(self)
+        eng = self._engine(batch_size, train=True)
+        eng.update_mask = self._mask
+        world = dist.get_world_size() if dist.is_initialized() else 1
+        rank = dist.get_rank() if dist.is_initialized() else 0
+        reducer = parallel.GradReducer(eng.grad, eng.head_grad_range()) if world > 1 else None
+        Yd = torch.from_numpy(np.ascontiguousarray(Y, dtype=np.float32)).to(eng.dev) if isinstance(Y, np.ndarray) else Y
+        N = Yd.shape[0]
+        for cb in callbacks:
+            cb.on_train_begin({})
+        history = {"loss": [], "val_loss": []}
+        for epoch in range(initial_epoch, epochs):
+            t_epoch = time.time()
+            for cb in callbacks:
+                cb.on_epoch_begin(epoch, {})
+            Xd = self._device_frames(X)
+            index = np.arange(N)
+            if shuffle:
+                np.random.shuffle(index)               # Keras shuffles with numpy's global RNG
+            if world > 1:
+                index = index[rank::world][:N // world]
+            nb = len(index) // batch_size
+            loss_sum = torch.zeros(2, device=eng.dev, dtype=torch.float64)
+            for b in range(nb):
+                for cb in callbacks:
+                    cb.on_batch_begin(b, {})
+                idx = torch.from_numpy(index[b * batch_size:(b + 1) * batch_size]).to(eng.dev)
+                torch.index_select(Xd, 0, idx, out=eng.x_in)
+                torch.index_select(Yd, 0, idx, out=eng.y_true)
+                out = eng.train_step(None, None, float(self.optimizer.lr), reducer=reducer)
+                loss_sum += out[5:7].double()
+                if verbose and (b % max(1, nb // 20) == 0 or b == nb - 1):
+                    print("\rEpoch %d/%d  batch %d/%d" % (epoch + 1, epochs, b + 1, nb), end="", flush=True)
+            ls = (loss_sum / max(nb, 1)).cpu().numpy()
+            logs = {"loss": float(ls[0] + ls[1])}             # Keras reports data loss + regularisation
+            if validation_data is not None:
+                Xv, Yv = validation_data[0], validation_data[1]
+                logs["val_loss"] = custom_loss(Yv, self.predict(Xv, batch_size=batch_size)) + float(ls[1])
+            history["loss"].append(logs["loss"])
+            history["val_loss"].append(logs.get("val_loss"))
+            if verbose:
+                n_img = nb * batch_size * world
+                print("\r%d/%d - %ds - loss: %.4e%s" % (n_img, n_img, time.time() - t_epoch, logs["loss"],
+                                                          (" - val_loss: %.4e" % logs["val_loss"]) if "val_loss" in logs else ""))
+            for cb in callbacks:
+                cb.on_epoch_end(epoch, logs)
+            if self.stop_training:
+                break
+        for cb in callbacks:
+            cb.on_train_end({})
+        return history
+
+
+# ----------------------------------------------------------------------------- constructors
+def create_model_functional(X, Y0size=576, freeze_fac=0.75, quick_setup=False):
+    """Stem (3x3 convs + average pooling + BN/LeakyReLU residual block, Dropout 0.1) -> cf.basemodel
+    backbone -> Flatten -> Dense(Y0size, 'FinalOutput'); l2(1e-4) on the ten regularised kernels
+    (models.py:302-424)."""
+    print("Using functional API model, cf.basemodel =", cf.basemodel)
+    print("X[0].shape = ", X[0].shape)
+    if cf.model_type == 'compound':
+        raise NotImplementedError("model_type 'compound' (sigmoid head + InterleaveColumns) is a legacy head of the "
+                                  "reference; use 'monolithic'/'big' with loss_type 'hybrid' instead")
+    model = Model(X[0].shape, Y0size=Y0size, freeze_fac=freeze_fac)
+    n_layers = len(keras_layer_table())
+    print("Freezing ", int(n_layers * freeze_fac), "/", n_layers, " layers of base_model")
+    total, trainable = model.count_params()
+    frozen = 0
+    if model._mask is not None:
+        frozen = int((model._mask == 0).sum().item())
+    print('create_model_functional: Total params: {:,}'.format(total))
+    print('create_model_functional: Trainable params: {:,}'.format(trainable - frozen))
+    print('create_model_functional: Non-trainable params: {:,}'.format(total - trainable + frozen))
+    return model
+
+
+def build_model(X, Y0size=576, freeze_fac=0.0, quick_setup=False):
+    """Alias named by the build's north star; the reference's symbol is create_model_functional."""
+    return create_model_functional(X, Y0size=Y0size, freeze_fac=freeze_fac, quick_setup=quick_setup)
+
+
+def create_model_simple(X, Y0size=576, freeze_fac=0.75):
+    raise NotImplementedError("model_type 'simple' (NASNetMobile with imagenet weights, models.py:428-458) needs a "
+                              "network download and is 'not recommended' by the reference; out of scope")
+
+
+def setup_model(X, Y0size=576, try_checkpoint=True, no_cp_fatal=False, weights_file='weights.hdf5', freeze_fac=0.75,
+                parallel=False, quick_setup=False):
+    """Build the model, optionally initialise it from `weights_file`, attach Adam(lr=1e-5) + custom_loss.
+    Returns (model, serial_model) -- the same object twice: data parallelism here is one process per
+    GPU (spnet_amd/parallel.py), not an in-graph wrapper."""
+    print("Initializing blank model: Y0size =", Y0size)
+    if cf.model_type == 'simple':
+        model = create_model_simple(X, Y0size=Y0size, freeze_fac=freeze_fac)
+    else:
+        model = create_model_functional(X, Y0size=Y0size, freeze_fac=freeze_fac, quick_setup=quick_setup)
+    if try_checkpoint:
+        if isfile(weights_file):
+            print('Weights file detected. Loading from', weights_file)
+            model.load_weights(weights_file)
+        elif no_cp_fatal:
+            raise Exception("*** No weights file detected; can't do anything.  Aborting.")
+        else:
+            print('    No weights file detected, so starting from scratch.')
+    model.optimizer = _Optimizer(lr=0.00001)
+    if parallel:
+        model = multi_gpu.make_parallel(model)
+    print("Compiling the model")
+    return model, model
+
+
+def load_model(path, custom_objects=None):
+    """Rebuild a model from a 'whole model' file written by Model.save()."""
+    from safetensors import safe_open
+    with safe_open(path, framework="pt") as f:
+        meta = f.metadata() or {}
+    shape = tuple(json.loads(meta.get("input_shape", "[331, 331, 1]")))
+    model = Model(shape, Y0size=int(meta.get("Y0size", 576)), freeze_fac=0.0)
+    model.load_weights(path)
+    return model
+
+
+def unfreeze_model(model, X, Y, parallel=False):
+    """Fresh, fully trainable model with the same weights and a new optimizer (models.py:510-552)."""
+    print("Unfreezing Model: make a new identical model, then copy the layer weights.")
+    new_model = create_model_functional(X, Y[0].size, freeze_fac=0)
+    new_model.set_weights(multi_gpu.get_serial_part(model, parallel=parallel).get_weights())
+    new_model.optimizer = _Optimizer(lr=0.00001)
+    print("  ...finished un-freezing model")
+    return new_model

@@ -311,7 +311,7 @@ def test_adam_matches_keras_form(L):
     import math
     lr_t = lr * math.sqrt(1 - 0.999 ** t) / (1 - 0.9 ** t)
     L.spnet_adam_step(pd.data_ptr(), gd.data_ptr(), md.data_ptr(), vd.data_ptr(), n, l2n, lr_t, 0.9, 0.999, 1e-7, 1e-4, 0.5,
-                      sq.data_ptr(), l2out.data_ptr(), st())
+                      None, sq.data_ptr(), l2out.data_ptr(), st())
     wp, wm, wv = p.copy(), m.copy(), v.copy()
     wp[:l2n], wm[:l2n], wv[:l2n] = R.adam_step(p[:l2n], g[:l2n] * 0.5, m[:l2n], v[:l2n], t, lr, l2=1e-4)
     wp[l2n:], wm[l2n:], wv[l2n:] = R.adam_step(p[l2n:], g[l2n:] * 0.5, m[l2n:], v[l2n:], t, lr)
