@@ -29,7 +29,7 @@ extern "C" {
  *                    1 = output index contiguous    (A[k*lda+m], B[k*ldb+n]).
  * Supported pairs: (0,1) forward, (0,0) dgrad, (1,1) wgrad.
  * split_k: 0 = choose automatically, >1 = that many K slices summed deterministically through
- * `workspace` (>= split_k*M*N floats).  tile: 0 auto, 1 128x128, 2 128x64, 3 64x64, 4 32x128. */
+ * `workspace` (>= split_k*M*N floats).  tile: 0 auto, 1 128x128, 2 128x64, 3 64x64, 4 32x128, 5 96x96. */
 int spnet_gemm_f32(const float* A, int a_major, int lda, const float* B, int b_major, int ldb, float* C,
                    int ldc, int M, int N, int K, int split_k, float* workspace, long ws_floats,
                    const float* bias, int tile, void* stream);
@@ -52,6 +52,14 @@ long spnet_dwconv3x3_bwd_weight_ws(int B, int H, int W, int C);
 int spnet_dwconv3x3_bwd_weight(const float* x, const float* dy, float* dw, int B, int H, int W, int C,
                                int relu_in, float* workspace, void* stream);
 int spnet_reduce_rows(const float* in, int P, int L, float* out, void* stream);
+/* LDS-tiled forms used by the engine: forward, and the FUSED backward (data + weight gradient in one
+ * pass over x and dy).  workspace: spnet_dwconv3x3_tiled_bwd_ws(B,H,W,C) floats. */
+int spnet_dwconv3x3_tiled_fwd(const float* x, const float* w, float* y, int B, int H, int W, int C,
+                              int relu_in, void* stream);
+long spnet_dwconv3x3_tiled_bwd_ws(int B, int H, int W, int C);
+int spnet_dwconv3x3_tiled_bwd(const float* dy, const float* x_fwd, const float* w, float* dx, float* dw,
+                              int B, int H, int W, int C, int relu_in, const float* add, float* workspace,
+                              void* stream);
 
 /* ---- BatchNormalization(axis=-1, momentum .99, eps 1e-3) (spnet/models.py:326-336 + 40 in Xception) --- */
 /* act: 0 none, 1 ReLU, 2 LeakyReLU(0.1) fused behind the affine; residual (or NULL) added last;
@@ -104,7 +112,8 @@ int spnet_adam_step(float* p, const float* g, float* m, float* v, long n, long l
                     float* sq_scratch, float* l2_loss_out, void* stream);
 
 /* ---- augmentation (spnet/callbacks.py:272-341, spnet/augmentation.py) ---------------------------- */
-int spnet_minmax(const float* x, int N, long hw, float* mm, void* stream);
+/* per-frame min/max -> mm[N][2]; scratch: N*32 floats */
+int spnet_minmax(const float* x, int N, long hw, float* mm, float* scratch, void* stream);
 int spnet_cutout(const float* src, const int* src_index, float* dst, int N, int H, int W,
                  const int* rects, const float* vals, const int* nrect, void* stream);
 int spnet_saltpepper(float* x, int N, int H, int W, const int* coords, int n_salt, int n_pepper,

@@ -8,7 +8,7 @@ import os
 from ctypes import c_float, c_int, c_long, c_uint, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libspnet_hip.so")
+LIB_PATH = os.environ.get("SPNET_HIP_LIB") or os.path.join(_HERE, "lib", "libspnet_hip.so")
 
 if not os.path.exists(LIB_PATH):
     raise ImportError(
@@ -30,6 +30,9 @@ _SIGS = {
     "spnet_dwconv3x3_bwd_weight_ws": (c_long, [c_int, c_int, c_int, c_int]),
     "spnet_dwconv3x3_bwd_weight": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, P, P]),
     "spnet_reduce_rows": (c_int, [P, c_int, c_int, P, P]),
+    "spnet_dwconv3x3_tiled_fwd": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, P]),
+    "spnet_dwconv3x3_tiled_bwd_ws": (c_long, [c_int, c_int, c_int, c_int]),
+    "spnet_dwconv3x3_tiled_bwd": (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, P, P, P]),
     "spnet_bn_ws": (c_long, [c_long, c_int]),
     "spnet_bn_fwd_train": (c_int, [P, c_long, c_int, P, P, P, P, P, P, P, c_int, P, c_int, P, c_float, c_float, P, P]),
     "spnet_bn_fwd_infer": (c_int, [P, c_long, c_int, P, P, P, P, P, c_int, P, c_int, P, c_float, P]),
@@ -42,7 +45,7 @@ _SIGS = {
     "spnet_ellipse_loss": (c_int, [P, P, P, P, P, c_int, c_int, c_int, P]),
     "spnet_decode": (c_int, [P, P, P, P, c_int, c_int, c_int, P]),
     "spnet_adam_step": (c_int, [P, P, P, P, c_long, c_long, c_float, c_float, c_float, c_float, c_float, c_float, P, P, P, P]),
-    "spnet_minmax": (c_int, [P, c_int, c_long, P, P]),
+    "spnet_minmax": (c_int, [P, c_int, c_long, P, P, P]),
     "spnet_cutout": (c_int, [P, P, P, c_int, c_int, c_int, P, P, P, P]),
     "spnet_saltpepper": (c_int, [P, c_int, c_int, c_int, P, c_int, c_int, P, P, P]),
     "spnet_warp_affine": (c_int, [P, P, c_int, c_int, c_int, c_int, P, P]),

@@ -84,7 +84,8 @@ class DeviceAugmenter:
         self.shape = (self.H, self.W, 1)
         self.real_blur = real_blur          # reserved: default reproduces the reference's no-op blur
         mm = torch.empty(self.N, 2, device=self.X.device)
-        L.spnet_minmax(self.X.data_ptr(), self.N, self.H * self.W, mm.data_ptr(), _stream())
+        scratch = torch.empty(self.N * 32, device=self.X.device)
+        L.spnet_minmax(self.X.data_ptr(), self.N, self.H * self.W, mm.data_ptr(), scratch.data_ptr(), _stream())
         self.mm_host = mm.cpu().numpy()     # min/max of the pristine frames: cutout's fill range
         self.n_salt, self.n_pepper = saltpepper_counts(self.shape)
 
@@ -120,9 +121,9 @@ class DeviceAugmenter:
         self._keep = up                    # keep the uploads alive until the kernels have consumed them
         L.spnet_cutout(self.X.data_ptr(), up["index"].data_ptr(), out.data_ptr(), B, self.H, self.W,
                        up["rects"].data_ptr(), up["vals"].data_ptr(), up["nrect"].data_ptr(), _stream())
-        mm = torch.empty(B, 2, device=dev)
+        mm = torch.empty(B * (2 + 32), device=dev)   # [B,2] result followed by B*32 floats of reduction scratch
         self._mm = mm
-        L.spnet_minmax(out.data_ptr(), B, self.H * self.W, mm.data_ptr(), _stream())
+        L.spnet_minmax(out.data_ptr(), B, self.H * self.W, mm.data_ptr(), mm[2 * B:].data_ptr(), _stream())
         L.spnet_saltpepper(out.data_ptr(), B, self.H, self.W, up["coords"].data_ptr(), self.n_salt, self.n_pepper,
                            up["flag"].data_ptr(), mm.data_ptr(), _stream())
         return out
@@ -136,12 +137,12 @@ def cutout_inplace(img, max_regions=6, minsize=11, maxsize=75):
     """Reference signature (augmentation.py:117); `img` is ONE device frame [H,W,1]."""
     _require_cuda(img)
     H, W = img.shape[0], img.shape[1]
-    mm = torch.empty(1, 2, device=img.device)
+    mm = torch.empty(2 + 32, device=img.device)
     n = np.random.randint(0, high=max_regions + 1)
     if n == 0:
         return
-    L.spnet_minmax(img.data_ptr(), 1, H * W, mm.data_ptr(), _stream())
-    lo, hi = mm.cpu().numpy()[0]
+    L.spnet_minmax(img.data_ptr(), 1, H * W, mm.data_ptr(), mm[2:].data_ptr(), _stream())
+    lo, hi = mm[:2].cpu().numpy()
     rects = np.zeros((1, MAX_RECTS, 4), np.int32)
     vals = np.zeros((1, MAX_RECTS), np.float32)
     for k in range(n):
@@ -167,8 +168,8 @@ def salt_n_pepa_inplace(img, salt_vs_pepper=0.2, amount=0.004):
     coords[0, 0, :ns], coords[0, 1, :ns], coords[0, 0, ns:], coords[0, 1, ns:] = sp
     c = torch.from_numpy(coords).to(img.device)
     flag = torch.ones(1, dtype=torch.int32, device=img.device)
-    mm = torch.empty(1, 2, device=img.device)
-    L.spnet_minmax(img.data_ptr(), 1, H * W, mm.data_ptr(), _stream())
+    mm = torch.empty(2 + 32, device=img.device)
+    L.spnet_minmax(img.data_ptr(), 1, H * W, mm.data_ptr(), mm[2:].data_ptr(), _stream())
     L.spnet_saltpepper(img.data_ptr(), 1, H, W, c.data_ptr(), ns, npep, flag.data_ptr(), mm.data_ptr(), _stream())
     torch.cuda.current_stream().synchronize()
 

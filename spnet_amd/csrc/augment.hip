@@ -12,13 +12,14 @@
 
 #define MAX_RECTS 6
 
-// per-image min / max -> mm[n][2]
-__global__ __launch_bounds__(256) void minmax_kernel(const float* __restrict__ x, long hw,
-                                                     float* __restrict__ mm) {
+// per-image min / max -> mm[n][2]; stage 1: MM_CHUNKS workgroups per image, stage 2: combine
+#define MM_CHUNKS 16
+__global__ __launch_bounds__(256) void minmax_partial_kernel(const float* __restrict__ x, long hw,
+                                                             float* __restrict__ part) {
   __shared__ float rlo[4], rhi[4];
-  const float* p = x + (long)blockIdx.x * hw;
+  const float* p = x + (long)blockIdx.y * hw;
   float lo = __builtin_huge_valf(), hi = -__builtin_huge_valf();
-  for (long i = threadIdx.x; i < hw; i += blockDim.x) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < hw; i += (long)gridDim.x * blockDim.x) {
     const float v = p[i];
     lo = fminf(lo, v);
     hi = fmaxf(hi, v);
@@ -28,9 +29,22 @@ __global__ __launch_bounds__(256) void minmax_kernel(const float* __restrict__ x
   if ((threadIdx.x & 63) == 0) { rlo[threadIdx.x >> 6] = lo; rhi[threadIdx.x >> 6] = hi; }
   __syncthreads();
   if (threadIdx.x == 0) {
-    mm[blockIdx.x * 2 + 0] = fminf(fminf(rlo[0], rlo[1]), fminf(rlo[2], rlo[3]));
-    mm[blockIdx.x * 2 + 1] = fmaxf(fmaxf(rhi[0], rhi[1]), fmaxf(rhi[2], rhi[3]));
+    float* o = part + ((long)blockIdx.y * MM_CHUNKS + blockIdx.x) * 2;
+    o[0] = fminf(fminf(rlo[0], rlo[1]), fminf(rlo[2], rlo[3]));
+    o[1] = fmaxf(fmaxf(rhi[0], rhi[1]), fmaxf(rhi[2], rhi[3]));
   }
+}
+__global__ __launch_bounds__(64) void minmax_combine_kernel(const float* __restrict__ part, int N,
+                                                            float* __restrict__ mm) {
+  const int n = blockIdx.x * 64 + threadIdx.x;
+  if (n >= N) return;
+  float lo = __builtin_huge_valf(), hi = -__builtin_huge_valf();
+  for (int c = 0; c < MM_CHUNKS; ++c) {
+    lo = fminf(lo, part[((long)n * MM_CHUNKS + c) * 2]);
+    hi = fmaxf(hi, part[((long)n * MM_CHUNKS + c) * 2 + 1]);
+  }
+  mm[n * 2] = lo;
+  mm[n * 2 + 1] = hi;
 }
 
 // dst[n] = src[src_index[n]] with the image's rectangles painted in order (later ones win).
@@ -134,8 +148,10 @@ __global__ __launch_bounds__(256) void dropout_kernel(const float* __restrict__ 
   }
 }
 
-extern "C" int spnet_minmax(const float* x, int N, long hw, float* mm, void* stream) {
-  hipLaunchKernelGGL(minmax_kernel, dim3(N), dim3(256), 0, (hipStream_t)stream, x, hw, mm);
+// scratch: N * 32 floats
+extern "C" int spnet_minmax(const float* x, int N, long hw, float* mm, float* scratch, void* stream) {
+  hipLaunchKernelGGL(minmax_partial_kernel, dim3(MM_CHUNKS, N), dim3(256), 0, (hipStream_t)stream, x, hw, scratch);
+  hipLaunchKernelGGL(minmax_combine_kernel, dim3((N + 63) / 64), dim3(64), 0, (hipStream_t)stream, scratch, N, mm);
   SPNET_RETURN_LAUNCH_STATUS();
 }
 

@@ -123,17 +123,19 @@ __global__ void bn_partial_small_kernel(const float* __restrict__ x, const float
   }
 }
 
-// Combine partial [P][2][C] in a fixed order: 256 threads = 64 channels x 4 interleaved groups of
-// partial rows, summed in double, then the 4 group sums are added in group order.  Returns the
-// channel owned by this thread (group 0 only) or -1.
+// Combine partial [P][2][C] in a fixed order: 256 threads = 16 channels x 16 interleaved groups of
+// partial rows, summed in double (4 independent loads in flight per thread), then the 16 group sums
+// are added in group order.  Returns the channel owned by this thread (group 0 only) or -1.
+#define BN_FIN_CH 16
 __device__ __forceinline__ int combine_partials(const float* __restrict__ partial, int P, int C,
                                                 double* s_out, double* q_out) {
-  __shared__ double cred[2][4][64];
-  const int lane = threadIdx.x & 63, g = threadIdx.x >> 6;
-  const int c = blockIdx.x * 64 + lane;
+  __shared__ double cred[2][16][BN_FIN_CH];
+  const int lane = threadIdx.x & (BN_FIN_CH - 1), g = threadIdx.x >> 4;
+  const int c = blockIdx.x * BN_FIN_CH + lane;
   double s = 0.0, q = 0.0;
   if (c < C) {
-    for (int p = g; p < P; p += 4) {
+#pragma unroll 4
+    for (int p = g; p < P; p += 16) {
       s += (double)partial[((long)p * 2 + 0) * C + c];
       q += (double)partial[((long)p * 2 + 1) * C + c];
     }
@@ -142,12 +144,15 @@ __device__ __forceinline__ int combine_partials(const float* __restrict__ partia
   cred[1][g][lane] = q;
   __syncthreads();
   if (g != 0 || c >= C) return -1;
-  *s_out = (cred[0][0][lane] + cred[0][1][lane]) + (cred[0][2][lane] + cred[0][3][lane]);
-  *q_out = (cred[1][0][lane] + cred[1][1][lane]) + (cred[1][2][lane] + cred[1][3][lane]);
+  double ss = 0.0, qq = 0.0;
+#pragma unroll
+  for (int k = 0; k < 16; ++k) { ss += cred[0][k][lane]; qq += cred[1][k][lane]; }
+  *s_out = ss;
+  *q_out = qq;
   return c;
 }
 
-// ---------------------------------------------------------------- finalize (64 channels per workgroup)
+// ---------------------------------------------------------------- finalize (16 channels per workgroup)
 // Forward: partial [P][2][C] -> batch mean / invstd, affine coefficients, moving-stat update.
 __global__ __launch_bounds__(256) void bn_fwd_finalize_kernel(
     const float* __restrict__ partial, int P, int C, long M, const float* __restrict__ gamma,
@@ -363,7 +368,7 @@ extern "C" int spnet_bn_fwd_train(const float* x, long M, int C, const float* ga
   if (res_bcast && !(C & 3)) return (int)hipErrorInvalidValue;
   const int parts = bn_parts(M, C);
   launch_partial<0>(x, nullptr, M, C, nullptr, nullptr, nullptr, nullptr, 0, workspace, parts, st);
-  hipLaunchKernelGGL(bn_fwd_finalize_kernel, dim3((C + 63) / 64), dim3(256), 0, st, workspace, parts,
+  hipLaunchKernelGGL(bn_fwd_finalize_kernel, dim3((C + BN_FIN_CH - 1) / BN_FIN_CH), dim3(256), 0, st, workspace, parts,
                      C, M, gamma, beta, moving_mean, moving_var, save_mean, save_invstd, scale_shift,
                      scale_shift + C, eps, momentum);
   launch_apply(x, M, C, scale_shift, scale_shift + C, act, residual, res_bcast, y, st);
@@ -394,7 +399,7 @@ extern "C" int spnet_bn_bwd(const float* x, const float* dy, long M, int C, cons
   if ((C & 3) && C > 4) return (int)hipErrorInvalidValue;
   const int parts = bn_parts(M, C);
   launch_partial<1>(x, dy, M, C, save_mean, save_invstd, gamma, beta, act, workspace, parts, st);
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 63) / 64), dim3(256), 0, st, workspace, parts,
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + BN_FIN_CH - 1) / BN_FIN_CH), dim3(256), 0, st, workspace, parts,
                      C, M, gamma, save_invstd, dgamma, dbeta, coeffs, coeffs + C, coeffs + 2 * C);
   if (C & 3) {
     const long n = M * C;

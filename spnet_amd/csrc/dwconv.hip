@@ -192,18 +192,235 @@ __global__ __launch_bounds__(256) void dw3x3_bwd_weight_partial_kernel(
   }
 }
 
-// out[l] = sum_p in[p*L + l]   (deterministic order; used by several two-stage reductions)
+// ================================================================================================
+// LDS-tiled depthwise kernels (the ones the engine uses).
+//
+// A workgroup owns TH x TW output pixels x CC4 channel quads.  Phase 1 stages the (TH+2) x (TW+2) halo
+// tile into LDS with every global element fetched once per tile (16 B per lane, CC4 lanes contiguous
+// along C, zero fill outside the image = SAME padding).  Phase 2: thread (channel quad, column, row
+// strip) slides a 3-row window down its strip reading 3 float4 per row from LDS (a wave reads 1 KiB
+// of consecutive LDS per instruction: conflict-free), so HBM sees ~1.2-1.3x the tensor on the read
+// side and exactly the tensor on the write side.
+//
+// The backward kernel fuses the data gradient (dx = dw3x3(dz, flip w) * relu-mask + add) and the
+// weight gradient (9 taps x C partial sums per workgroup, combined across the 32 threads that share a
+// channel quad through LDS, then by reduce_rows over workgroups): x and dz are each read once.
+// ================================================================================================
+template <int CC4, int TW, int RS, int NS>
+__global__ __launch_bounds__(256) void dw3x3_tile_fwd_kernel(const float* __restrict__ in,
+                                                             const float* __restrict__ wt,
+                                                             float* __restrict__ out, int H, int W, int C,
+                                                             int relu_in, int tiles_h, int tiles_w,
+                                                             int cchunks) {
+  constexpr int TH = RS * NS;
+  constexpr int PW = TW + 2;
+  static_assert(CC4 * TW * NS == 256, "thread layout");
+  extern __shared__ __attribute__((aligned(16))) float4 tile[];   // [(TH+2)][PW][CC4]
+  const int c4n = C >> 2;
+  int bid = blockIdx.x;
+  const int cc = bid % cchunks; bid /= cchunks;
+  const int tw = bid % tiles_w; bid /= tiles_w;
+  const int th = bid % tiles_h;
+  const int b = bid / tiles_h;
+  const int h0 = th * TH, w0 = tw * TW, c40 = cc * CC4;
+  const float* base = in + (long)b * H * W * C;
+  const int tid = threadIdx.x;
+  for (int idx = tid; idx < (TH + 2) * PW * CC4; idx += 256) {
+    const int l = idx % CC4, p = idx / CC4;
+    const int pw = p % PW, ph = p / PW;
+    const int h = h0 - 1 + ph, w = w0 - 1 + pw, c4 = c40 + l;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (h >= 0 && h < H && w >= 0 && w < W && c4 < c4n) {
+      v = *reinterpret_cast<const float4*>(base + ((long)h * W + w) * C + c4 * 4);
+      if (relu_in) v = f4_relu(v);
+    }
+    tile[idx] = v;
+  }
+  __syncthreads();
+  const int l = tid % CC4, tcol = (tid / CC4) % TW, strip = tid / (CC4 * TW);
+  const int c4 = c40 + l;
+  if (c4 >= c4n) return;
+  float4 k[9];
+#pragma unroll
+  for (int tp = 0; tp < 9; ++tp) k[tp] = *reinterpret_cast<const float4*>(wt + (long)tp * C + c4 * 4);
+  float4 acc[RS];
+#pragma unroll
+  for (int r = 0; r < RS; ++r) acc[r] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+  for (int rr = 0; rr < RS + 2; ++rr) {
+    const float4* row = tile + ((strip * RS + rr) * PW + tcol) * CC4 + l;
+    const float4 v0 = row[0], v1 = row[CC4], v2 = row[2 * CC4];
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh) {
+      const int r = rr - kh;
+      if (r >= 0 && r < RS) {
+        f4_fma(acc[r], v0, k[kh * 3 + 0]);
+        f4_fma(acc[r], v1, k[kh * 3 + 1]);
+        f4_fma(acc[r], v2, k[kh * 3 + 2]);
+      }
+    }
+  }
+  const int w = w0 + tcol;
+  if (w < W) {
+#pragma unroll
+    for (int r = 0; r < RS; ++r) {
+      const int h = h0 + strip * RS + r;
+      if (h < H)
+        *reinterpret_cast<float4*>(out + (((long)b * H + h) * W + w) * C + c4 * 4) = acc[r];
+    }
+  }
+}
+
+template <int CC4, int TW, int RS, int NS>
+__global__ __launch_bounds__(256) void dw3x3_tile_bwd_kernel(
+    const float* __restrict__ dz, const float* __restrict__ x, const float* __restrict__ wt,
+    float* __restrict__ dx, float* __restrict__ partial, const float* __restrict__ add, int H, int W,
+    int C, int relu_in, int tiles_h, int tiles_w, int cchunks) {
+  constexpr int TH = RS * NS;
+  constexpr int PW = TW + 2;
+  constexpr int TILE = (TH + 2) * PW * CC4;
+  constexpr int GROUP = TW * NS;            // threads that share one channel quad
+  static_assert(CC4 * TW * NS == 256, "thread layout");
+  static_assert(9 * GROUP * CC4 <= 2 * TILE, "reduction scratch fits in the tiles");
+  extern __shared__ __attribute__((aligned(16))) float4 tile[];   // dz tile, then x tile
+  float4* tdz = tile;
+  float4* tx = tile + TILE;
+  const int c4n = C >> 2;
+  int bid = blockIdx.x;
+  const int cc = bid % cchunks; bid /= cchunks;
+  const int sp = bid;                        // spatial workgroup index = partial row
+  const int tw = bid % tiles_w; bid /= tiles_w;
+  const int th = bid % tiles_h;
+  const int b = bid / tiles_h;
+  const int h0 = th * TH, w0 = tw * TW, c40 = cc * CC4;
+  const long ibase = (long)b * H * W * C;
+  const int tid = threadIdx.x;
+  for (int idx = tid; idx < TILE; idx += 256) {
+    const int l = idx % CC4, p = idx / CC4;
+    const int pw = p % PW, ph = p / PW;
+    const int h = h0 - 1 + ph, w = w0 - 1 + pw, c4 = c40 + l;
+    float4 g = make_float4(0.f, 0.f, 0.f, 0.f), v = g;
+    if (h >= 0 && h < H && w >= 0 && w < W && c4 < c4n) {
+      const long o = ibase + ((long)h * W + w) * C + c4 * 4;
+      g = *reinterpret_cast<const float4*>(dz + o);
+      v = *reinterpret_cast<const float4*>(x + o);
+      if (relu_in) v = f4_relu(v);
+    }
+    tdz[idx] = g;
+    tx[idx] = v;
+  }
+  __syncthreads();
+  const int l = tid % CC4, tcol = (tid / CC4) % TW, strip = tid / (CC4 * TW);
+  const int c4 = c40 + l;
+  const bool active = c4 < c4n;
+  float4 accw[9];
+#pragma unroll
+  for (int tp = 0; tp < 9; ++tp) accw[tp] = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (active) {
+    float4 kf[9];   // flipped taps for the data gradient
+#pragma unroll
+    for (int tp = 0; tp < 9; ++tp) kf[tp] = *reinterpret_cast<const float4*>(wt + (long)(8 - tp) * C + c4 * 4);
+    float4 accd[RS];
+#pragma unroll
+    for (int r = 0; r < RS; ++r) accd[r] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int rr = 0; rr < RS + 2; ++rr) {
+      const int o = ((strip * RS + rr) * PW + tcol) * CC4 + l;
+      const float4 g0 = tdz[o], g1 = tdz[o + CC4], g2 = tdz[o + 2 * CC4];
+      const float4 x0 = tx[o], x1 = tx[o + CC4], x2 = tx[o + 2 * CC4];
+#pragma unroll
+      for (int kh = 0; kh < 3; ++kh) {
+        const int r = rr - kh;               // output row of this strip fed by tile row rr through tap row kh
+        if (r >= 0 && r < RS) {
+          f4_fma(accd[r], g0, kf[kh * 3 + 0]);
+          f4_fma(accd[r], g1, kf[kh * 3 + 1]);
+          f4_fma(accd[r], g2, kf[kh * 3 + 2]);
+          // weight gradient: x row rr, tap row kh, times dz at the centre of output row r
+          const float4 gc = tdz[((strip * RS + r + 1) * PW + tcol + 1) * CC4 + l];
+          f4_fma(accw[kh * 3 + 0], x0, gc);
+          f4_fma(accw[kh * 3 + 1], x1, gc);
+          f4_fma(accw[kh * 3 + 2], x2, gc);
+        }
+      }
+    }
+    const int w = w0 + tcol;
+    if (w < W) {
+#pragma unroll
+      for (int r = 0; r < RS; ++r) {
+        const int h = h0 + strip * RS + r;
+        if (h < H) {
+          const long o = ibase + ((long)h * W + w) * C + c4 * 4;
+          float4 res = accd[r];
+          if (relu_in) {
+            const float4 xm = tx[((strip * RS + r + 1) * PW + tcol + 1) * CC4 + l];
+            res.x = xm.x > 0.f ? res.x : 0.f;
+            res.y = xm.y > 0.f ? res.y : 0.f;
+            res.z = xm.z > 0.f ? res.z : 0.f;
+            res.w = xm.w > 0.f ? res.w : 0.f;
+          }
+          if (add) {
+            const float4 a = *reinterpret_cast<const float4*>(add + o);
+            res.x += a.x; res.y += a.y; res.z += a.z; res.w += a.w;
+          }
+          *reinterpret_cast<float4*>(dx + o) = res;
+        }
+      }
+    }
+  }
+  // combine the 9 tap sums over the GROUP threads of each channel quad (fixed order), one partial row
+  // per spatial workgroup
+  __syncthreads();
+  const int grp = tid / CC4;                 // 0..GROUP-1
+#pragma unroll
+  for (int tp = 0; tp < 9; ++tp) tile[(tp * GROUP + grp) * CC4 + l] = accw[tp];
+  __syncthreads();
+  if (tid < 9 * CC4) {
+    const int tp = tid / CC4, ll = tid % CC4;
+    const int c4o = c40 + ll;
+    if (c4o < c4n) {
+      float4 s = tile[(tp * GROUP) * CC4 + ll];
+      for (int g = 1; g < GROUP; ++g) {
+        const float4 v = tile[(tp * GROUP + g) * CC4 + ll];
+        s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+      }
+      *reinterpret_cast<float4*>(partial + ((long)sp * 9 + tp) * C + c4o * 4) = s;
+    }
+  }
+}
+
+// out[l] = sum_p in[p*L + l]   (deterministic order; used by several two-stage reductions).
+// Workgroup = 16 columns x 16 interleaved row groups; grid.y > 1 splits the rows into grid.y strided
+// slices written to out[y*L + l] (a second call then folds the slices).
 __global__ __launch_bounds__(256) void reduce_rows_kernel(const float* __restrict__ in, int P, int L,
                                                           float* __restrict__ out) {
-  __shared__ float red[4][64];
-  const int col = blockIdx.x * 64 + (threadIdx.x & 63);
-  const int g = threadIdx.x >> 6;
+  __shared__ float red[16][16];
+  const int lane = threadIdx.x & 15, g = threadIdx.x >> 4;
+  const int col = blockIdx.x * 16 + lane;
   float s = 0.f;
-  if (col < L)
-    for (int p = g; p < P; p += 4) s += in[(long)p * L + col];
-  red[g][threadIdx.x & 63] = s;
+  if (col < L) {
+#pragma unroll 4
+    for (int p = blockIdx.y + g * gridDim.y; p < P; p += 16 * gridDim.y) s += in[(long)p * L + col];
+  }
+  red[g][lane] = s;
   __syncthreads();
-  if (g == 0 && col < L) out[col] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+  if (g == 0 && col < L) {
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) t += red[k][lane];
+    out[(long)blockIdx.y * L + col] = t;
+  }
+}
+
+// Fold P rows of L floats into out[L].  For many rows a first pass leaves 32 slices at the tail of the
+// input buffer's own rows 0..31 region is NOT touched: the slices go to `scratch` (32*L floats).
+static void launch_reduce_rows(const float* in, int P, int L, float* out, float* scratch, hipStream_t st) {
+  const int gx = (L + 15) / 16;
+  if (P > 128 && scratch) {
+    hipLaunchKernelGGL(reduce_rows_kernel, dim3(gx, 32), dim3(256), 0, st, in, P, L, scratch);
+    hipLaunchKernelGGL(reduce_rows_kernel, dim3(gx, 1), dim3(256), 0, st, scratch, 32, L, out);
+  } else {
+    hipLaunchKernelGGL(reduce_rows_kernel, dim3(gx, 1), dim3(256), 0, st, in, P, L, out);
+  }
 }
 
 static int chan_lanes(int c4n) {
@@ -258,14 +475,66 @@ extern "C" int spnet_dwconv3x3_bwd_weight(const float* x, const float* dy, float
   const size_t shm = (size_t)by * 9 * cl * sizeof(float4);
   hipLaunchKernelGGL(dw3x3_bwd_weight_partial_kernel, grid, block, shm, (hipStream_t)stream, x, dy,
                      workspace, B, H, W, C, relu_in);
-  const int L = 9 * C;
-  hipLaunchKernelGGL(reduce_rows_kernel, dim3((L + 63) / 64), dim3(256), 0, (hipStream_t)stream,
-                     workspace, (int)gy, L, dw);
+  launch_reduce_rows(workspace, (int)gy, 9 * C, dw, nullptr, (hipStream_t)stream);
   SPNET_RETURN_LAUNCH_STATUS();
 }
 
 extern "C" int spnet_reduce_rows(const float* in, int P, int L, float* out, void* stream) {
-  hipLaunchKernelGGL(reduce_rows_kernel, dim3((L + 63) / 64), dim3(256), 0, (hipStream_t)stream, in,
-                     P, L, out);
+  launch_reduce_rows(in, P, L, out, nullptr, (hipStream_t)stream);
+  SPNET_RETURN_LAUNCH_STATUS();
+}
+
+// ---------------------------------------------------------------- tiled entry points
+struct DwGeom { int cfg, th, tw, cc4, tiles_h, tiles_w, cchunks; long nblk; size_t lds_fwd, lds_bwd; };
+static DwGeom dw_geom(int B, int H, int W, int C) {
+  DwGeom g;
+  g.cfg = (H <= 6 && W <= 8) ? 1 : 0;       // 1: 6x8 tile x 16 quads (exit flow); 0: 12x16 tile x 8 quads
+  g.th = g.cfg ? 6 : 12;
+  g.tw = g.cfg ? 8 : 16;
+  g.cc4 = g.cfg ? 16 : 8;
+  g.tiles_h = (H + g.th - 1) / g.th;
+  g.tiles_w = (W + g.tw - 1) / g.tw;
+  g.cchunks = (C / 4 + g.cc4 - 1) / g.cc4;
+  g.nblk = (long)B * g.tiles_h * g.tiles_w * g.cchunks;
+  g.lds_fwd = (size_t)(g.th + 2) * (g.tw + 2) * g.cc4 * sizeof(float4);
+  g.lds_bwd = 2 * g.lds_fwd;
+  return g;
+}
+
+extern "C" int spnet_dwconv3x3_tiled_fwd(const float* x, const float* w, float* y, int B, int H, int W,
+                                         int C, int relu_in, void* stream) {
+  if (C & 3) return (int)hipErrorInvalidValue;
+  const DwGeom g = dw_geom(B, H, W, C);
+  if (g.cfg)
+    hipLaunchKernelGGL((dw3x3_tile_fwd_kernel<16, 8, 3, 2>), dim3((unsigned)g.nblk), dim3(256), g.lds_fwd,
+                       (hipStream_t)stream, x, w, y, H, W, C, relu_in, g.tiles_h, g.tiles_w, g.cchunks);
+  else
+    hipLaunchKernelGGL((dw3x3_tile_fwd_kernel<8, 16, 6, 2>), dim3((unsigned)g.nblk), dim3(256), g.lds_fwd,
+                       (hipStream_t)stream, x, w, y, H, W, C, relu_in, g.tiles_h, g.tiles_w, g.cchunks);
+  SPNET_RETURN_LAUNCH_STATUS();
+}
+
+// floats of workspace needed by spnet_dwconv3x3_tiled_bwd
+extern "C" long spnet_dwconv3x3_tiled_bwd_ws(int B, int H, int W, int C) {
+  const DwGeom g = dw_geom(B, H, W, C);
+  return ((long)B * g.tiles_h * g.tiles_w + 32) * 9 * C;      // partial rows + 32 second-level slices
+}
+
+// Fused backward: dx = dw3x3(dy, flip w) * (x_fwd > 0 if relu_in) (+ add);  dw[3][3][C] = weight gradient.
+extern "C" int spnet_dwconv3x3_tiled_bwd(const float* dy, const float* x_fwd, const float* w, float* dx,
+                                         float* dw, int B, int H, int W, int C, int relu_in,
+                                         const float* add, float* workspace, void* stream) {
+  if (C & 3) return (int)hipErrorInvalidValue;
+  const DwGeom g = dw_geom(B, H, W, C);
+  if (g.cfg)
+    hipLaunchKernelGGL((dw3x3_tile_bwd_kernel<16, 8, 3, 2>), dim3((unsigned)g.nblk), dim3(256), g.lds_bwd,
+                       (hipStream_t)stream, dy, x_fwd, w, dx, workspace, add, H, W, C, relu_in, g.tiles_h,
+                       g.tiles_w, g.cchunks);
+  else
+    hipLaunchKernelGGL((dw3x3_tile_bwd_kernel<8, 16, 6, 2>), dim3((unsigned)g.nblk), dim3(256), g.lds_bwd,
+                       (hipStream_t)stream, dy, x_fwd, w, dx, workspace, add, H, W, C, relu_in, g.tiles_h,
+                       g.tiles_w, g.cchunks);
+  const int P = B * g.tiles_h * g.tiles_w, L = 9 * C;
+  launch_reduce_rows(workspace, P, L, dw, workspace + (long)P * L, (hipStream_t)stream);
   SPNET_RETURN_LAUNCH_STATUS();
 }

@@ -3,7 +3,7 @@
 //
 // Replaces the TensorFlow/cuDNN kernels behind keras SeparableConv2D's pointwise step, Conv2D(1x1)
 // and Dense (call sites spnet/models.py:357-359, 388).  Arithmetic is exact f32: the
-// v_mfma_f32_32x32x2_f32 instruction is a k-ordered fmaf chain (one rounding per product), so the
+// v_mfma_f32_16x16x4_f32 instruction is a k-ordered fmaf chain (one rounding per product), so the
 // result equals a plain f32 dot product evaluated in k order.
 //
 // Operand layouts ("major" = which index is contiguous in memory):
@@ -11,22 +11,28 @@
 //      OUT_MAJOR : A(m,k) = A[k*lda + m]      (wgrad: A = X^T, read without a transpose pass)
 //   B  OUT_MAJOR : B(k,n) = B[k*ldb + n]      (weights [Cin][Cout]: forward; dY in wgrad)
 //      K_MAJOR   : B(k,n) = B[n*ldb + k]      (dgrad: B = W^T read in place)
-// LDS image of both operands is [k][row] with row contiguous, so that the 32 lanes of an MFMA
-// operand fetch read 32 consecutive dwords (conflict-free ds_read_b32).
+// Each operand's LDS image keeps its own major (see TileStage): operand fetches are conflict-free
+// ds_read_b32 and no staging pass transposes.
 //
 // Split-K: grid.z slices write fp32 slabs to a workspace, a second kernel sums them in slice order
 // (deterministic; no float atomics).
 #include "common.h"
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 enum { SP_K_MAJOR = 0, SP_OUT_MAJOR = 1 };
 
+// One operand tile (BR output rows/cols x BK reduction steps) staged global -> registers -> LDS.
+// The LDS image keeps the operand's own major, so no staging pass transposes anything:
+//   K_MAJOR   image [r][k], leading dim BK+2 : the 16 rows x 2 k of a 32-lane fetch group land on
+//             banks (2r + k) % 32, all distinct; rows are 8-byte aligned -> two ds_write_b64 per float4
+//   OUT_MAJOR image [k][r], leading dim BR+16: 16 consecutive r per k, the next k 16 banks further
 template <int BR, int BK, int MAJ>
 struct TileStage {
   static constexpr int TOTAL = BR * BK / 4;            // float4 per tile
   static constexpr int NV = (TOTAL + 255) / 256;       // float4 per thread
-  static constexpr int LD = BR + 4;
+  static constexpr int LD = (MAJ == SP_K_MAJOR) ? (BK + 2) : (BR + 16);
+  static constexpr int SIZE = (MAJ == SP_K_MAJOR) ? BR * LD : BK * LD;
   float4 v[NV];
 
   __device__ __forceinline__ void load(const float* __restrict__ P, int ld, int r0, int R, int k0,
@@ -60,17 +66,22 @@ struct TileStage {
           *reinterpret_cast<float4*>(S + k * LD + r4 * 4) = v[i];
         } else {
           const int r = f / (BK / 4), kq = f % (BK / 4);
-          float* s = S + (kq * 4) * LD + r;
-          s[0] = v[i].x;
-          s[LD] = v[i].y;
-          s[2 * LD] = v[i].z;
-          s[3 * LD] = v[i].w;
+          float2* s = reinterpret_cast<float2*>(S + r * LD + kq * 4);
+          s[0] = make_float2(v[i].x, v[i].y);
+          s[1] = make_float2(v[i].z, v[i].w);
         }
       }
     }
   }
+
+  // element (row r of the tile, reduction index k of the tile)
+  static __device__ __forceinline__ float fetch(const float* __restrict__ S, int r, int k) {
+    return (MAJ == SP_K_MAJOR) ? S[r * LD + k] : S[k * LD + r];
+  }
 };
 
+// 4 waves (WM x WN), each wave owns a (BM/WM) x (BN/WN) block built from 16x16 MFMA tiles
+// (v_mfma_f32_16x16x4_f32: A[l&15][k=l>>4], B[k=l>>4][l&15], D col=l&15,row=4*(l>>4)+reg).
 template <int BM, int BN, int BK, int WM, int WN, int AMAJ, int BMAJ>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__ A, int lda,
                                                        const float* __restrict__ B, int ldb,
@@ -79,10 +90,11 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
                                                        int tiles_m, int tiles_n, int nsplit,
                                                        const float* __restrict__ bias) {
   static_assert(WM * WN == 4, "4 waves per workgroup");
-  constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
-  static_assert(TM >= 1 && TN >= 1, "wave tile");
-  constexpr int LDA = BM + 4, LDB = BN + 4;
-  constexpr int STAGE = BK * (LDA + LDB);
+  constexpr int TM = BM / WM / 16, TN = BN / WN / 16;
+  static_assert(TM >= 1 && TN >= 1 && (BM % (WM * 16)) == 0 && (BN % (WN * 16)) == 0, "wave tile");
+  typedef TileStage<BM, BK, AMAJ> SA;
+  typedef TileStage<BN, BK, BMAJ> SB;
+  constexpr int STAGE = SA::SIZE + SB::SIZE;
   __shared__ __attribute__((aligned(16))) float smem[2 * STAGE];
 
   const int tid = threadIdx.x;
@@ -102,52 +114,55 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
   const int kend = min(K, kbeg + k_chunk);
   const int nt = (kend - kbeg + BK - 1) / BK;
 
-  f32x16 acc[TM][TN];
+  f32x4 acc[TM][TN];
 #pragma unroll
   for (int i = 0; i < TM; ++i)
 #pragma unroll
     for (int j = 0; j < TN; ++j)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+      for (int r = 0; r < 4; ++r) acc[i][j][r] = 0.f;
 
-  TileStage<BM, BK, AMAJ> sa;
-  TileStage<BN, BK, BMAJ> sb;
+  SA sa;
+  SB sb;
 
   if (nt > 0) {
     sa.load(A, lda, m0, M, kbeg, kend, tid);
     sb.load(B, ldb, n0, N, kbeg, kend, tid);
     sa.store(smem, tid);
-    sb.store(smem + BK * LDA, tid);
+    sb.store(smem + SA::SIZE, tid);
   }
   __syncthreads();
 
+  const int arow = wm * (TM * 16) + (lane & 15);
+  const int bcol = wn * (TN * 16) + (lane & 15);
+  const int kq = lane >> 4;
+
   for (int t = 0; t < nt; ++t) {
-    float* cur = smem + (t & 1) * STAGE;
+    const float* cur = smem + (t & 1) * STAGE;
     float* nxt = smem + ((t + 1) & 1) * STAGE;
     const bool more = (t + 1 < nt);
     if (more) {
       sa.load(A, lda, m0, M, kbeg + (t + 1) * BK, kend, tid);
       sb.load(B, ldb, n0, N, kbeg + (t + 1) * BK, kend, tid);
     }
-    const float* as = cur + wm * (TM * 32) + (lane & 31);
-    const float* bs = cur + BK * LDA + wn * (TN * 32) + (lane & 31);
+    const float* as = cur;
+    const float* bs = cur + SA::SIZE;
 #pragma unroll
-    for (int kk = 0; kk < BK; kk += 2) {
-      const int ka = kk + (lane >> 5);
+    for (int kk = 0; kk < BK; kk += 4) {
       float a[TM], b[TN];
 #pragma unroll
-      for (int i = 0; i < TM; ++i) a[i] = as[ka * LDA + i * 32];
+      for (int i = 0; i < TM; ++i) a[i] = SA::fetch(as, arow + i * 16, kk + kq);
 #pragma unroll
-      for (int j = 0; j < TN; ++j) b[j] = bs[ka * LDB + j * 32];
+      for (int j = 0; j < TN; ++j) b[j] = SB::fetch(bs, bcol + j * 16, kk + kq);
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[i][j], 0, 0, 0);
     }
     if (more) {
       sa.store(nxt, tid);
-      sb.store(nxt + BK * LDA, tid);
+      sb.store(nxt + SA::SIZE, tid);
     }
     __syncthreads();
   }
@@ -157,13 +172,13 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
   for (int i = 0; i < TM; ++i) {
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
-      const int col = n0 + wn * (TN * 32) + j * 32 + (lane & 31);
-      const int rbase = m0 + wm * (TM * 32) + i * 32 + 4 * (lane >> 5);
+      const int col = n0 + wn * (TN * 16) + j * 16 + (lane & 15);
+      const int rbase = m0 + wm * (TM * 16) + i * 16 + 4 * (lane >> 4);
       if (col < N) {
         const float bv = bias ? bias[col] : 0.f;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int row = rbase + (r & 3) + 8 * (r >> 2);
+        for (int r = 0; r < 4; ++r) {
+          const int row = rbase + r;
           if (row < M) Cz[(long)row * ldc + col] = acc[i][j][r] + bv;
         }
       }
@@ -194,11 +209,15 @@ __global__ __launch_bounds__(256) void reduce_slabs_kernel(const float* __restri
   }
 }
 
+#ifndef SP_BK
+#define SP_BK 32
+#endif
+
 template <int BM, int BN, int WM, int WN>
 static int launch_tile(const float* A, int amaj, int lda, const float* B, int bmaj, int ldb, float* C,
                        int ldc, int M, int N, int K, int nsplit, int k_chunk, long slab_stride,
                        const float* bias, hipStream_t st) {
-  constexpr int BK = 16;
+  constexpr int BK = SP_BK;
   const int tm = spnet_cdiv(M, BM), tn = spnet_cdiv(N, BN);
   dim3 grid(tm * tn * nsplit), block(256);
 #define SP_LAUNCH(AM, BMJ)                                                                          \
@@ -212,30 +231,48 @@ static int launch_tile(const float* A, int amaj, int lda, const float* B, int bm
   return 0;
 }
 
-// Tile ids: 0 = auto, 1 = 128x128, 2 = 128x64, 3 = 64x64, 4 = 32x128
+// Tile ids: 0 = auto, 1 = 128x128, 2 = 128x64, 3 = 64x64, 4 = 32x128, 5 = 96x96
+#define SP_NTILES 5
 static void tile_dims(int tile, int* bm, int* bn) {
   switch (tile) {
     case 1: *bm = 128; *bn = 128; break;
     case 2: *bm = 128; *bn = 64; break;
     case 3: *bm = 64; *bn = 64; break;
+    case 5: *bm = 96; *bn = 96; break;
     default: *bm = 32; *bn = 128; break;
   }
 }
 
-static int pick_tile(int M, int N) {
+// Automatic K split of one tile shape: enough workgroups for ~2 per CU, slices at least 4 K-tiles deep.
+static int auto_split(long tiles, int M, int N, int K, bool have_ws, long ws_floats) {
+  if (tiles >= 512 || !have_ws) return 1;
+  long want = (512 + tiles - 1) / tiles;
+  long maxk = K / (SP_BK * 4);
+  if (maxk < 1) maxk = 1;
+  if (want > maxk) want = maxk;
+  const long fit = ws_floats / ((long)M * N);
+  if (want > fit) want = fit;
+  return want > 1 ? (int)want : 1;
+}
+
+// cost ~ rounds over the 256 CUs x work per workgroup / tile efficiency.  The 96x96 tile exists for the
+// network's dominant shape, M = batch*12*16 = 6144 rows x 728 channels: 64 x 8 = 512 tiles = exactly two
+// per CU, where 128x128 leaves 288 tiles (1.125 rounds) and 64x64 pays twice the LDS traffic per FLOP.
+static int pick_tile(int M, int N, int K, int split_k, bool have_ws, long ws_floats) {
   if (M <= 32) return 4;
-  // cost ~ (rounds over 2 resident workgroups per CU) x tile area / tile efficiency
-  const double eff[4] = {0.0, 1.00, 0.92, 0.80};
+  const int cand[4] = {1, 5, 2, 3};
+  const double eff[4] = {1.00, 0.97, 0.90, 0.85};
   int best = 1;
   double best_cost = 1e300;
-  for (int t = 1; t <= 3; ++t) {
+  for (int c = 0; c < 4; ++c) {
     int bm, bn;
-    tile_dims(t, &bm, &bn);
-    const double blocks = (double)spnet_cdiv(M, bm) * spnet_cdiv(N, bn);
-    double rounds = blocks / 512.0;
-    rounds = rounds < 1.0 ? 1.0 : (double)(long)(rounds + 0.999);
-    const double cost = rounds * bm * bn / eff[t];
-    if (cost < best_cost) { best_cost = cost; best = t; }
+    tile_dims(cand[c], &bm, &bn);
+    const long tiles = (long)spnet_cdiv(M, bm) * spnet_cdiv(N, bn);
+    const int ns = split_k > 0 ? split_k : auto_split(tiles, M, N, K, have_ws, ws_floats);
+    const double blocks = (double)tiles * ns;
+    double rounds = (double)(long)((blocks + 255.0) / 256.0);
+    const double cost = rounds * bm * bn * ((double)K / ns + 64.0) / eff[c];
+    if (cost < best_cost) { best_cost = cost; best = cand[c]; }
   }
   return best;
 }
@@ -250,24 +287,13 @@ extern "C" int spnet_gemm_f32(const float* A, int a_major, int lda, const float*
   if ((a_major == SP_K_MAJOR || b_major == SP_K_MAJOR) && (K & 3)) return (int)hipErrorInvalidValue;
   if (a_major == SP_OUT_MAJOR && (M & 3)) return (int)hipErrorInvalidValue;
   if (((uintptr_t)A | (uintptr_t)B | (uintptr_t)C) & 15) return (int)hipErrorInvalidValue;
-  if (tile <= 0 || tile > 4) tile = pick_tile(M, N);
+  if (tile <= 0 || tile > SP_NTILES) tile = pick_tile(M, N, K, split_k, workspace != nullptr, ws_floats);
   int bm, bn;
   tile_dims(tile, &bm, &bn);
   const long tiles = (long)spnet_cdiv(M, bm) * spnet_cdiv(N, bn);
-  const int BK = 16;
+  const int BK = SP_BK;
   int nsplit = split_k;
-  if (nsplit <= 0) {  // auto: enough workgroups for ~2 per CU, each slice at least 4 K-tiles deep
-    nsplit = 1;
-    if (tiles < 512 && workspace) {
-      long want = (512 + tiles - 1) / tiles;
-      long maxk = K / (BK * 4);
-      if (maxk < 1) maxk = 1;
-      if (want > maxk) want = maxk;
-      long fit = ws_floats / ((long)M * N);
-      if (want > fit) want = fit;
-      if (want > 1) nsplit = (int)want;
-    }
-  }
+  if (nsplit <= 0) nsplit = auto_split(tiles, M, N, K, workspace != nullptr, ws_floats);
   int k_chunk = ((K + nsplit - 1) / nsplit + BK - 1) / BK * BK;
   nsplit = (K + k_chunk - 1) / k_chunk;
   float* out = C;
@@ -287,6 +313,7 @@ extern "C" int spnet_gemm_f32(const float* A, int a_major, int lda, const float*
     case 1: rc = launch_tile<128, 128, 2, 2>(A, a_major, lda, B, b_major, ldb, out, out_ld, M, N, K, nsplit, k_chunk, slab, kbias, st); break;
     case 2: rc = launch_tile<128, 64, 2, 2>(A, a_major, lda, B, b_major, ldb, out, out_ld, M, N, K, nsplit, k_chunk, slab, kbias, st); break;
     case 3: rc = launch_tile<64, 64, 2, 2>(A, a_major, lda, B, b_major, ldb, out, out_ld, M, N, K, nsplit, k_chunk, slab, kbias, st); break;
+    case 5: rc = launch_tile<96, 96, 2, 2>(A, a_major, lda, B, b_major, ldb, out, out_ld, M, N, K, nsplit, k_chunk, slab, kbias, st); break;
     default: rc = launch_tile<32, 128, 1, 4>(A, a_major, lda, B, b_major, ldb, out, out_ld, M, N, K, nsplit, k_chunk, slab, kbias, st); break;
   }
   if (rc) return rc;

@@ -164,22 +164,36 @@ __global__ __launch_bounds__(256) void conv3x3_wide_bwd_weight_kernel(const floa
 #pragma unroll
   for (int j = 0; j < PER; ++j) acc[j] = 0.f;
   const long total = (long)Bn * OH * OW;
-  for (long p = blockIdx.x; p < total; p += gridDim.x) {
-    const int ow = (int)(p % OW);
-    long t = p / OW;
-    const int oh = (int)(t % OH);
-    const int b = (int)(t / OH);
-    const float g = dy[p * COUT + co];
+  // PB pixels per trip with all their loads issued before the FMAs: the loop is latency-bound
+  // (a handful of dependent-free scalar loads per pixel), so memory-level parallelism is what counts.
+  constexpr int PB = 8;
+  for (long p0 = (long)blockIdx.x * PB; p0 < total; p0 += (long)gridDim.x * PB) {
+    float g[PB], xv[PB][PER];
 #pragma unroll
-    for (int j = 0; j < PER; ++j) {
-      const int tc = grp * PER + j;
-      if (tc < NTC) {
-        const int tap = tc / CIN, ci = tc % CIN;
-        const int h = oh * STRIDE - PAD + tap / 3, ww = ow * STRIDE - PAD + tap % 3;
-        const float xv = (h >= 0 && h < H && ww >= 0 && ww < W) ? x[(((long)b * H + h) * W + ww) * CIN + ci] : 0.f;
-        acc[j] = fmaf(xv, g, acc[j]);
+    for (int u = 0; u < PB; ++u) {
+      const long p = p0 + u;
+      const bool pv = p < total;
+      const int ow = pv ? (int)(p % OW) : 0;
+      const long t = pv ? p / OW : 0;
+      const int oh = (int)(t % OH);
+      const int b = (int)(t / OH);
+      g[u] = pv ? dy[p * COUT + co] : 0.f;
+#pragma unroll
+      for (int j = 0; j < PER; ++j) {
+        const int tc = grp * PER + j;
+        float v = 0.f;
+        if (pv && tc < NTC) {
+          const int tap = tc / CIN, ci = tc % CIN;
+          const int h = oh * STRIDE - PAD + tap / 3, ww = ow * STRIDE - PAD + tap % 3;
+          if (h >= 0 && h < H && ww >= 0 && ww < W) v = x[(((long)b * H + h) * W + ww) * CIN + ci];
+        }
+        xv[u][j] = v;
       }
     }
+#pragma unroll
+    for (int u = 0; u < PB; ++u)
+#pragma unroll
+      for (int j = 0; j < PER; ++j) acc[j] = fmaf(xv[u][j], g[u], acc[j]);
   }
 #pragma unroll
   for (int j = 0; j < PER; ++j) {

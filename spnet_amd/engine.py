@@ -563,8 +563,8 @@ class SepConvBN:
         prof = e.prof
         if prof is not None:
             t0 = prof.start()
-        L.spnet_dwconv3x3_fwd(L.ptr(self.x), L.ptr(self.wd), L.ptr(self.z), e.B, self.H, self.W, self.cin,
-                              self.relu_in, _stream())
+        L.spnet_dwconv3x3_tiled_fwd(L.ptr(self.x), L.ptr(self.wd), L.ptr(self.z), e.B, self.H, self.W, self.cin,
+                                    self.relu_in, _stream())
         if prof is not None:
             prof.stop("dw", t0, 2.0 * 4 * self.M * self.cin)        # read x + write z
         self.pw.fwd(self.z, self.yp)
@@ -579,10 +579,8 @@ class SepConvBN:
         prof = e.prof
         if prof is not None:
             t0 = prof.start()
-        L.spnet_dwconv3x3_bwd_weight(L.ptr(self.x), L.ptr(self.dz), L.ptr(self.gwd), e.B, self.H, self.W,
-                                     self.cin, self.relu_in, L.ptr(e.ws), _stream())
-        L.spnet_dwconv3x3_bwd_data(L.ptr(self.dz), L.ptr(self.wd), L.ptr(self.dx), e.B, self.H, self.W, self.cin,
-                                   self.relu_in, L.ptr(self.x) if self.relu_in else None, L.ptr(add), _stream())
+        L.spnet_dwconv3x3_tiled_bwd(L.ptr(self.dz), L.ptr(self.x), L.ptr(self.wd), L.ptr(self.dx), L.ptr(self.gwd),
+                                    e.B, self.H, self.W, self.cin, self.relu_in, L.ptr(add), L.ptr(e.ws), _stream())
         if prof is not None:
             prof.stop("dw", t0, 3.0 * 4 * self.M * self.cin)        # read dz, read x, write dx
         return self.dx

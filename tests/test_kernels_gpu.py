@@ -36,7 +36,7 @@ WS = 8 * 1024 * 1024
 
 @pytest.mark.parametrize("M,N,K", [(128, 128, 64), (6144, 728, 728), (100, 728, 256), (37, 64, 288), (32, 576, 4096),
                                    (1000, 128, 64), (4, 12, 8)])
-@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4])
+@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4, 5])
 def test_gemm_forward_form(L, M, N, K, tile):
     rs = np.random.RandomState(M + N + K)
     A, B = rs.randn(M, K).astype(np.float32), rs.randn(K, N).astype(np.float32)
@@ -122,6 +122,31 @@ def test_dwconv(L, B, H, W, C, relu_in):
     dwd = torch.empty(3, 3, C, device="cuda")
     L.spnet_dwconv3x3_bwd_weight(xd.data_ptr(), dyd.data_ptr(), dwd.data_ptr(), B, H, W, C, relu_in, ws.data_ptr(), st())
     close(dwd, w.grad, rtol=1e-4, atol=1e-4 * np.sqrt(B * H * W))
+
+
+@pytest.mark.parametrize("B,H,W,C", [(2, 12, 16, 728), (3, 7, 5, 64), (1, 93, 125, 128), (2, 6, 8, 1536), (1, 1, 1, 8),
+                                     (2, 24, 32, 256), (1, 47, 63, 128), (2, 13, 17, 40)])
+@pytest.mark.parametrize("relu_in", [0, 1])
+def test_dwconv_tiled(L, B, H, W, C, relu_in):
+    """LDS-tiled forward and FUSED backward (data + weight gradient) -- the forms the engine uses."""
+    rs = np.random.RandomState(C + H + 1)
+    x = torch.tensor(rs.randn(B, H, W, C), dtype=torch.float32, requires_grad=True)
+    w = torch.tensor(rs.randn(3, 3, C) * 0.3, dtype=torch.float32, requires_grad=True)
+    add = torch.tensor(rs.randn(B, H, W, C), dtype=torch.float32)
+    y = T.dwconv3x3(torch.relu(x) if relu_in else x, w)
+    dy = torch.tensor(rs.randn(B, H, W, C), dtype=torch.float32)
+    y.backward(dy)
+    xd, wd, dyd, addd = x.detach().cuda(), w.detach().cuda(), dy.cuda(), add.cuda()
+    yd = torch.full_like(xd, float("nan"))
+    L.spnet_dwconv3x3_tiled_fwd(xd.data_ptr(), wd.data_ptr(), yd.data_ptr(), B, H, W, C, relu_in, st())
+    close(yd, y.detach(), rtol=1e-5, atol=1e-5)
+    ws = torch.empty(L.spnet_dwconv3x3_tiled_bwd_ws(B, H, W, C), device="cuda")
+    dxd, dwd = torch.full_like(xd, float("nan")), torch.full((3, 3, C), float("nan"), device="cuda")
+    for use_add in (True, False):
+        L.spnet_dwconv3x3_tiled_bwd(dyd.data_ptr(), xd.data_ptr(), wd.data_ptr(), dxd.data_ptr(), dwd.data_ptr(), B, H, W, C,
+                                    relu_in, addd.data_ptr() if use_add else None, ws.data_ptr(), st())
+        close(dxd, x.grad + add if use_add else x.grad, rtol=1e-5, atol=1e-5)
+        close(dwd, w.grad, rtol=1e-4, atol=1e-4 * np.sqrt(B * H * W))
 
 
 @pytest.mark.parametrize("M,C", [(6144, 728), (50, 64), (23250, 128), (4096, 3), (7, 2048), (3000, 32)])
