@@ -33,6 +33,12 @@ extern "C" {
 int spnet_gemm_f32(const float* A, int a_major, int lda, const float* B, int b_major, int ldb, float* C,
                    int ldc, int M, int N, int K, int split_k, float* workspace, long ws_floats,
                    const float* bias, int tile, void* stream);
+/* Same contraction (no split-K, no bias) that also emits BatchNorm column statistics of C from the
+ * accumulators: colstats[rows][2][N] per row-tile (sum, sum of squares), *stat_rows (HOST int) = rows.
+ * colstats must hold ceil(M/32)*2*N floats. */
+int spnet_gemm_f32_colstats(const float* A, int a_major, int lda, const float* B, int b_major, int ldb,
+                            float* C, int ldc, int M, int N, int K, int tile, float* colstats,
+                            int* stat_rows, void* stream);
 
 /* 3x3 VALID stride-1 patch matrix and its adjoint (block1_conv2 of keras Xception). */
 int spnet_im2col3x3(const float* x, float* col, int B, int H, int W, int C, void* stream);
@@ -55,11 +61,15 @@ int spnet_reduce_rows(const float* in, int P, int L, float* out, void* stream);
 /* LDS-tiled forms used by the engine: forward, and the FUSED backward (data + weight gradient in one
  * pass over x and dy).  workspace: spnet_dwconv3x3_tiled_bwd_ws(B,H,W,C) floats. */
 int spnet_dwconv3x3_tiled_fwd(const float* x, const float* w, float* y, int B, int H, int W, int C,
-                              int relu_in, void* stream);
+                              int relu_in, const float* in_scale, const float* in_shift, void* stream);
 long spnet_dwconv3x3_tiled_bwd_ws(int B, int H, int W, int C);
+long spnet_dwconv3x3_tiled_rows(int B, int H, int W, int C);
+/* in_scale/in_shift (or NULL): the producer BatchNorm's affine applied on load (x_fwd is then the PRE-BN
+ * tensor); bn_partial (or NULL): also emit that BatchNorm's backward sums [rows][2][C]. */
 int spnet_dwconv3x3_tiled_bwd(const float* dy, const float* x_fwd, const float* w, float* dx, float* dw,
                               int B, int H, int W, int C, int relu_in, const float* add, float* workspace,
-                              void* stream);
+                              const float* in_scale, const float* in_shift, const float* bn_mean,
+                              const float* bn_invstd, float* bn_partial, void* stream);
 
 /* ---- BatchNormalization(axis=-1, momentum .99, eps 1e-3) (spnet/models.py:326-336 + 40 in Xception) --- */
 /* act: 0 none, 1 ReLU, 2 LeakyReLU(0.1) fused behind the affine; residual (or NULL) added last;
@@ -76,12 +86,26 @@ int spnet_bn_fwd_infer(const float* x, long M, int C, const float* gamma, const 
 int spnet_bn_bwd(const float* x, const float* dy, long M, int C, const float* gamma, const float* beta,
                  const float* save_mean, const float* save_invstd, int act, float* dx, float* dgamma,
                  float* dbeta, float* coeffs, float* workspace, void* stream);
+/* Split forms for fused pipelines: statistics arrive as partial[P][2][C] from a GEMM epilogue
+ * (spnet_gemm_f32_colstats) or from the fused depthwise backward. */
+int spnet_bn_finalize_fwd(const float* partial, int P, long M, int C, const float* gamma, const float* beta,
+                          float* moving_mean, float* moving_var, float* save_mean, float* save_invstd,
+                          float* scale_shift, float eps, float momentum, void* stream);
+int spnet_bn_infer_coeffs(int C, const float* gamma, const float* beta, const float* moving_mean,
+                          const float* moving_var, float* scale_shift, float eps, void* stream);
+int spnet_bn_apply(const float* x, long M, int C, const float* scale_shift, int act, const float* residual,
+                   int res_bcast, float* y, void* stream);
+int spnet_bn_bwd_from_partials(const float* x, const float* dy, long M, int C, const float* gamma,
+                               const float* beta, const float* save_mean, const float* save_invstd, int P,
+                               const float* partial, float* dx, float* dgamma, float* dbeta, float* coeffs,
+                               void* stream);
 
 /* ---- pooling --------------------------------------------------------------------------------- */
 /* MaxPooling2D(3, strides 2, 'same') + residual add (Xception blocks 2,3,4,13); idx4 packs the argmax
  * tap of 4 channels per uint32 (B*OH*OW*C/4 words) for the backward pass. */
+/* x_ss / r_ss (or NULL): [scale|shift] of the BatchNorm producing x / residual, applied on load. */
 int spnet_maxpool3x3s2_add_fwd(const float* x, const float* residual, float* y, uint32_t* idx4, int B,
-                               int H, int W, int C, void* stream);
+                               int H, int W, int C, const float* x_ss, const float* r_ss, void* stream);
 int spnet_maxpool3x3s2_bwd(const float* dy, const uint32_t* idx4, float* dx, int B, int H, int W, int C,
                            void* stream);
 /* AveragePooling2D(2) of the stem (spnet/models.py:323,337); any C. */

@@ -5,7 +5,7 @@ every wrapper raises on a non-zero HIP status.
 """
 import ctypes
 import os
-from ctypes import c_float, c_int, c_long, c_uint, c_void_p
+from ctypes import POINTER, byref, c_float, c_int, c_long, c_uint, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SPNET_HIP_LIB") or os.path.join(_HERE, "lib", "libspnet_hip.so")
@@ -30,14 +30,20 @@ _SIGS = {
     "spnet_dwconv3x3_bwd_weight_ws": (c_long, [c_int, c_int, c_int, c_int]),
     "spnet_dwconv3x3_bwd_weight": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, P, P]),
     "spnet_reduce_rows": (c_int, [P, c_int, c_int, P, P]),
-    "spnet_dwconv3x3_tiled_fwd": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, P]),
+    "spnet_dwconv3x3_tiled_fwd": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, P, P, P]),
     "spnet_dwconv3x3_tiled_bwd_ws": (c_long, [c_int, c_int, c_int, c_int]),
-    "spnet_dwconv3x3_tiled_bwd": (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, P, P, P]),
+    "spnet_dwconv3x3_tiled_rows": (c_long, [c_int, c_int, c_int, c_int]),
+    "spnet_dwconv3x3_tiled_bwd": (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, P, P, P, P, P, P, P, P]),
+    "spnet_bn_finalize_fwd": (c_int, [P, c_int, c_long, c_int, P, P, P, P, P, P, P, c_float, c_float, P]),
+    "spnet_bn_infer_coeffs": (c_int, [c_int, P, P, P, P, P, c_float, P]),
+    "spnet_bn_apply": (c_int, [P, c_long, c_int, P, c_int, P, c_int, P, P]),
+    "spnet_bn_bwd_from_partials": (c_int, [P, P, c_long, c_int, P, P, P, P, c_int, P, P, P, P, P, P]),
+    "spnet_gemm_f32_colstats": (c_int, [P, c_int, c_int, P, c_int, c_int, P, c_int, c_int, c_int, c_int, c_int, P, P, P]),
     "spnet_bn_ws": (c_long, [c_long, c_int]),
     "spnet_bn_fwd_train": (c_int, [P, c_long, c_int, P, P, P, P, P, P, P, c_int, P, c_int, P, c_float, c_float, P, P]),
     "spnet_bn_fwd_infer": (c_int, [P, c_long, c_int, P, P, P, P, P, c_int, P, c_int, P, c_float, P]),
     "spnet_bn_bwd": (c_int, [P, P, c_long, c_int, P, P, P, P, c_int, P, P, P, P, P, P]),
-    "spnet_maxpool3x3s2_add_fwd": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, P]),
+    "spnet_maxpool3x3s2_add_fwd": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, P, P, P]),
     "spnet_maxpool3x3s2_bwd": (c_int, [P, P, P, c_int, c_int, c_int, c_int, P]),
     "spnet_avgpool2_fwd": (c_int, [P, P, c_int, c_int, c_int, c_int, P]),
     "spnet_avgpool2_bwd": (c_int, [P, P, c_int, c_int, c_int, c_int, P]),

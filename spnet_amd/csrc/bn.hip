@@ -414,3 +414,51 @@ extern "C" int spnet_bn_bwd(const float* x, const float* dy, long M, int C, cons
   }
   SPNET_RETURN_LAUNCH_STATUS();
 }
+
+// ---------------------------------------------------------------- split entry points (fused pipelines)
+// The statistics may come from another kernel's epilogue (spnet_gemm_f32_colstats forward,
+// spnet_dwconv3x3_tiled_bwd backward) as partial[P][2][C]; these entries do only the remaining steps.
+
+// partial -> batch mean/invstd, scale_shift[2C], moving-stat update.  No pass over the activations.
+extern "C" int spnet_bn_finalize_fwd(const float* partial, int P, long M, int C, const float* gamma,
+                                     const float* beta, float* moving_mean, float* moving_var,
+                                     float* save_mean, float* save_invstd, float* scale_shift, float eps,
+                                     float momentum, void* stream) {
+  hipLaunchKernelGGL(bn_fwd_finalize_kernel, dim3((C + BN_FIN_CH - 1) / BN_FIN_CH), dim3(256), 0,
+                     (hipStream_t)stream, partial, P, C, M, gamma, beta, moving_mean, moving_var, save_mean,
+                     save_invstd, scale_shift, scale_shift + C, eps, momentum);
+  SPNET_RETURN_LAUNCH_STATUS();
+}
+
+// scale_shift[2C] from the moving statistics (inference).
+extern "C" int spnet_bn_infer_coeffs(int C, const float* gamma, const float* beta, const float* moving_mean,
+                                     const float* moving_var, float* scale_shift, float eps, void* stream) {
+  hipLaunchKernelGGL(bn_infer_coeffs_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, C, gamma,
+                     beta, moving_mean, moving_var, scale_shift, scale_shift + C, eps);
+  SPNET_RETURN_LAUNCH_STATUS();
+}
+
+// y = act(x*scale + shift) (+ residual)
+extern "C" int spnet_bn_apply(const float* x, long M, int C, const float* scale_shift, int act,
+                              const float* residual, int res_bcast, float* y, void* stream) {
+  if ((C & 3) && C > 4) return (int)hipErrorInvalidValue;
+  if (res_bcast && !(C & 3)) return (int)hipErrorInvalidValue;
+  launch_apply(x, M, C, scale_shift, scale_shift + C, act, residual, res_bcast, y, (hipStream_t)stream);
+  SPNET_RETURN_LAUNCH_STATUS();
+}
+
+// Backward given the two per-channel sums as partial[P][2][C] (sum g, sum g*xhat; g already includes
+// any activation mask): dgamma, dbeta, dx = k1*g + k2*xhat + k3.
+extern "C" int spnet_bn_bwd_from_partials(const float* x, const float* dy, long M, int C, const float* gamma,
+                                          const float* beta, const float* save_mean,
+                                          const float* save_invstd, int P, const float* partial, float* dx,
+                                          float* dgamma, float* dbeta, float* coeffs, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  if (C & 3) return (int)hipErrorInvalidValue;
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + BN_FIN_CH - 1) / BN_FIN_CH), dim3(256), 0, st, partial, P,
+                     C, M, gamma, save_invstd, dgamma, dbeta, coeffs, coeffs + C, coeffs + 2 * C);
+  const long n4 = M * (C / 4);
+  hipLaunchKernelGGL(bn_bwd_apply_vec_kernel, dim3(spnet_ew_grid(n4, 256)), dim3(256), 0, st, x, dy, M, C,
+                     save_mean, save_invstd, gamma, beta, 0, coeffs, coeffs + C, coeffs + 2 * C, dx);
+  SPNET_RETURN_LAUNCH_STATUS();
+}

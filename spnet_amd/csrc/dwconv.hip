@@ -211,7 +211,8 @@ __global__ __launch_bounds__(256) void dw3x3_tile_fwd_kernel(const float* __rest
                                                              const float* __restrict__ wt,
                                                              float* __restrict__ out, int H, int W, int C,
                                                              int relu_in, int tiles_h, int tiles_w,
-                                                             int cchunks) {
+                                                             int cchunks, const float* __restrict__ in_scale,
+                                                             const float* __restrict__ in_shift) {
   constexpr int TH = RS * NS;
   constexpr int PW = TW + 2;
   static_assert(CC4 * TW * NS == 256, "thread layout");
@@ -232,6 +233,12 @@ __global__ __launch_bounds__(256) void dw3x3_tile_fwd_kernel(const float* __rest
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
     if (h >= 0 && h < H && w >= 0 && w < W && c4 < c4n) {
       v = *reinterpret_cast<const float4*>(base + ((long)h * W + w) * C + c4 * 4);
+      if (in_scale) {   // the producer's BatchNorm affine, applied on load (its output is never stored)
+        const float4 sc = *reinterpret_cast<const float4*>(in_scale + c4 * 4);
+        const float4 sh = *reinterpret_cast<const float4*>(in_shift + c4 * 4);
+        v.x = fmaf(v.x, sc.x, sh.x); v.y = fmaf(v.y, sc.y, sh.y);
+        v.z = fmaf(v.z, sc.z, sh.z); v.w = fmaf(v.w, sc.w, sh.w);
+      }
       if (relu_in) v = f4_relu(v);
     }
     tile[idx] = v;
@@ -275,7 +282,9 @@ template <int CC4, int TW, int RS, int NS>
 __global__ __launch_bounds__(256) void dw3x3_tile_bwd_kernel(
     const float* __restrict__ dz, const float* __restrict__ x, const float* __restrict__ wt,
     float* __restrict__ dx, float* __restrict__ partial, const float* __restrict__ add, int H, int W,
-    int C, int relu_in, int tiles_h, int tiles_w, int cchunks) {
+    int C, int relu_in, int tiles_h, int tiles_w, int cchunks, const float* __restrict__ in_scale,
+    const float* __restrict__ in_shift, const float* __restrict__ bn_mean,
+    const float* __restrict__ bn_invstd, float* __restrict__ bn_partial) {
   constexpr int TH = RS * NS;
   constexpr int PW = TW + 2;
   constexpr int TILE = (TH + 2) * PW * CC4;
@@ -304,10 +313,15 @@ __global__ __launch_bounds__(256) void dw3x3_tile_bwd_kernel(
       const long o = ibase + ((long)h * W + w) * C + c4 * 4;
       g = *reinterpret_cast<const float4*>(dz + o);
       v = *reinterpret_cast<const float4*>(x + o);
-      if (relu_in) v = f4_relu(v);
+      if (in_scale) {
+        const float4 sc = *reinterpret_cast<const float4*>(in_scale + c4 * 4);
+        const float4 sh = *reinterpret_cast<const float4*>(in_shift + c4 * 4);
+        v.x = fmaf(v.x, sc.x, sh.x); v.y = fmaf(v.y, sc.y, sh.y);
+        v.z = fmaf(v.z, sc.z, sh.z); v.w = fmaf(v.w, sc.w, sh.w);
+      }
     }
     tdz[idx] = g;
-    tx[idx] = v;
+    tx[idx] = v;        // the forward input BEFORE its ReLU (post-affine): sign = mask, relu() = operand
   }
   __syncthreads();
   const int l = tid % CC4, tcol = (tid / CC4) % TW, strip = tid / (CC4 * TW);
@@ -316,6 +330,7 @@ __global__ __launch_bounds__(256) void dw3x3_tile_bwd_kernel(
   float4 accw[9];
 #pragma unroll
   for (int tp = 0; tp < 9; ++tp) accw[tp] = make_float4(0.f, 0.f, 0.f, 0.f);
+  float4 bsg = make_float4(0.f, 0.f, 0.f, 0.f), bsgx = bsg;   // BatchNorm-backward sums of the producer
   if (active) {
     float4 kf[9];   // flipped taps for the data gradient
 #pragma unroll
@@ -327,7 +342,8 @@ __global__ __launch_bounds__(256) void dw3x3_tile_bwd_kernel(
     for (int rr = 0; rr < RS + 2; ++rr) {
       const int o = ((strip * RS + rr) * PW + tcol) * CC4 + l;
       const float4 g0 = tdz[o], g1 = tdz[o + CC4], g2 = tdz[o + 2 * CC4];
-      const float4 x0 = tx[o], x1 = tx[o + CC4], x2 = tx[o + 2 * CC4];
+      float4 x0 = tx[o], x1 = tx[o + CC4], x2 = tx[o + 2 * CC4];
+      if (relu_in) { x0 = f4_relu(x0); x1 = f4_relu(x1); x2 = f4_relu(x2); }
 #pragma unroll
       for (int kh = 0; kh < 3; ++kh) {
         const int r = rr - kh;               // output row of this strip fed by tile row rr through tap row kh
@@ -363,6 +379,17 @@ __global__ __launch_bounds__(256) void dw3x3_tile_bwd_kernel(
             res.x += a.x; res.y += a.y; res.z += a.z; res.w += a.w;
           }
           *reinterpret_cast<float4*>(dx + o) = res;
+          if (bn_partial) {
+            // res = dL/d(BN output of the producer); xhat = (raw - mean) * invstd from the raw pre-BN value
+            const float4 raw = *reinterpret_cast<const float4*>(x + o);
+            const float4 mu = *reinterpret_cast<const float4*>(bn_mean + c4 * 4);
+            const float4 is = *reinterpret_cast<const float4*>(bn_invstd + c4 * 4);
+            bsg.x += res.x; bsg.y += res.y; bsg.z += res.z; bsg.w += res.w;
+            bsgx.x = fmaf(res.x, (raw.x - mu.x) * is.x, bsgx.x);
+            bsgx.y = fmaf(res.y, (raw.y - mu.y) * is.y, bsgx.y);
+            bsgx.z = fmaf(res.z, (raw.z - mu.z) * is.z, bsgx.z);
+            bsgx.w = fmaf(res.w, (raw.w - mu.w) * is.w, bsgx.w);
+          }
         }
       }
     }
@@ -384,6 +411,24 @@ __global__ __launch_bounds__(256) void dw3x3_tile_bwd_kernel(
         s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
       }
       *reinterpret_cast<float4*>(partial + ((long)sp * 9 + tp) * C + c4o * 4) = s;
+    }
+  }
+  if (bn_partial) {   // second round through the same scratch: the two BatchNorm-backward sums
+    __syncthreads();
+    tile[(0 * GROUP + grp) * CC4 + l] = bsg;
+    tile[(1 * GROUP + grp) * CC4 + l] = bsgx;
+    __syncthreads();
+    if (tid < 2 * CC4) {
+      const int q = tid / CC4, ll = tid % CC4;
+      const int c4o = c40 + ll;
+      if (c4o < c4n) {
+        float4 s = tile[(q * GROUP) * CC4 + ll];
+        for (int g = 1; g < GROUP; ++g) {
+          const float4 v = tile[(q * GROUP + g) * CC4 + ll];
+          s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        }
+        *reinterpret_cast<float4*>(bn_partial + ((long)sp * 2 + q) * C + c4o * 4) = s;
+      }
     }
   }
 }
@@ -502,16 +547,24 @@ static DwGeom dw_geom(int B, int H, int W, int C) {
 }
 
 extern "C" int spnet_dwconv3x3_tiled_fwd(const float* x, const float* w, float* y, int B, int H, int W,
-                                         int C, int relu_in, void* stream) {
+                                         int C, int relu_in, const float* in_scale,
+                                         const float* in_shift, void* stream) {
   if (C & 3) return (int)hipErrorInvalidValue;
   const DwGeom g = dw_geom(B, H, W, C);
   if (g.cfg)
     hipLaunchKernelGGL((dw3x3_tile_fwd_kernel<16, 8, 3, 2>), dim3((unsigned)g.nblk), dim3(256), g.lds_fwd,
-                       (hipStream_t)stream, x, w, y, H, W, C, relu_in, g.tiles_h, g.tiles_w, g.cchunks);
+                       (hipStream_t)stream, x, w, y, H, W, C, relu_in, g.tiles_h, g.tiles_w, g.cchunks, in_scale,
+                       in_shift);
   else
     hipLaunchKernelGGL((dw3x3_tile_fwd_kernel<8, 16, 6, 2>), dim3((unsigned)g.nblk), dim3(256), g.lds_fwd,
-                       (hipStream_t)stream, x, w, y, H, W, C, relu_in, g.tiles_h, g.tiles_w, g.cchunks);
+                       (hipStream_t)stream, x, w, y, H, W, C, relu_in, g.tiles_h, g.tiles_w, g.cchunks, in_scale,
+                       in_shift);
   SPNET_RETURN_LAUNCH_STATUS();
+}
+
+extern "C" long spnet_dwconv3x3_tiled_rows(int B, int H, int W, int C) {
+  const DwGeom g = dw_geom(B, H, W, C);
+  return (long)B * g.tiles_h * g.tiles_w;   // rows of the [rows][2][C] BatchNorm partial buffer
 }
 
 // floats of workspace needed by spnet_dwconv3x3_tiled_bwd
@@ -520,20 +573,26 @@ extern "C" long spnet_dwconv3x3_tiled_bwd_ws(int B, int H, int W, int C) {
   return ((long)B * g.tiles_h * g.tiles_w + 32) * 9 * C;      // partial rows + 32 second-level slices
 }
 
-// Fused backward: dx = dw3x3(dy, flip w) * (x_fwd > 0 if relu_in) (+ add);  dw[3][3][C] = weight gradient.
+// Fused backward: dx = dw3x3(dy, flip w) * (xin > 0 if relu_in) (+ add);  dw[3][3][C] = weight gradient,
+// xin = x_fwd*in_scale + in_shift when the producer's BatchNorm affine is fused (else x_fwd).  With
+// bn_partial != NULL the kernel also emits the producer BatchNorm's backward sums (sum dx, sum dx*xhat)
+// as [rows][2][C] partials, rows = spnet_dwconv3x3_tiled_rows().
 extern "C" int spnet_dwconv3x3_tiled_bwd(const float* dy, const float* x_fwd, const float* w, float* dx,
                                          float* dw, int B, int H, int W, int C, int relu_in,
-                                         const float* add, float* workspace, void* stream) {
+                                         const float* add, float* workspace, const float* in_scale,
+                                         const float* in_shift, const float* bn_mean,
+                                         const float* bn_invstd, float* bn_partial, void* stream) {
+  if (bn_partial && (!bn_mean || !bn_invstd)) return (int)hipErrorInvalidValue;
   if (C & 3) return (int)hipErrorInvalidValue;
   const DwGeom g = dw_geom(B, H, W, C);
   if (g.cfg)
     hipLaunchKernelGGL((dw3x3_tile_bwd_kernel<16, 8, 3, 2>), dim3((unsigned)g.nblk), dim3(256), g.lds_bwd,
                        (hipStream_t)stream, dy, x_fwd, w, dx, workspace, add, H, W, C, relu_in, g.tiles_h,
-                       g.tiles_w, g.cchunks);
+                       g.tiles_w, g.cchunks, in_scale, in_shift, bn_mean, bn_invstd, bn_partial);
   else
     hipLaunchKernelGGL((dw3x3_tile_bwd_kernel<8, 16, 6, 2>), dim3((unsigned)g.nblk), dim3(256), g.lds_bwd,
                        (hipStream_t)stream, dy, x_fwd, w, dx, workspace, add, H, W, C, relu_in, g.tiles_h,
-                       g.tiles_w, g.cchunks);
+                       g.tiles_w, g.cchunks, in_scale, in_shift, bn_mean, bn_invstd, bn_partial);
   const int P = B * g.tiles_h * g.tiles_w, L = 9 * C;
   launch_reduce_rows(workspace, P, L, dw, workspace + (long)P * L, (hipStream_t)stream);
   SPNET_RETURN_LAUNCH_STATUS();

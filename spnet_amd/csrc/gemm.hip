@@ -88,7 +88,8 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
                                                        float* __restrict__ C, int ldc, int M, int N,
                                                        int K, int k_chunk, long slab_stride,
                                                        int tiles_m, int tiles_n, int nsplit,
-                                                       const float* __restrict__ bias) {
+                                                       const float* __restrict__ bias,
+                                                       float* __restrict__ colstats) {
   static_assert(WM * WN == 4, "4 waves per workgroup");
   constexpr int TM = BM / WM / 16, TN = BN / WN / 16;
   static_assert(TM >= 1 && TN >= 1 && (BM % (WM * 16)) == 0 && (BN % (WN * 16)) == 0, "wave tile");
@@ -167,6 +168,45 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
     __syncthreads();
   }
 
+  // Optional BatchNorm statistics of the output tile: per column sum and sum of squares over this
+  // workgroup's BM rows -> colstats[tm][2][N] (rows past M hold zeros and contribute nothing).
+  // Fixed reduction order: registers (i, r) -> lanes (xor 16, 32) -> waves (wm order) through LDS.
+  if (colstats) {
+    float* sred = smem;                       // [2][WM][BN], the staging buffers are idle now
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      float sv = 0.f, qv = 0.f;
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float v = acc[i][j][r];
+          sv += v;
+          qv = fmaf(v, v, qv);
+        }
+      sv += __shfl_xor(sv, 16, 64);
+      qv += __shfl_xor(qv, 16, 64);
+      sv += __shfl_xor(sv, 32, 64);
+      qv += __shfl_xor(qv, 32, 64);
+      if (lane < 16) {
+        const int cl = wn * (TN * 16) + j * 16 + lane;
+        sred[(0 * WM + wm) * BN + cl] = sv;
+        sred[(1 * WM + wm) * BN + cl] = qv;
+      }
+    }
+    __syncthreads();
+    for (int c = tid; c < 2 * BN; c += 256) {
+      const int q = c / BN, cl = c % BN;
+      const int col = n0 + cl;
+      if (col < N) {
+        float t = sred[(q * WM) * BN + cl];
+#pragma unroll
+        for (int w = 1; w < WM; ++w) t += sred[(q * WM + w) * BN + cl];
+        colstats[((long)tm * 2 + q) * N + col] = t;
+      }
+    }
+  }
+
   float* Cz = C + (long)z * slab_stride;
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
@@ -216,13 +256,13 @@ __global__ __launch_bounds__(256) void reduce_slabs_kernel(const float* __restri
 template <int BM, int BN, int WM, int WN>
 static int launch_tile(const float* A, int amaj, int lda, const float* B, int bmaj, int ldb, float* C,
                        int ldc, int M, int N, int K, int nsplit, int k_chunk, long slab_stride,
-                       const float* bias, hipStream_t st) {
+                       const float* bias, float* colstats, hipStream_t st) {
   constexpr int BK = SP_BK;
   const int tm = spnet_cdiv(M, BM), tn = spnet_cdiv(N, BN);
   dim3 grid(tm * tn * nsplit), block(256);
 #define SP_LAUNCH(AM, BMJ)                                                                          \
   hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, BK, WM, WN, AM, BMJ>), grid, block, 0, st, A, lda, B, \
-                     ldb, C, ldc, M, N, K, k_chunk, slab_stride, tm, tn, nsplit, bias)
+                     ldb, C, ldc, M, N, K, k_chunk, slab_stride, tm, tn, nsplit, bias, colstats)
   if (amaj == SP_K_MAJOR && bmaj == SP_OUT_MAJOR) SP_LAUNCH(SP_K_MAJOR, SP_OUT_MAJOR);
   else if (amaj == SP_K_MAJOR && bmaj == SP_K_MAJOR) SP_LAUNCH(SP_K_MAJOR, SP_K_MAJOR);
   else if (amaj == SP_OUT_MAJOR && bmaj == SP_OUT_MAJOR) SP_LAUNCH(SP_OUT_MAJOR, SP_OUT_MAJOR);
@@ -277,11 +317,11 @@ static int pick_tile(int M, int N, int K, int split_k, bool have_ws, long ws_flo
   return best;
 }
 
-extern "C" int spnet_gemm_f32(const float* A, int a_major, int lda, const float* B, int b_major,
-                              int ldb, float* C, int ldc, int M, int N, int K, int split_k,
-                              float* workspace, long ws_floats, const float* bias, int tile,
-                              void* stream) {
+static int gemm_impl(const float* A, int a_major, int lda, const float* B, int b_major, int ldb, float* C,
+                     int ldc, int M, int N, int K, int split_k, float* workspace, long ws_floats,
+                     const float* bias, int tile, float* colstats, int* stat_rows, void* stream) {
   hipStream_t st = (hipStream_t)stream;
+  if (colstats) split_k = 1;   // statistics are taken from complete dot products
   if (M <= 0 || N <= 0 || K <= 0) return (int)hipErrorInvalidValue;
   if ((lda & 3) || (ldb & 3) || (N & 3) || (ldc & 3)) return (int)hipErrorInvalidValue;
   if ((a_major == SP_K_MAJOR || b_major == SP_K_MAJOR) && (K & 3)) return (int)hipErrorInvalidValue;
@@ -308,13 +348,14 @@ extern "C" int spnet_gemm_f32(const float* A, int a_major, int lda, const float*
     slab = (long)M * N;
     kbias = nullptr;
   }
+  if (stat_rows) *stat_rows = spnet_cdiv(M, bm);
   int rc;
   switch (tile) {
-    case 1: rc = launch_tile<128, 128, 2, 2>(A, a_major, lda, B, b_major, ldb, out, out_ld, M, N, K, nsplit, k_chunk, slab, kbias, st); break;
-    case 2: rc = launch_tile<128, 64, 2, 2>(A, a_major, lda, B, b_major, ldb, out, out_ld, M, N, K, nsplit, k_chunk, slab, kbias, st); break;
-    case 3: rc = launch_tile<64, 64, 2, 2>(A, a_major, lda, B, b_major, ldb, out, out_ld, M, N, K, nsplit, k_chunk, slab, kbias, st); break;
-    case 5: rc = launch_tile<96, 96, 2, 2>(A, a_major, lda, B, b_major, ldb, out, out_ld, M, N, K, nsplit, k_chunk, slab, kbias, st); break;
-    default: rc = launch_tile<32, 128, 1, 4>(A, a_major, lda, B, b_major, ldb, out, out_ld, M, N, K, nsplit, k_chunk, slab, kbias, st); break;
+    case 1: rc = launch_tile<128, 128, 2, 2>(A, a_major, lda, B, b_major, ldb, out, out_ld, M, N, K, nsplit, k_chunk, slab, kbias, colstats, st); break;
+    case 2: rc = launch_tile<128, 64, 2, 2>(A, a_major, lda, B, b_major, ldb, out, out_ld, M, N, K, nsplit, k_chunk, slab, kbias, colstats, st); break;
+    case 3: rc = launch_tile<64, 64, 2, 2>(A, a_major, lda, B, b_major, ldb, out, out_ld, M, N, K, nsplit, k_chunk, slab, kbias, colstats, st); break;
+    case 5: rc = launch_tile<96, 96, 2, 2>(A, a_major, lda, B, b_major, ldb, out, out_ld, M, N, K, nsplit, k_chunk, slab, kbias, colstats, st); break;
+    default: rc = launch_tile<32, 128, 1, 4>(A, a_major, lda, B, b_major, ldb, out, out_ld, M, N, K, nsplit, k_chunk, slab, kbias, colstats, st); break;
   }
   if (rc) return rc;
   if (nsplit > 1) {
@@ -323,6 +364,25 @@ extern "C" int spnet_gemm_f32(const float* A, int a_major, int lda, const float*
                        workspace, nsplit, M, N, C, ldc, bias);
   }
   SPNET_RETURN_LAUNCH_STATUS();
+}
+
+extern "C" int spnet_gemm_f32(const float* A, int a_major, int lda, const float* B, int b_major,
+                              int ldb, float* C, int ldc, int M, int N, int K, int split_k,
+                              float* workspace, long ws_floats, const float* bias, int tile,
+                              void* stream) {
+  return gemm_impl(A, a_major, lda, B, b_major, ldb, C, ldc, M, N, K, split_k, workspace, ws_floats, bias,
+                   tile, nullptr, nullptr, stream);
+}
+
+// Forward-form GEMM that also emits BatchNorm column statistics of C: colstats[rows][2][N] holds per
+// row-tile partial (sum, sum of squares); *stat_rows (host) receives `rows`.  colstats must hold
+// ceil(M/32)*2*N floats (an upper bound for every tile shape).
+extern "C" int spnet_gemm_f32_colstats(const float* A, int a_major, int lda, const float* B, int b_major,
+                                       int ldb, float* C, int ldc, int M, int N, int K, int tile,
+                                       float* colstats, int* stat_rows, void* stream) {
+  if (!colstats || !stat_rows) return (int)hipErrorInvalidValue;
+  return gemm_impl(A, a_major, lda, B, b_major, ldb, C, ldc, M, N, K, 1, nullptr, 0, nullptr, tile, colstats,
+                   stat_rows, stream);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -12,7 +12,9 @@ __global__ __launch_bounds__(256) void maxpool_add_fwd_kernel(const float* __res
                                                               float* __restrict__ y,
                                                               uint32_t* __restrict__ idx4, int Bn,
                                                               int H, int W, int C, int OH, int OW,
-                                                              int pt, int pl) {
+                                                              int pt, int pl,
+                                                              const float* __restrict__ x_ss,
+                                                              const float* __restrict__ r_ss) {
   const int c4n = C >> 2;
   const long total = (long)Bn * OH * OW * c4n;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
@@ -24,6 +26,11 @@ __global__ __launch_bounds__(256) void maxpool_add_fwd_kernel(const float* __res
     const int oh = (int)(t % OH);
     const int b = (int)(t / OH);
     const float ninf = -__builtin_huge_valf();
+    float4 xs = make_float4(1.f, 1.f, 1.f, 1.f), xh = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (x_ss) {   // BatchNorm affine of the pooled branch applied on load: [scale[C] | shift[C]]
+      xs = *reinterpret_cast<const float4*>(x_ss + c4 * 4);
+      xh = *reinterpret_cast<const float4*>(x_ss + C + c4 * 4);
+    }
     float4 m = make_float4(ninf, ninf, ninf, ninf);
     uint32_t ix = 0, iy = 0, iz = 0, iw = 0;
 #pragma unroll
@@ -34,7 +41,9 @@ __global__ __launch_bounds__(256) void maxpool_add_fwd_kernel(const float* __res
       for (int kw = 0; kw < 3; ++kw) {
         const int w = ow * 2 - pl + kw;
         if (w < 0 || w >= W) continue;
-        const float4 v = *reinterpret_cast<const float4*>(x + (((long)b * H + h) * W + w) * C + c4 * 4);
+        float4 v = *reinterpret_cast<const float4*>(x + (((long)b * H + h) * W + w) * C + c4 * 4);
+        v.x = fmaf(v.x, xs.x, xh.x); v.y = fmaf(v.y, xs.y, xh.y);
+        v.z = fmaf(v.z, xs.z, xh.z); v.w = fmaf(v.w, xs.w, xh.w);
         const uint32_t tap = kh * 3 + kw;
         if (v.x > m.x) { m.x = v.x; ix = tap; }
         if (v.y > m.y) { m.y = v.y; iy = tap; }
@@ -43,7 +52,13 @@ __global__ __launch_bounds__(256) void maxpool_add_fwd_kernel(const float* __res
       }
     }
     if (residual) {
-      const float4 r = *reinterpret_cast<const float4*>(residual + i * 4);
+      float4 r = *reinterpret_cast<const float4*>(residual + i * 4);
+      if (r_ss) {   // BatchNorm affine of the residual branch
+        const float4 rs = *reinterpret_cast<const float4*>(r_ss + c4 * 4);
+        const float4 rh = *reinterpret_cast<const float4*>(r_ss + C + c4 * 4);
+        r.x = fmaf(r.x, rs.x, rh.x); r.y = fmaf(r.y, rs.y, rh.y);
+        r.z = fmaf(r.z, rs.z, rh.z); r.w = fmaf(r.w, rs.w, rh.w);
+      }
       m.x += r.x; m.y += r.y; m.z += r.z; m.w += r.w;
     }
     *reinterpret_cast<float4*>(y + i * 4) = m;
@@ -128,15 +143,18 @@ static void same_pool_geom(int in, int* out, int* pad_before) {
   *pad_before = total / 2;
 }
 
+// x_ss / r_ss (or NULL): [scale[C] | shift[C]] of the BatchNorm that produced x / residual, applied on
+// load so that neither normalised tensor is ever written to HBM.
 extern "C" int spnet_maxpool3x3s2_add_fwd(const float* x, const float* residual, float* y,
-                                          uint32_t* idx4, int B, int H, int W, int C, void* stream) {
+                                          uint32_t* idx4, int B, int H, int W, int C, const float* x_ss,
+                                          const float* r_ss, void* stream) {
   if (C & 3) return (int)hipErrorInvalidValue;
   int OH, OW, pt, pl;
   same_pool_geom(H, &OH, &pt);
   same_pool_geom(W, &OW, &pl);
   const long total = (long)B * OH * OW * (C / 4);
   hipLaunchKernelGGL(maxpool_add_fwd_kernel, dim3(spnet_ew_grid(total, 256)), dim3(256), 0,
-                     (hipStream_t)stream, x, residual, y, idx4, B, H, W, C, OH, OW, pt, pl);
+                     (hipStream_t)stream, x, residual, y, idx4, B, H, W, C, OH, OW, pt, pl, x_ss, r_ss);
   SPNET_RETURN_LAUNCH_STATUS();
 }
 

@@ -28,7 +28,11 @@ BN_MOMENTUM = 0.99
 L2_COEF = 1e-4
 ACT_NONE, ACT_RELU, ACT_LRELU = 0, 1, 2
 K_MAJOR, OUT_MAJOR = 0, 1
-WS_FLOATS = 48 * 1024 * 1024       # shared split-K / partial-sum workspace (192 MiB)
+WS_FLOATS = 48 * 1024 * 1024       # shared scratch (192 MiB), carved into regions (float offsets):
+WS_GEMM = (0, 16 * 1024 * 1024)                       # split-K slabs
+WS_DW = (16 * 1024 * 1024, 16 * 1024 * 1024)          # depthwise weight-gradient partials
+WS_BNP = (32 * 1024 * 1024, 8 * 1024 * 1024)          # BatchNorm partial sums from GEMM / depthwise epilogues
+WS_MISC = (40 * 1024 * 1024, 8 * 1024 * 1024)         # stand-alone BN reductions, small-conv partials
 ALIGN = 64
 
 
@@ -259,6 +263,9 @@ class Engine:
     def new(self, *shape):
         return torch.empty(shape, device=self.dev, dtype=torch.float32)
 
+    def ws_ptr(self, region):
+        return self.ws.data_ptr() + 4 * region[0]
+
     def _build_graph(self):
         B, H, W = self.B, self.H, self.W
         tr = self.train_capable
@@ -383,9 +390,27 @@ def _gemm(A, a_major, lda, Bm, b_major, ldb, C, ldc, M, N, K, eng, bias=None, sp
     if prof is not None:
         t0 = prof.start()
     L.spnet_gemm_f32(L.ptr(A), a_major, lda, L.ptr(Bm), b_major, ldb, L.ptr(C), ldc, M, N, K, split_k,
-                     L.ptr(eng.ws), WS_FLOATS, L.ptr(bias), tile, _stream())
+                     eng.ws_ptr(WS_GEMM), WS_GEMM[1], L.ptr(bias), tile, _stream())
     if prof is not None:
         prof.stop("gemm", t0, 2.0 * M * N * K)
+
+
+_stat_rows = __import__("ctypes").c_int(0)
+
+
+def _gemm_colstats(A, lda, Bm, ldb, C, ldc, M, N, K, eng):
+    """Forward-form GEMM whose epilogue also leaves the BatchNorm column sums of C in the WS_BNP region;
+    returns the number of partial rows."""
+    if (M + 31) // 32 * 2 * N > WS_BNP[1]:
+        raise RuntimeError("BatchNorm partial region too small for M=%d N=%d" % (M, N))
+    prof = eng.prof
+    if prof is not None:
+        t0 = prof.start()
+    L.spnet_gemm_f32_colstats(L.ptr(A), K_MAJOR, lda, L.ptr(Bm), OUT_MAJOR, ldb, L.ptr(C), ldc, M, N, K, 0,
+                              eng.ws_ptr(WS_BNP), __import__("ctypes").addressof(_stat_rows), _stream())
+    if prof is not None:
+        prof.stop("gemm", t0, 2.0 * M * N * K)
+    return _stat_rows.value
 
 
 class SmallConv(Node):
@@ -407,7 +432,7 @@ class SmallConv(Node):
     def _call(self, op, a, b, out):
         e = self.e
         L.spnet_conv3x3_small(op, self.cin, self.cout, self.stride, self.same, L.ptr(a), L.ptr(b), L.ptr(out),
-                              e.B, self.Hin, self.Win, L.ptr(e.ws), WS_FLOATS, _stream())
+                              e.B, self.Hin, self.Win, e.ws_ptr(WS_MISC), WS_MISC[1], _stream())
 
     def fwd(self, training):
         self._call(0, self.x, self.w, self.y)
@@ -461,7 +486,7 @@ class BatchNorm(Node):
             L.spnet_bn_fwd_train(L.ptr(self.x), self.M, C, L.ptr(self.gamma), L.ptr(self.beta), L.ptr(self.mm),
                                  L.ptr(self.mv), L.ptr(self.save), self.save[C:].data_ptr(), L.ptr(ss), self.act,
                                  L.ptr(self.residual), int(self.res_bcast), L.ptr(self.y), BN_EPS, BN_MOMENTUM,
-                                 L.ptr(e.ws), _stream())
+                                 e.ws_ptr(WS_MISC), _stream())
         else:
             L.spnet_bn_fwd_infer(L.ptr(self.x), self.M, C, L.ptr(self.gamma), L.ptr(self.beta), L.ptr(self.mm),
                                  L.ptr(self.mv), L.ptr(ss), self.act, L.ptr(self.residual), int(self.res_bcast),
@@ -473,7 +498,7 @@ class BatchNorm(Node):
         out = g if self.dx is None else self.dx
         L.spnet_bn_bwd(L.ptr(self.x), L.ptr(g), self.M, C, L.ptr(self.gamma), L.ptr(self.beta), L.ptr(self.save),
                        self.save[C:].data_ptr(), self.act, L.ptr(out), L.ptr(self.ggamma), L.ptr(self.gbeta),
-                       L.ptr(co), L.ptr(e.ws), _stream())
+                       L.ptr(co), e.ws_ptr(WS_MISC), _stream())
         return out
 
 
@@ -505,6 +530,10 @@ class Pointwise:
 
     def fwd(self, x, y):
         _gemm(x, K_MAJOR, self.cin, self.w, OUT_MAJOR, self.cout, y, self.cout, self.M, self.cout, self.cin, self.e)
+
+    def fwd_colstats(self, x, y):
+        """Forward + BatchNorm column sums of y left in WS_BNP; returns the partial row count."""
+        return _gemm_colstats(x, self.cin, self.w, self.cout, y, self.cout, self.M, self.cout, self.cin, self.e)
 
     def bwd(self, x, dy, dx):
         # dW[cin,cout] = x^T dy ; dx[M,cin] = dy W^T
@@ -539,63 +568,169 @@ class Conv3x3Gemm(Node):
         return self.dx
 
 
-class SepConvBN:
-    """relu? -> depthwise 3x3 -> pointwise -> BN(act) (+residual): one Xception 'sepconv' unit."""
+class BN:
+    """Parameters, statistics and per-layer affine (scale|shift) of one BatchNormalization layer whose
+    reductions run inside OTHER kernels' epilogues and whose affine is applied by its consumers on load
+    (the normalised tensor itself is only written when `apply()` is called)."""
 
-    def __init__(self, eng, x, cin, cout, name, relu_in, act=ACT_NONE, residual=None, bwd_inplace=True):
-        self.e, self.x, self.cin, self.cout, self.relu_in = eng, x, cin, cout, int(relu_in)
-        B, H, W, _ = x.shape
+    def __init__(self, eng, C, M, name):
+        self.e, self.C, self.M = eng, C, M
+        self.gamma, self.beta = eng.P(name + "/gamma"), eng.P(name + "/beta")
+        self.mm, self.mv = eng.S(name + "/moving_mean"), eng.S(name + "/moving_variance")
+        self.ss = eng.new(2 * C)                 # [scale | shift], valid after finalize()/infer()
+        if eng.train_capable:
+            self.ggamma, self.gbeta = eng.G(name + "/gamma"), eng.G(name + "/beta")
+            self.save = eng.new(2 * C)           # [batch mean | invstd]
+
+    @property
+    def scale_ptr(self):
+        return self.ss.data_ptr()
+
+    @property
+    def shift_ptr(self):
+        return self.ss.data_ptr() + 4 * self.C
+
+    @property
+    def mean_ptr(self):
+        return self.save.data_ptr()
+
+    @property
+    def invstd_ptr(self):
+        return self.save.data_ptr() + 4 * self.C
+
+    def finalize(self, rows):
+        """Batch statistics from the `rows` partial rows waiting in WS_BNP -> scale/shift, moving stats."""
+        e = self.e
+        L.spnet_bn_finalize_fwd(e.ws_ptr(WS_BNP), rows, self.M, self.C, L.ptr(self.gamma), L.ptr(self.beta),
+                                L.ptr(self.mm), L.ptr(self.mv), self.mean_ptr, self.invstd_ptr, L.ptr(self.ss),
+                                BN_EPS, BN_MOMENTUM, _stream())
+
+    def infer(self):
+        L.spnet_bn_infer_coeffs(self.C, L.ptr(self.gamma), L.ptr(self.beta), L.ptr(self.mm), L.ptr(self.mv),
+                                L.ptr(self.ss), BN_EPS, _stream())
+
+    def apply(self, x, y, act, residual=None):
+        L.spnet_bn_apply(L.ptr(x), self.M, self.C, L.ptr(self.ss), act, L.ptr(residual), 0, L.ptr(y), _stream())
+
+    def bwd_full(self, x, g, out, act):
+        """Stand-alone backward (own reduction pass) of y = act(BN(x)); `out` may alias g."""
+        e, C = self.e, self.C
+        L.spnet_bn_bwd(L.ptr(x), L.ptr(g), self.M, C, L.ptr(self.gamma), L.ptr(self.beta), self.mean_ptr,
+                       self.invstd_ptr, act, L.ptr(out), L.ptr(self.ggamma), L.ptr(self.gbeta), L.ptr(e.small[:3 * C]),
+                       e.ws_ptr(WS_MISC), _stream())
+        return out
+
+    def bwd_from_partials(self, x, g, out, rows):
+        """Backward when the consumer's depthwise-backward epilogue already left (sum g, sum g*xhat)
+        as `rows` partial rows in WS_BNP."""
+        e, C = self.e, self.C
+        L.spnet_bn_bwd_from_partials(L.ptr(x), L.ptr(g), self.M, C, L.ptr(self.gamma), L.ptr(self.beta),
+                                     self.mean_ptr, self.invstd_ptr, rows, e.ws_ptr(WS_BNP), L.ptr(out),
+                                     L.ptr(self.ggamma), L.ptr(self.gbeta), L.ptr(e.small[:3 * C]), _stream())
+        return out
+
+
+class Ref:
+    """A tensor as consumers see it: `t` in HBM, plus (optionally) the BatchNorm whose affine still has to
+    be applied on load because the normalised tensor was never materialised."""
+
+    def __init__(self, t, bn=None):
+        self.t, self.bn = t, bn
+
+
+class SepConvBN:
+    """[affine on load] -> relu? -> depthwise 3x3 -> pointwise (+BN sums in the GEMM epilogue) -> BN.
+
+    mode 'lazy'   the BN output is never written; the consumer applies scale/shift (+relu) on load and its
+                  fused depthwise backward also produces this BN's backward sums
+    mode 'pool'   like lazy for the forward (a max-pool consumes it), stand-alone BN backward
+    mode 'apply'  y = act(BN(.)) (+residual) is materialised; stand-alone BN backward
+    """
+
+    def __init__(self, eng, src, cin, cout, name, relu_in, mode="lazy", act=ACT_NONE, residual=None,
+                 bwd_inplace=True):
+        self.e, self.src, self.cin, self.cout, self.relu_in = eng, src, cin, cout, int(relu_in)
+        self.mode, self.act, self.residual, self.bwd_inplace = mode, act, residual, bwd_inplace
+        B, H, W, _ = src.t.shape
         self.H, self.W = H, W
         self.M = B * H * W
         self.wd = eng.P(name + "/depthwise_kernel")
         self.z = eng.new(B, H, W, cin)
         self.yp = eng.new(B, H, W, cout)
         self.pw = Pointwise(eng, self.M, cin, cout, name + "/pointwise_kernel")
-        self.bn = BatchNorm(eng, self.yp, cout, name + "_bn", act, residual=residual, bwd_inplace=bwd_inplace)
-        self.y = self.bn.y
+        self.bn = BN(eng, cout, self.M, name + "_bn")
+        self.y = eng.new(B, H, W, cout) if mode == "apply" else None
+        self.rows_src = L.spnet_dwconv3x3_tiled_rows(B, H, W, cin)   # partial rows this unit emits for src.bn
+        if L.spnet_dwconv3x3_tiled_bwd_ws(B, H, W, cin) > WS_DW[1] or self.rows_src * 2 * cin > WS_BNP[1]:
+            raise RuntimeError("workspace regions too small for %s" % name)
+        self.consumer_rows = 0              # set by the consumer (lazy mode)
         if eng.train_capable:
             self.gwd = eng.G(name + "/depthwise_kernel")
             self.dz = eng.new(B, H, W, cin)
             self.dx = eng.new(B, H, W, cin)
+            self.dbn = None if bwd_inplace else eng.new(B, H, W, cout)
+        if src.bn is not None and hasattr(src, "owner"):
+            src.owner.consumer_rows = self.rows_src
+
+    def ref(self):
+        if self.mode == "apply":
+            return Ref(self.y)
+        r = Ref(self.yp, self.bn)
+        r.owner = self
+        return r
 
     def fwd(self, training):
-        e = self.e
+        e, sb = self.e, self.src.bn
         prof = e.prof
         if prof is not None:
             t0 = prof.start()
-        L.spnet_dwconv3x3_tiled_fwd(L.ptr(self.x), L.ptr(self.wd), L.ptr(self.z), e.B, self.H, self.W, self.cin,
-                                    self.relu_in, _stream())
+        L.spnet_dwconv3x3_tiled_fwd(L.ptr(self.src.t), L.ptr(self.wd), L.ptr(self.z), e.B, self.H, self.W, self.cin,
+                                    self.relu_in, sb.scale_ptr if sb else None, sb.shift_ptr if sb else None, _stream())
         if prof is not None:
             prof.stop("dw", t0, 2.0 * 4 * self.M * self.cin)        # read x + write z
-        self.pw.fwd(self.z, self.yp)
-        self.bn.fwd(training)
+        if training:
+            rows = self.pw.fwd_colstats(self.z, self.yp)
+            self.bn.finalize(rows)
+        else:
+            self.pw.fwd(self.z, self.yp)
+            self.bn.infer()
+        if self.mode == "apply":
+            self.bn.apply(self.yp, self.y, self.act, self.residual)
 
     def bwd(self, g, add=None):
-        """g: gradient wrt this unit's output (overwritten).  Returns gradient wrt the unit's input
-        (pre-ReLU), plus `add` if given."""
-        e = self.e
-        g = self.bn.bwd(g)
-        self.pw.bwd(self.z, g, self.dz)
+        """g: gradient wrt this unit's BN output (after `act` for mode 'apply').  Returns the gradient wrt
+        the source as its consumers see it (wrt src's BN output when src is lazy), plus `add`."""
+        e, sb = self.e, self.src.bn
+        out = g if self.bwd_inplace else self.dbn
+        if self.mode == "lazy":
+            dy = self.bn.bwd_from_partials(self.yp, g, out, self.consumer_rows)
+        else:
+            dy = self.bn.bwd_full(self.yp, g, out, self.act if self.mode == "apply" else ACT_NONE)
+        self.pw.bwd(self.z, dy, self.dz)
         prof = e.prof
         if prof is not None:
             t0 = prof.start()
-        L.spnet_dwconv3x3_tiled_bwd(L.ptr(self.dz), L.ptr(self.x), L.ptr(self.wd), L.ptr(self.dx), L.ptr(self.gwd),
-                                    e.B, self.H, self.W, self.cin, self.relu_in, L.ptr(add), L.ptr(e.ws), _stream())
+        L.spnet_dwconv3x3_tiled_bwd(L.ptr(self.dz), L.ptr(self.src.t), L.ptr(self.wd), L.ptr(self.dx), L.ptr(self.gwd),
+                                    e.B, self.H, self.W, self.cin, self.relu_in, L.ptr(add), e.ws_ptr(WS_DW),
+                                    sb.scale_ptr if sb else None, sb.shift_ptr if sb else None,
+                                    sb.mean_ptr if sb else None, sb.invstd_ptr if sb else None,
+                                    e.ws_ptr(WS_BNP) if sb else None, _stream())
         if prof is not None:
             prof.stop("dw", t0, 3.0 * 4 * self.M * self.cin)        # read dz, read x, write dx
         return self.dx
 
 
 class MiddleBlock(Node):
-    """Xception blocks 5-12: x + [relu, sepconv, BN] x 3."""
+    """Xception blocks 5-12: x + [relu, sepconv, BN] x 3.  Only the block output is materialised."""
 
     def __init__(self, eng, x, b, C):
         self.x = x
-        self.u1 = SepConvBN(eng, x, C, C, "block%d_sepconv1" % b, True)
-        self.u2 = SepConvBN(eng, self.u1.y, C, C, "block%d_sepconv2" % b, True)
-        # u3's BN backward writes to its own buffer: the incoming gradient is also the identity
-        # branch's gradient and is added back in u1's depthwise backward.
-        self.u3 = SepConvBN(eng, self.u2.y, C, C, "block%d_sepconv3" % b, True, residual=x, bwd_inplace=False)
+        self.u1 = SepConvBN(eng, Ref(x), C, C, "block%d_sepconv1" % b, True, mode="lazy")
+        self.u2 = SepConvBN(eng, self.u1.ref(), C, C, "block%d_sepconv2" % b, True, mode="lazy")
+        # u3's BN backward writes to its own buffer: the incoming gradient is also the identity branch's
+        # gradient and is added back in u1's depthwise backward.
+        self.u3 = SepConvBN(eng, self.u2.ref(), C, C, "block%d_sepconv3" % b, True, mode="apply", residual=x,
+                            bwd_inplace=False)
         self.y = self.u3.y
 
     def fwd(self, training):
@@ -610,7 +745,8 @@ class MiddleBlock(Node):
 
 
 class StridedBlock(Node):
-    """Xception blocks 2,3,4,13: maxpool(sepconv x2) + BN(conv1x1/s2)."""
+    """Xception blocks 2,3,4,13: maxpool(BN(sepconv x2)) + BN(conv1x1/s2); both BN affines are applied
+    inside the pooling kernel."""
 
     def __init__(self, eng, x, b, cin, c1, c2, first_relu, conv_name, bn_name):
         self.e, self.x, self.cin, self.c2 = eng, x, cin, c2
@@ -622,9 +758,9 @@ class StridedBlock(Node):
         self.xs = eng.new(B, OH, OW, cin)
         self.yr = eng.new(B, OH, OW, c2)
         self.pwr = Pointwise(eng, self.Ms, cin, c2, conv_name + "/kernel")
-        self.bnr = BatchNorm(eng, self.yr, c2, bn_name, ACT_NONE)
-        self.u1 = SepConvBN(eng, x, cin, c1, "block%d_sepconv1" % b, first_relu)
-        self.u2 = SepConvBN(eng, self.u1.y, c1, c2, "block%d_sepconv2" % b, True)
+        self.bnr = BN(eng, c2, self.Ms, bn_name)
+        self.u1 = SepConvBN(eng, Ref(x), cin, c1, "block%d_sepconv1" % b, first_relu, mode="lazy")
+        self.u2 = SepConvBN(eng, self.u1.ref(), c1, c2, "block%d_sepconv2" % b, True, mode="pool")
         self.y = eng.new(B, OH, OW, c2)
         if eng.train_capable:
             self.idx = torch.empty(B * OH * OW * (c2 // 4), device=eng.dev, dtype=torch.int32)
@@ -636,17 +772,21 @@ class StridedBlock(Node):
     def fwd(self, training):
         e = self.e
         L.spnet_gather_s2(L.ptr(self.x), L.ptr(self.xs), e.B, self.H, self.W, self.cin, _stream())
-        self.pwr.fwd(self.xs, self.yr)
-        self.bnr.fwd(training)
+        if training:
+            self.bnr.finalize(self.pwr.fwd_colstats(self.xs, self.yr))
+        else:
+            self.pwr.fwd(self.xs, self.yr)
+            self.bnr.infer()
         self.u1.fwd(training)
         self.u2.fwd(training)
-        L.spnet_maxpool3x3s2_add_fwd(L.ptr(self.u2.y), L.ptr(self.bnr.y), L.ptr(self.y),
-                                     L.ptr(self.idx) if training else None, e.B, self.H, self.W, self.c2, _stream())
+        L.spnet_maxpool3x3s2_add_fwd(L.ptr(self.u2.yp), L.ptr(self.yr), L.ptr(self.y),
+                                     L.ptr(self.idx) if training else None, e.B, self.H, self.W, self.c2,
+                                     L.ptr(self.u2.bn.ss), L.ptr(self.bnr.ss), _stream())
 
     def bwd(self, g):
         e = self.e
         L.spnet_maxpool3x3s2_bwd(L.ptr(g), L.ptr(self.idx), L.ptr(self.dpool), e.B, self.H, self.W, self.c2, _stream())
-        gr = self.bnr.bwd(g)                # in place: g is dead after the pool backward above
+        gr = self.bnr.bwd_full(self.yr, g, g, ACT_NONE)       # in place: g is dead after the pool backward
         self.pwr.bwd(self.xs, gr, self.dxs)
         d = self.u2.bwd(self.dpool)
         dx = self.u1.bwd(d)
@@ -655,11 +795,12 @@ class StridedBlock(Node):
 
 
 class ExitBlock(Node):
-    """Xception block 14: sepconv-BN-relu x 2 (no pre-activation)."""
+    """Xception block 14: sepconv-BN-relu x 2 (no pre-activation); the first ReLU is applied by the second
+    depthwise on load, the last one when the block output is materialised for the Dense head."""
 
     def __init__(self, eng, x, cin, c1, c2):
-        self.u1 = SepConvBN(eng, x, cin, c1, "block14_sepconv1", False, act=ACT_RELU)
-        self.u2 = SepConvBN(eng, self.u1.y, c1, c2, "block14_sepconv2", False, act=ACT_RELU)
+        self.u1 = SepConvBN(eng, Ref(x), cin, c1, "block14_sepconv1", False, mode="lazy")
+        self.u2 = SepConvBN(eng, self.u1.ref(), c1, c2, "block14_sepconv2", True, mode="apply", act=ACT_RELU)
         self.y = self.u2.y
 
     def fwd(self, training):

@@ -127,26 +127,91 @@ def test_dwconv(L, B, H, W, C, relu_in):
 @pytest.mark.parametrize("B,H,W,C", [(2, 12, 16, 728), (3, 7, 5, 64), (1, 93, 125, 128), (2, 6, 8, 1536), (1, 1, 1, 8),
                                      (2, 24, 32, 256), (1, 47, 63, 128), (2, 13, 17, 40)])
 @pytest.mark.parametrize("relu_in", [0, 1])
-def test_dwconv_tiled(L, B, H, W, C, relu_in):
-    """LDS-tiled forward and FUSED backward (data + weight gradient) -- the forms the engine uses."""
+@pytest.mark.parametrize("fused_bn", [0, 1])
+def test_dwconv_tiled(L, B, H, W, C, relu_in, fused_bn):
+    """LDS-tiled forward and FUSED backward (data + weight gradient) -- the forms the engine uses.
+    fused_bn=1: the input is a PRE-BatchNorm tensor whose affine is applied on load, and the backward
+    also emits that BatchNorm's two backward sums."""
     rs = np.random.RandomState(C + H + 1)
     x = torch.tensor(rs.randn(B, H, W, C), dtype=torch.float32, requires_grad=True)
     w = torch.tensor(rs.randn(3, 3, C) * 0.3, dtype=torch.float32, requires_grad=True)
     add = torch.tensor(rs.randn(B, H, W, C), dtype=torch.float32)
-    y = T.dwconv3x3(torch.relu(x) if relu_in else x, w)
+    gamma = torch.tensor(rs.rand(C) + 0.5, dtype=torch.float32)
+    beta = torch.tensor(rs.randn(C) * 0.3, dtype=torch.float32)
+    if fused_bn:
+        flat = x.reshape(-1, C)
+        mu, var = flat.mean(0), flat.var(0, unbiased=False)
+        invstd = torch.rsqrt(var + 1e-3)
+        xhat = (x - mu) * invstd
+        a = xhat * gamma + beta
+        a.retain_grad()
+        sc = (gamma * invstd).detach()
+        sh = (beta - mu * gamma * invstd).detach()
+    else:
+        a = x
+    y = T.dwconv3x3(torch.relu(a) if relu_in else a, w)
     dy = torch.tensor(rs.randn(B, H, W, C), dtype=torch.float32)
-    y.backward(dy)
+    (y * dy).sum().backward() if not fused_bn else ((y * dy).sum() + (a * add).sum()).backward()
     xd, wd, dyd, addd = x.detach().cuda(), w.detach().cuda(), dy.cuda(), add.cuda()
+    scd = shd = mud = isd = None
+    if fused_bn:
+        scd, shd, mud, isd = sc.cuda(), sh.cuda(), mu.detach().cuda(), invstd.detach().cuda()
+    P = lambda t: None if t is None else t.data_ptr()
     yd = torch.full_like(xd, float("nan"))
-    L.spnet_dwconv3x3_tiled_fwd(xd.data_ptr(), wd.data_ptr(), yd.data_ptr(), B, H, W, C, relu_in, st())
-    close(yd, y.detach(), rtol=1e-5, atol=1e-5)
+    L.spnet_dwconv3x3_tiled_fwd(xd.data_ptr(), wd.data_ptr(), yd.data_ptr(), B, H, W, C, relu_in, P(scd), P(shd), st())
+    close(yd, y.detach(), rtol=1e-5, atol=2e-5)
     ws = torch.empty(L.spnet_dwconv3x3_tiled_bwd_ws(B, H, W, C), device="cuda")
+    rows = L.spnet_dwconv3x3_tiled_rows(B, H, W, C)
+    bnp = torch.full((rows, 2, C), float("nan"), device="cuda") if fused_bn else None
     dxd, dwd = torch.full_like(xd, float("nan")), torch.full((3, 3, C), float("nan"), device="cuda")
-    for use_add in (True, False):
-        L.spnet_dwconv3x3_tiled_bwd(dyd.data_ptr(), xd.data_ptr(), wd.data_ptr(), dxd.data_ptr(), dwd.data_ptr(), B, H, W, C,
-                                    relu_in, addd.data_ptr() if use_add else None, ws.data_ptr(), st())
-        close(dxd, x.grad + add if use_add else x.grad, rtol=1e-5, atol=1e-5)
-        close(dwd, w.grad, rtol=1e-4, atol=1e-4 * np.sqrt(B * H * W))
+    L.spnet_dwconv3x3_tiled_bwd(dyd.data_ptr(), xd.data_ptr(), wd.data_ptr(), dxd.data_ptr(), dwd.data_ptr(), B, H, W, C,
+                                relu_in, addd.data_ptr(), ws.data_ptr(), P(scd), P(shd), P(mud), P(isd), P(bnp), st())
+    if fused_bn:
+        # dx is the gradient wrt the BatchNorm OUTPUT a (incl. the added branch); the two sums are dbeta / dgamma/gamma-free
+        close(dxd, a.grad, rtol=1e-5, atol=2e-5)
+        sums = bnp.sum(0).cpu()
+        close(sums[0], a.grad.reshape(-1, C).sum(0), rtol=1e-4, atol=1e-4 * np.sqrt(B * H * W))
+        close(sums[1], (a.grad * xhat.detach()).reshape(-1, C).sum(0), rtol=1e-4, atol=2e-4 * np.sqrt(B * H * W))
+    else:
+        close(dxd, x.grad + add, rtol=1e-5, atol=1e-5)
+        L.spnet_dwconv3x3_tiled_bwd(dyd.data_ptr(), xd.data_ptr(), wd.data_ptr(), dxd.data_ptr(), dwd.data_ptr(), B, H, W,
+                                    C, relu_in, None, ws.data_ptr(), None, None, None, None, None, st())
+        close(dxd, x.grad, rtol=1e-5, atol=1e-5)
+    close(dwd, w.grad, rtol=1e-4, atol=1e-4 * np.sqrt(B * H * W))
+
+
+@pytest.mark.parametrize("M,N,K", [(6144, 728, 728), (372, 128, 64), (1536, 2048, 1536), (100, 64, 288), (33, 72, 40)])
+@pytest.mark.parametrize("tile", [0, 1, 2, 3, 5])
+def test_gemm_colstats_and_bn_finalize(L, M, N, K, tile):
+    import ctypes
+    rs = np.random.RandomState(M + N)
+    A, Bm = rs.randn(M, K).astype(np.float32), (rs.randn(K, N) * 0.1).astype(np.float32)
+    a, b = dev(A), dev(Bm)
+    c = torch.empty(M, N, device="cuda")
+    part = torch.full(((M + 31) // 32 * 2 * N,), float("nan"), device="cuda")
+    rows = ctypes.c_int(0)
+    L.spnet_gemm_f32_colstats(a.data_ptr(), 0, K, b.data_ptr(), 1, N, c.data_ptr(), N, M, N, K, tile, part.data_ptr(),
+                              ctypes.addressof(rows), st())
+    Cref = A.astype(np.float64) @ Bm.astype(np.float64)
+    close(c, Cref, rtol=2e-5, atol=2e-5 * np.sqrt(K))
+    p = part[:rows.value * 2 * N].reshape(rows.value, 2, N).sum(0).cpu()
+    close(p[0], Cref.sum(0), rtol=1e-4, atol=1e-3 * np.sqrt(M))
+    close(p[1], (Cref ** 2).sum(0), rtol=1e-4, atol=1e-3)
+    # finalize from those partials == oracle batch statistics
+    gamma, beta = dev(rs.rand(N) + 0.5), dev(rs.randn(N))
+    mm, mv = dev(np.zeros(N)), dev(np.ones(N))
+    save, ss = torch.empty(2 * N, device="cuda"), torch.empty(2 * N, device="cuda")
+    L.spnet_bn_finalize_fwd(part.data_ptr(), rows.value, M, N, gamma.data_ptr(), beta.data_ptr(), mm.data_ptr(), mv.data_ptr(),
+                            save.data_ptr(), save[N:].data_ptr(), ss.data_ptr(), 1e-3, 0.99, st())
+    mu, var = Cref.mean(0), Cref.var(0)
+    close(save[:N], mu, rtol=1e-4, atol=1e-5)
+    close(save[N:], 1 / np.sqrt(var + 1e-3), rtol=1e-4, atol=1e-5)
+    sc = gamma.cpu().double().numpy() / np.sqrt(var + 1e-3)
+    close(ss[:N], sc, rtol=1e-4, atol=1e-5)
+    close(ss[N:], beta.cpu().double().numpy() - mu * sc, rtol=1e-4, atol=1e-4)
+    y = torch.empty_like(c)
+    L.spnet_bn_apply(c.data_ptr(), M, N, ss.data_ptr(), 1, None, 0, y.data_ptr(), st())
+    close(y, np.maximum((Cref - mu) * sc + beta.cpu().double().numpy(), 0), rtol=1e-3, atol=2e-4)
 
 
 @pytest.mark.parametrize("M,C", [(6144, 728), (50, 64), (23250, 128), (4096, 3), (7, 2048), (3000, 32)])
@@ -218,8 +283,14 @@ def test_maxpool_add(L, B, H, W, C):
     yd = torch.empty(B, OH, OW, C, device="cuda")
     idx = torch.empty(B * OH * OW * C // 4, dtype=torch.int32, device="cuda")
     resd, dyd = res.cuda(), dy.cuda()
-    L.spnet_maxpool3x3s2_add_fwd(xd.data_ptr(), resd.data_ptr(), yd.data_ptr(), idx.data_ptr(), B, H, W, C, st())
+    L.spnet_maxpool3x3s2_add_fwd(xd.data_ptr(), resd.data_ptr(), yd.data_ptr(), idx.data_ptr(), B, H, W, C, None, None, st())
     assert torch.equal(yd.cpu(), y.detach())          # max + one add: bit-exact
+    # with both BatchNorm affines applied on load
+    xs, rss = dev(np.concatenate([rs.randn(C), rs.randn(C)])), dev(np.concatenate([rs.randn(C), rs.randn(C)]))
+    ya = T.maxpool3x3s2_same(x.detach() * xs[:C].cpu() + xs[C:].cpu()) + (res * rss[:C].cpu() + rss[C:].cpu())
+    yd2 = torch.empty_like(yd)
+    L.spnet_maxpool3x3s2_add_fwd(xd.data_ptr(), resd.data_ptr(), yd2.data_ptr(), None, B, H, W, C, xs.data_ptr(), rss.data_ptr(), st())
+    close(yd2, ya, rtol=1e-5, atol=1e-5)
     dxd = torch.empty_like(xd)
     L.spnet_maxpool3x3s2_bwd(dyd.data_ptr(), idx.data_ptr(), dxd.data_ptr(), B, H, W, C, st())
     close(dxd, x.grad, rtol=1e-6, atol=1e-6)
