@@ -197,238 +197,233 @@ __global__ __launch_bounds__(256) void dw3x3_bwd_weight_partial_kernel(
 //
 // A workgroup owns TH x TW output pixels x CC4 channel quads.  Phase 1 stages the (TH+2) x (TW+2) halo
 // tile into LDS with every global element fetched once per tile (16 B per lane, CC4 lanes contiguous
-// along C, zero fill outside the image = SAME padding).  Phase 2: thread (channel quad, column, row
-// strip) slides a 3-row window down its strip reading 3 float4 per row from LDS (a wave reads 1 KiB
-// of consecutive LDS per instruction: conflict-free), so HBM sees ~1.2-1.3x the tensor on the read
-// side and exactly the tensor on the write side.
+// along C, zero fill outside the image = SAME padding).  Phase 2: thread = (channel PAIR, column); it
+// walks down its column with a rolled loop, keeping a three-row window of partial sums in registers
+// (a tile row is read from LDS once: 3 x 8 B per row, a wave reads 512 contiguous bytes per
+// instruction, conflict-free).  Register use is independent of the tile height, so the kernels stay at
+// high occupancy; HBM sees ~1.2-1.3x the tensor on the read side and exactly the tensor on the write.
 //
-// The backward kernel fuses the data gradient (dx = dw3x3(dz, flip w) * relu-mask + add) and the
-// weight gradient (9 taps x C partial sums per workgroup, combined across the 32 threads that share a
-// channel quad through LDS, then by reduce_rows over workgroups): x and dz are each read once.
+// The backward kernel fuses, in one pass over x and dz:
+//   data gradient     dx = dw3x3(dz, flip w) * relu-mask + add
+//   weight gradient   9 taps x C partial sums per workgroup (LDS combine, then reduce_rows)
+//   BatchNorm backward sums of the PRODUCER layer (sum dx, sum dx*xhat) when that layer's affine is
+//   applied here on load (its normalised output is never stored).
 // ================================================================================================
-template <int CC4, int TW, int RS, int NS>
+__device__ __forceinline__ float2 f2_relu(float2 v) { return make_float2(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f)); }
+__device__ __forceinline__ void f2_fma(float2& a, const float2 x, const float2 w) {
+  a.x = fmaf(x.x, w.x, a.x);
+  a.y = fmaf(x.y, w.y, a.y);
+}
+__device__ __forceinline__ float2 f2_mul(const float2 x, const float2 w) { return make_float2(x.x * w.x, x.y * w.y); }
+
+// stage a (TH+2) x (TW+2) x CC4 halo tile of `src` into LDS (float4 per lane, zero outside the image)
+template <int CC4, int TW, int TH>
+__device__ __forceinline__ void dw_stage_tile(float4* __restrict__ tile, const float* __restrict__ src, long ibase,
+                                              int h0, int w0, int c40, int H, int W, int C, int c4n, int tid) {
+  constexpr int PW = TW + 2;
+  for (int idx = tid; idx < (TH + 2) * PW * CC4; idx += 256) {
+    const int l = idx % CC4, p = idx / CC4;
+    const int pw = p % PW, ph = p / PW;
+    const int h = h0 - 1 + ph, w = w0 - 1 + pw, c4 = c40 + l;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (h >= 0 && h < H && w >= 0 && w < W && c4 < c4n)
+      v = *reinterpret_cast<const float4*>(src + ibase + ((long)h * W + w) * C + c4 * 4);
+    tile[idx] = v;
+  }
+}
+
+template <int CC4, int TW, int TH>
 __global__ __launch_bounds__(256) void dw3x3_tile_fwd_kernel(const float* __restrict__ in,
                                                              const float* __restrict__ wt,
                                                              float* __restrict__ out, int H, int W, int C,
                                                              int relu_in, int tiles_h, int tiles_w,
                                                              int cchunks, const float* __restrict__ in_scale,
                                                              const float* __restrict__ in_shift) {
-  constexpr int TH = RS * NS;
   constexpr int PW = TW + 2;
-  static_assert(CC4 * TW * NS == 256, "thread layout");
-  extern __shared__ __attribute__((aligned(16))) float4 tile[];   // [(TH+2)][PW][CC4]
+  constexpr int CC2 = 2 * CC4;
+  static_assert(CC2 * TW == 256, "thread layout");
+  extern __shared__ __attribute__((aligned(16))) float4 tile[];   // [(TH+2)][PW][CC4], raw values
   const int c4n = C >> 2;
   int bid = blockIdx.x;
   const int cc = bid % cchunks; bid /= cchunks;
-  const int tw = bid % tiles_w; bid /= tiles_w;
-  const int th = bid % tiles_h;
-  const int b = bid / tiles_h;
-  const int h0 = th * TH, w0 = tw * TW, c40 = cc * CC4;
-  const float* base = in + (long)b * H * W * C;
-  const int tid = threadIdx.x;
-  for (int idx = tid; idx < (TH + 2) * PW * CC4; idx += 256) {
-    const int l = idx % CC4, p = idx / CC4;
-    const int pw = p % PW, ph = p / PW;
-    const int h = h0 - 1 + ph, w = w0 - 1 + pw, c4 = c40 + l;
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (h >= 0 && h < H && w >= 0 && w < W && c4 < c4n) {
-      v = *reinterpret_cast<const float4*>(base + ((long)h * W + w) * C + c4 * 4);
-      if (in_scale) {   // the producer's BatchNorm affine, applied on load (its output is never stored)
-        const float4 sc = *reinterpret_cast<const float4*>(in_scale + c4 * 4);
-        const float4 sh = *reinterpret_cast<const float4*>(in_shift + c4 * 4);
-        v.x = fmaf(v.x, sc.x, sh.x); v.y = fmaf(v.y, sc.y, sh.y);
-        v.z = fmaf(v.z, sc.z, sh.z); v.w = fmaf(v.w, sc.w, sh.w);
-      }
-      if (relu_in) v = f4_relu(v);
-    }
-    tile[idx] = v;
-  }
-  __syncthreads();
-  const int l = tid % CC4, tcol = (tid / CC4) % TW, strip = tid / (CC4 * TW);
-  const int c4 = c40 + l;
-  if (c4 >= c4n) return;
-  float4 k[9];
-#pragma unroll
-  for (int tp = 0; tp < 9; ++tp) k[tp] = *reinterpret_cast<const float4*>(wt + (long)tp * C + c4 * 4);
-  float4 acc[RS];
-#pragma unroll
-  for (int r = 0; r < RS; ++r) acc[r] = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-  for (int rr = 0; rr < RS + 2; ++rr) {
-    const float4* row = tile + ((strip * RS + rr) * PW + tcol) * CC4 + l;
-    const float4 v0 = row[0], v1 = row[CC4], v2 = row[2 * CC4];
-#pragma unroll
-    for (int kh = 0; kh < 3; ++kh) {
-      const int r = rr - kh;
-      if (r >= 0 && r < RS) {
-        f4_fma(acc[r], v0, k[kh * 3 + 0]);
-        f4_fma(acc[r], v1, k[kh * 3 + 1]);
-        f4_fma(acc[r], v2, k[kh * 3 + 2]);
-      }
-    }
-  }
-  const int w = w0 + tcol;
-  if (w < W) {
-#pragma unroll
-    for (int r = 0; r < RS; ++r) {
-      const int h = h0 + strip * RS + r;
-      if (h < H)
-        *reinterpret_cast<float4*>(out + (((long)b * H + h) * W + w) * C + c4 * 4) = acc[r];
-    }
-  }
-}
-
-template <int CC4, int TW, int RS, int NS>
-__global__ __launch_bounds__(256) void dw3x3_tile_bwd_kernel(
-    const float* __restrict__ dz, const float* __restrict__ x, const float* __restrict__ wt,
-    float* __restrict__ dx, float* __restrict__ partial, const float* __restrict__ add, int H, int W,
-    int C, int relu_in, int tiles_h, int tiles_w, int cchunks, const float* __restrict__ in_scale,
-    const float* __restrict__ in_shift, const float* __restrict__ bn_mean,
-    const float* __restrict__ bn_invstd, float* __restrict__ bn_partial) {
-  constexpr int TH = RS * NS;
-  constexpr int PW = TW + 2;
-  constexpr int TILE = (TH + 2) * PW * CC4;
-  constexpr int GROUP = TW * NS;            // threads that share one channel quad
-  static_assert(CC4 * TW * NS == 256, "thread layout");
-  static_assert(9 * GROUP * CC4 <= 2 * TILE, "reduction scratch fits in the tiles");
-  extern __shared__ __attribute__((aligned(16))) float4 tile[];   // dz tile, then x tile
-  float4* tdz = tile;
-  float4* tx = tile + TILE;
-  const int c4n = C >> 2;
-  int bid = blockIdx.x;
-  const int cc = bid % cchunks; bid /= cchunks;
-  const int sp = bid;                        // spatial workgroup index = partial row
   const int tw = bid % tiles_w; bid /= tiles_w;
   const int th = bid % tiles_h;
   const int b = bid / tiles_h;
   const int h0 = th * TH, w0 = tw * TW, c40 = cc * CC4;
   const long ibase = (long)b * H * W * C;
   const int tid = threadIdx.x;
-  for (int idx = tid; idx < TILE; idx += 256) {
-    const int l = idx % CC4, p = idx / CC4;
-    const int pw = p % PW, ph = p / PW;
-    const int h = h0 - 1 + ph, w = w0 - 1 + pw, c4 = c40 + l;
-    float4 g = make_float4(0.f, 0.f, 0.f, 0.f), v = g;
-    if (h >= 0 && h < H && w >= 0 && w < W && c4 < c4n) {
-      const long o = ibase + ((long)h * W + w) * C + c4 * 4;
-      g = *reinterpret_cast<const float4*>(dz + o);
-      v = *reinterpret_cast<const float4*>(x + o);
-      if (in_scale) {
-        const float4 sc = *reinterpret_cast<const float4*>(in_scale + c4 * 4);
-        const float4 sh = *reinterpret_cast<const float4*>(in_shift + c4 * 4);
-        v.x = fmaf(v.x, sc.x, sh.x); v.y = fmaf(v.y, sc.y, sh.y);
-        v.z = fmaf(v.z, sc.z, sh.z); v.w = fmaf(v.w, sc.w, sh.w);
-      }
-    }
-    tdz[idx] = g;
-    tx[idx] = v;        // the forward input BEFORE its ReLU (post-affine): sign = mask, relu() = operand
-  }
+  dw_stage_tile<CC4, TW, TH>(tile, in, ibase, h0, w0, c40, H, W, C, c4n, tid);
   __syncthreads();
-  const int l = tid % CC4, tcol = (tid / CC4) % TW, strip = tid / (CC4 * TW);
-  const int c4 = c40 + l;
-  const bool active = c4 < c4n;
-  float4 accw[9];
+  const int l2 = tid % CC2, tcol = tid / CC2;
+  const int c2 = c40 * 2 + l2;                       // channel-pair index
+  if (c2 * 2 >= C) return;
+  const float2* t2 = reinterpret_cast<const float2*>(tile);
+  float2 k[9];
 #pragma unroll
-  for (int tp = 0; tp < 9; ++tp) accw[tp] = make_float4(0.f, 0.f, 0.f, 0.f);
-  float4 bsg = make_float4(0.f, 0.f, 0.f, 0.f), bsgx = bsg;   // BatchNorm-backward sums of the producer
-  if (active) {
-    float4 kf[9];   // flipped taps for the data gradient
-#pragma unroll
-    for (int tp = 0; tp < 9; ++tp) kf[tp] = *reinterpret_cast<const float4*>(wt + (long)(8 - tp) * C + c4 * 4);
-    float4 accd[RS];
-#pragma unroll
-    for (int r = 0; r < RS; ++r) accd[r] = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-    for (int rr = 0; rr < RS + 2; ++rr) {
-      const int o = ((strip * RS + rr) * PW + tcol) * CC4 + l;
-      const float4 g0 = tdz[o], g1 = tdz[o + CC4], g2 = tdz[o + 2 * CC4];
-      float4 x0 = tx[o], x1 = tx[o + CC4], x2 = tx[o + 2 * CC4];
-      if (relu_in) { x0 = f4_relu(x0); x1 = f4_relu(x1); x2 = f4_relu(x2); }
-#pragma unroll
-      for (int kh = 0; kh < 3; ++kh) {
-        const int r = rr - kh;               // output row of this strip fed by tile row rr through tap row kh
-        if (r >= 0 && r < RS) {
-          f4_fma(accd[r], g0, kf[kh * 3 + 0]);
-          f4_fma(accd[r], g1, kf[kh * 3 + 1]);
-          f4_fma(accd[r], g2, kf[kh * 3 + 2]);
-          // weight gradient: x row rr, tap row kh, times dz at the centre of output row r
-          const float4 gc = tdz[((strip * RS + r + 1) * PW + tcol + 1) * CC4 + l];
-          f4_fma(accw[kh * 3 + 0], x0, gc);
-          f4_fma(accw[kh * 3 + 1], x1, gc);
-          f4_fma(accw[kh * 3 + 2], x2, gc);
-        }
-      }
+  for (int tp = 0; tp < 9; ++tp) k[tp] = *reinterpret_cast<const float2*>(wt + (long)tp * C + c2 * 2);
+  float2 sc = make_float2(1.f, 1.f), sh = make_float2(0.f, 0.f);
+  const bool affine = in_scale != nullptr;
+  if (affine) {
+    sc = *reinterpret_cast<const float2*>(in_scale + c2 * 2);
+    sh = *reinterpret_cast<const float2*>(in_shift + c2 * 2);
+  }
+  const int w = w0 + tcol;
+  // output tile-row t (1..TH) = sum_kh in[t+kh-1] . k[kh]; input row rr feeds t = rr+1 (kh 0), rr (kh 1), rr-1 (kh 2)
+  float2 a_prev = make_float2(0.f, 0.f), a_cur = a_prev;
+#ifndef DW_FWD_UNROLL
+#define DW_FWD_UNROLL 2
+#endif
+#pragma unroll DW_FWD_UNROLL
+  for (int rr = 0; rr < TH + 2; ++rr) {
+    const int o = ((rr * PW + tcol) * CC4) * 2 + l2;
+    float2 v0 = t2[o], v1 = t2[o + CC2], v2 = t2[o + 2 * CC2];
+    // zero padding must stay zero: the affine / relu only apply to pixels inside the image
+    const int h = h0 - 1 + rr;
+    const bool rv = (h >= 0 && h < H);
+    if (affine) {
+      const bool c0 = rv && (w - 1 >= 0), c1 = rv && (w < W), c2v = rv && (w + 1 < W);
+      v0 = c0 ? make_float2(fmaf(v0.x, sc.x, sh.x), fmaf(v0.y, sc.y, sh.y)) : v0;
+      v1 = c1 ? make_float2(fmaf(v1.x, sc.x, sh.x), fmaf(v1.y, sc.y, sh.y)) : v1;
+      v2 = c2v ? make_float2(fmaf(v2.x, sc.x, sh.x), fmaf(v2.y, sc.y, sh.y)) : v2;
     }
-    const int w = w0 + tcol;
-    if (w < W) {
+    if (relu_in) { v0 = f2_relu(v0); v1 = f2_relu(v1); v2 = f2_relu(v2); }
+    f2_fma(a_prev, v0, k[6]); f2_fma(a_prev, v1, k[7]); f2_fma(a_prev, v2, k[8]);
+    f2_fma(a_cur, v0, k[3]); f2_fma(a_cur, v1, k[4]); f2_fma(a_cur, v2, k[5]);
+    float2 a_next = f2_mul(v0, k[0]);
+    f2_fma(a_next, v1, k[1]); f2_fma(a_next, v2, k[2]);
+    const int t = rr - 1;                            // completed output tile-row
+    const int ho = h0 + t - 1;
+    if (t >= 1 && t <= TH && ho < H && w < W)
+      *reinterpret_cast<float2*>(out + ibase + ((long)ho * W + w) * C + c2 * 2) = a_prev;
+    a_prev = a_cur;
+    a_cur = a_next;
+  }
+}
+
+// Backward.  With offsets d in {-1,0,1}^2 and forward y[p] = sum_d xin[p+d] k[d]:
+//   dx[q]  = sum_d dz[q-d] k[d]          dk[d] = sum_q xin[q] dz[q-d]
+// so BOTH gradients consume the same dz neighbourhood of the centre pixel q: only the dz halo tile goes
+// through LDS, x (and the residual-branch gradient `add`) are read once, at the centres, straight from
+// global memory (128 contiguous bytes per pixel and wave row), one row ahead of their use.
+template <int CC4, int TW, int TH>
+__global__ __launch_bounds__(256) void dw3x3_tile_bwd_kernel(
+    const float* __restrict__ dz, const float* __restrict__ x, const float* __restrict__ wt,
+    float* __restrict__ dx, float* __restrict__ partial, const float* __restrict__ add, int H, int W,
+    int C, int relu_in, int tiles_h, int tiles_w, int cchunks, const float* __restrict__ in_scale,
+    const float* __restrict__ in_shift, const float* __restrict__ bn_mean,
+    const float* __restrict__ bn_invstd, float* __restrict__ bn_partial) {
+  constexpr int PW = TW + 2;
+  constexpr int CC2 = 2 * CC4;
+  constexpr int TILE = (TH + 2) * PW * CC4;          // float4 per tile
+  static_assert(CC2 * TW == 256, "thread layout");
+  extern __shared__ __attribute__((aligned(16))) float4 tile[];   // dz halo tile; >= 11*256 float2 of reduction scratch
+  const int c4n = C >> 2;
+  int bid = blockIdx.x;
+  const int cc = bid % cchunks; bid /= cchunks;
+  const int sp = bid;                                // spatial workgroup index = partial row
+  const int tw = bid % tiles_w; bid /= tiles_w;
+  const int th = bid % tiles_h;
+  const int b = bid / tiles_h;
+  const int h0 = th * TH, w0 = tw * TW, c40 = cc * CC4;
+  const long ibase = (long)b * H * W * C;
+  const int tid = threadIdx.x;
+  dw_stage_tile<CC4, TW, TH>(tile, dz, ibase, h0, w0, c40, H, W, C, c4n, tid);
+  __syncthreads();
+  const int l2 = tid % CC2, tcol = tid / CC2;
+  const int c2 = c40 * 2 + l2;
+  const bool active = c2 * 2 < C;
+  const float2* tdz = reinterpret_cast<const float2*>(tile);
+  const float2 zero2 = make_float2(0.f, 0.f);
+  float2 accw[9];
 #pragma unroll
-      for (int r = 0; r < RS; ++r) {
-        const int h = h0 + strip * RS + r;
-        if (h < H) {
-          const long o = ibase + ((long)h * W + w) * C + c4 * 4;
-          float4 res = accd[r];
-          if (relu_in) {
-            const float4 xm = tx[((strip * RS + r + 1) * PW + tcol + 1) * CC4 + l];
-            res.x = xm.x > 0.f ? res.x : 0.f;
-            res.y = xm.y > 0.f ? res.y : 0.f;
-            res.z = xm.z > 0.f ? res.z : 0.f;
-            res.w = xm.w > 0.f ? res.w : 0.f;
-          }
-          if (add) {
-            const float4 a = *reinterpret_cast<const float4*>(add + o);
-            res.x += a.x; res.y += a.y; res.z += a.z; res.w += a.w;
-          }
-          *reinterpret_cast<float4*>(dx + o) = res;
-          if (bn_partial) {
-            // res = dL/d(BN output of the producer); xhat = (raw - mean) * invstd from the raw pre-BN value
-            const float4 raw = *reinterpret_cast<const float4*>(x + o);
-            const float4 mu = *reinterpret_cast<const float4*>(bn_mean + c4 * 4);
-            const float4 is = *reinterpret_cast<const float4*>(bn_invstd + c4 * 4);
-            bsg.x += res.x; bsg.y += res.y; bsg.z += res.z; bsg.w += res.w;
-            bsgx.x = fmaf(res.x, (raw.x - mu.x) * is.x, bsgx.x);
-            bsgx.y = fmaf(res.y, (raw.y - mu.y) * is.y, bsgx.y);
-            bsgx.z = fmaf(res.z, (raw.z - mu.z) * is.z, bsgx.z);
-            bsgx.w = fmaf(res.w, (raw.w - mu.w) * is.w, bsgx.w);
-          }
-        }
+  for (int tp = 0; tp < 9; ++tp) accw[tp] = zero2;
+  float2 bsg = zero2, bsgx = zero2;                  // BatchNorm-backward sums of the producer
+  const int w = w0 + tcol;
+  if (active && w < W) {
+    float2 k[9];
+#pragma unroll
+    for (int tp = 0; tp < 9; ++tp) k[tp] = *reinterpret_cast<const float2*>(wt + (long)tp * C + c2 * 2);
+    float2 sc = make_float2(1.f, 1.f), sh = zero2, mu = zero2, is = zero2;
+    const bool affine = in_scale != nullptr;
+    if (affine) {
+      sc = *reinterpret_cast<const float2*>(in_scale + c2 * 2);
+      sh = *reinterpret_cast<const float2*>(in_shift + c2 * 2);
+    }
+    if (bn_partial) {
+      mu = *reinterpret_cast<const float2*>(bn_mean + c2 * 2);
+      is = *reinterpret_cast<const float2*>(bn_invstd + c2 * 2);
+    }
+    const long cbase = ibase + (long)w * C + c2 * 2;     // + h*W*C per row
+    // dz window rows (r-1, r, r+1) x columns (w-1, w, w+1); row index r is tile-local (1..TH = outputs)
+    float2 m0, m1, m2, c0, c1, c2r, n0, n1, n2;
+    {
+      const int o0 = ((0 * PW + tcol) * CC4) * 2 + l2, o1 = ((1 * PW + tcol) * CC4) * 2 + l2;
+      m0 = tdz[o0]; m1 = tdz[o0 + CC2]; m2 = tdz[o0 + 2 * CC2];
+      c0 = tdz[o1]; c1 = tdz[o1 + CC2]; c2r = tdz[o1 + 2 * CC2];
+    }
+    float2 x_nxt = zero2, add_nxt = zero2;
+    if (h0 < H) {
+      x_nxt = *reinterpret_cast<const float2*>(x + cbase + (long)h0 * W * C);
+      if (add) add_nxt = *reinterpret_cast<const float2*>(add + cbase + (long)h0 * W * C);
+    }
+#pragma unroll 2
+    for (int t = 1; t <= TH; ++t) {
+      const int ho = h0 + t - 1;
+      if (ho >= H) break;
+      const int o2 = (((t + 1) * PW + tcol) * CC4) * 2 + l2;
+      n0 = tdz[o2]; n1 = tdz[o2 + CC2]; n2 = tdz[o2 + 2 * CC2];
+      const float2 raw = x_nxt, ad = add_nxt;
+      if (t < TH && ho + 1 < H) {                     // next centre row, one iteration ahead
+        x_nxt = *reinterpret_cast<const float2*>(x + cbase + (long)(ho + 1) * W * C);
+        if (add) add_nxt = *reinterpret_cast<const float2*>(add + cbase + (long)(ho + 1) * W * C);
       }
+      float2 a = raw;
+      if (affine) a = make_float2(fmaf(raw.x, sc.x, sh.x), fmaf(raw.y, sc.y, sh.y));
+      const float2 xin = relu_in ? f2_relu(a) : a;
+      // dz[q-d]: d = (kh-1, kw-1)  ->  window row (1-kh)+1 -> kh=0: next row (n*), kh=1: centre, kh=2: previous (m*);
+      //                                 column kw=0: right (index 2), kw=1: centre, kw=2: left (index 0)
+      float2 res = f2_mul(n2, k[0]);
+      f2_fma(res, n1, k[1]); f2_fma(res, n0, k[2]);
+      f2_fma(res, c2r, k[3]); f2_fma(res, c1, k[4]); f2_fma(res, c0, k[5]);
+      f2_fma(res, m2, k[6]); f2_fma(res, m1, k[7]); f2_fma(res, m0, k[8]);
+      f2_fma(accw[0], xin, n2); f2_fma(accw[1], xin, n1); f2_fma(accw[2], xin, n0);
+      f2_fma(accw[3], xin, c2r); f2_fma(accw[4], xin, c1); f2_fma(accw[5], xin, c0);
+      f2_fma(accw[6], xin, m2); f2_fma(accw[7], xin, m1); f2_fma(accw[8], xin, m0);
+      if (relu_in) {
+        res.x = a.x > 0.f ? res.x : 0.f;
+        res.y = a.y > 0.f ? res.y : 0.f;
+      }
+      if (add) { res.x += ad.x; res.y += ad.y; }
+      *reinterpret_cast<float2*>(dx + cbase + (long)ho * W * C) = res;
+      if (bn_partial) {   // res = dL/d(BN output of the producer); xhat from the raw pre-BN value
+        bsg.x += res.x; bsg.y += res.y;
+        bsgx.x = fmaf(res.x, (raw.x - mu.x) * is.x, bsgx.x);
+        bsgx.y = fmaf(res.y, (raw.y - mu.y) * is.y, bsgx.y);
+      }
+      m0 = c0; m1 = c1; m2 = c2r;
+      c0 = n0; c1 = n1; c2r = n2;
     }
   }
-  // combine the 9 tap sums over the GROUP threads of each channel quad (fixed order), one partial row
-  // per spatial workgroup
+  // combine the 9 tap sums (+ the 2 BatchNorm sums) over the TW threads of each channel pair, fixed order
   __syncthreads();
-  const int grp = tid / CC4;                 // 0..GROUP-1
+  float2* red = reinterpret_cast<float2*>(tile);
+  const int grp = tid / CC2;                         // 0..TW-1
 #pragma unroll
-  for (int tp = 0; tp < 9; ++tp) tile[(tp * GROUP + grp) * CC4 + l] = accw[tp];
+  for (int tp = 0; tp < 9; ++tp) red[(tp * TW + grp) * CC2 + l2] = accw[tp];
+  red[(9 * TW + grp) * CC2 + l2] = bsg;
+  red[(10 * TW + grp) * CC2 + l2] = bsgx;
   __syncthreads();
-  if (tid < 9 * CC4) {
-    const int tp = tid / CC4, ll = tid % CC4;
-    const int c4o = c40 + ll;
-    if (c4o < c4n) {
-      float4 s = tile[(tp * GROUP) * CC4 + ll];
-      for (int g = 1; g < GROUP; ++g) {
-        const float4 v = tile[(tp * GROUP + g) * CC4 + ll];
-        s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+  for (int q = tid; q < 11 * CC2; q += 256) {
+    const int tp = q / CC2, ll = q % CC2;
+    const int c2o = c40 * 2 + ll;
+    if (c2o * 2 < C && (tp < 9 || bn_partial)) {
+      float2 s = red[(tp * TW) * CC2 + ll];
+      for (int g = 1; g < TW; ++g) {
+        const float2 v = red[(tp * TW + g) * CC2 + ll];
+        s.x += v.x; s.y += v.y;
       }
-      *reinterpret_cast<float4*>(partial + ((long)sp * 9 + tp) * C + c4o * 4) = s;
-    }
-  }
-  if (bn_partial) {   // second round through the same scratch: the two BatchNorm-backward sums
-    __syncthreads();
-    tile[(0 * GROUP + grp) * CC4 + l] = bsg;
-    tile[(1 * GROUP + grp) * CC4 + l] = bsgx;
-    __syncthreads();
-    if (tid < 2 * CC4) {
-      const int q = tid / CC4, ll = tid % CC4;
-      const int c4o = c40 + ll;
-      if (c4o < c4n) {
-        float4 s = tile[(q * GROUP) * CC4 + ll];
-        for (int g = 1; g < GROUP; ++g) {
-          const float4 v = tile[(q * GROUP + g) * CC4 + ll];
-          s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
-        }
-        *reinterpret_cast<float4*>(bn_partial + ((long)sp * 2 + q) * C + c4o * 4) = s;
-      }
+      if (tp < 9) *reinterpret_cast<float2*>(partial + ((long)sp * 9 + tp) * C + c2o * 2) = s;
+      else *reinterpret_cast<float2*>(bn_partial + ((long)sp * 2 + (tp - 9)) * C + c2o * 2) = s;
     }
   }
 }
@@ -531,18 +526,20 @@ extern "C" int spnet_reduce_rows(const float* in, int P, int L, float* out, void
 
 // ---------------------------------------------------------------- tiled entry points
 struct DwGeom { int cfg, th, tw, cc4, tiles_h, tiles_w, cchunks; long nblk; size_t lds_fwd, lds_bwd; };
-static DwGeom dw_geom(int B, int H, int W, int C) {
+// cfg 1: 6x8 pixel tile x 16 channel quads (exit flow, 6x8 planes); cfg 0: 12x16 tile x 8 quads;
+// cfg 2 (forward only): 24x16 tile x 8 quads for the large planes (halo read overhead 1.22 instead of 1.31)
+static DwGeom dw_geom(int B, int H, int W, int C, bool fwd) {
   DwGeom g;
-  g.cfg = (H <= 6 && W <= 8) ? 1 : 0;       // 1: 6x8 tile x 16 quads (exit flow); 0: 12x16 tile x 8 quads
-  g.th = g.cfg ? 6 : 12;
-  g.tw = g.cfg ? 8 : 16;
-  g.cc4 = g.cfg ? 16 : 8;
+  g.cfg = (H <= 6 && W <= 8) ? 1 : 0;   // (a 24x16 forward tile was tried: 60 KB of LDS halves residency and loses)
+  g.th = g.cfg == 1 ? 6 : (g.cfg == 2 ? 24 : 12);
+  g.tw = g.cfg == 1 ? 8 : 16;
+  g.cc4 = g.cfg == 1 ? 16 : 8;
   g.tiles_h = (H + g.th - 1) / g.th;
   g.tiles_w = (W + g.tw - 1) / g.tw;
   g.cchunks = (C / 4 + g.cc4 - 1) / g.cc4;
   g.nblk = (long)B * g.tiles_h * g.tiles_w * g.cchunks;
   g.lds_fwd = (size_t)(g.th + 2) * (g.tw + 2) * g.cc4 * sizeof(float4);
-  g.lds_bwd = 2 * g.lds_fwd;
+  g.lds_bwd = g.lds_fwd > 11 * 256 * sizeof(float2) ? g.lds_fwd : 11 * 256 * sizeof(float2);   // dz tile / reduction scratch
   return g;
 }
 
@@ -550,26 +547,26 @@ extern "C" int spnet_dwconv3x3_tiled_fwd(const float* x, const float* w, float* 
                                          int C, int relu_in, const float* in_scale,
                                          const float* in_shift, void* stream) {
   if (C & 3) return (int)hipErrorInvalidValue;
-  const DwGeom g = dw_geom(B, H, W, C);
-  if (g.cfg)
-    hipLaunchKernelGGL((dw3x3_tile_fwd_kernel<16, 8, 3, 2>), dim3((unsigned)g.nblk), dim3(256), g.lds_fwd,
-                       (hipStream_t)stream, x, w, y, H, W, C, relu_in, g.tiles_h, g.tiles_w, g.cchunks, in_scale,
-                       in_shift);
-  else
-    hipLaunchKernelGGL((dw3x3_tile_fwd_kernel<8, 16, 6, 2>), dim3((unsigned)g.nblk), dim3(256), g.lds_fwd,
-                       (hipStream_t)stream, x, w, y, H, W, C, relu_in, g.tiles_h, g.tiles_w, g.cchunks, in_scale,
-                       in_shift);
+  const DwGeom g = dw_geom(B, H, W, C, true);
+#define DW_FWD(CC4, TW, TH)                                                                                     \
+  hipLaunchKernelGGL((dw3x3_tile_fwd_kernel<CC4, TW, TH>), dim3((unsigned)g.nblk), dim3(256), g.lds_fwd,        \
+                     (hipStream_t)stream, x, w, y, H, W, C, relu_in, g.tiles_h, g.tiles_w, g.cchunks, in_scale, \
+                     in_shift)
+  if (g.cfg == 1) DW_FWD(16, 8, 6);
+  else if (g.cfg == 2) DW_FWD(8, 16, 24);
+  else DW_FWD(8, 16, 12);
+#undef DW_FWD
   SPNET_RETURN_LAUNCH_STATUS();
 }
 
 extern "C" long spnet_dwconv3x3_tiled_rows(int B, int H, int W, int C) {
-  const DwGeom g = dw_geom(B, H, W, C);
+  const DwGeom g = dw_geom(B, H, W, C, false);
   return (long)B * g.tiles_h * g.tiles_w;   // rows of the [rows][2][C] BatchNorm partial buffer
 }
 
 // floats of workspace needed by spnet_dwconv3x3_tiled_bwd
 extern "C" long spnet_dwconv3x3_tiled_bwd_ws(int B, int H, int W, int C) {
-  const DwGeom g = dw_geom(B, H, W, C);
+  const DwGeom g = dw_geom(B, H, W, C, false);
   return ((long)B * g.tiles_h * g.tiles_w + 32) * 9 * C;      // partial rows + 32 second-level slices
 }
 
@@ -584,13 +581,13 @@ extern "C" int spnet_dwconv3x3_tiled_bwd(const float* dy, const float* x_fwd, co
                                          const float* bn_invstd, float* bn_partial, void* stream) {
   if (bn_partial && (!bn_mean || !bn_invstd)) return (int)hipErrorInvalidValue;
   if (C & 3) return (int)hipErrorInvalidValue;
-  const DwGeom g = dw_geom(B, H, W, C);
-  if (g.cfg)
-    hipLaunchKernelGGL((dw3x3_tile_bwd_kernel<16, 8, 3, 2>), dim3((unsigned)g.nblk), dim3(256), g.lds_bwd,
+  const DwGeom g = dw_geom(B, H, W, C, false);
+  if (g.cfg == 1)
+    hipLaunchKernelGGL((dw3x3_tile_bwd_kernel<16, 8, 6>), dim3((unsigned)g.nblk), dim3(256), g.lds_bwd,
                        (hipStream_t)stream, dy, x_fwd, w, dx, workspace, add, H, W, C, relu_in, g.tiles_h,
                        g.tiles_w, g.cchunks, in_scale, in_shift, bn_mean, bn_invstd, bn_partial);
   else
-    hipLaunchKernelGGL((dw3x3_tile_bwd_kernel<8, 16, 6, 2>), dim3((unsigned)g.nblk), dim3(256), g.lds_bwd,
+    hipLaunchKernelGGL((dw3x3_tile_bwd_kernel<8, 16, 12>), dim3((unsigned)g.nblk), dim3(256), g.lds_bwd,
                        (hipStream_t)stream, dy, x_fwd, w, dx, workspace, add, H, W, C, relu_in, g.tiles_h,
                        g.tiles_w, g.cchunks, in_scale, in_shift, bn_mean, bn_invstd, bn_partial);
   const int P = B * g.tiles_h * g.tiles_w, L = 9 * C;
