@@ -111,11 +111,11 @@ def main():
     rank, local_rank, world = parallel.init_distributed()
     if world != args.gpus:
         raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, world))
-    dev = torch.device("cuda", local_rank)
+    dev = torch.device("cuda", local_rank % torch.cuda.device_count())   # (>1 rank per GPU only in gloo rehearsals)
     torch.cuda.set_device(dev)
 
     # ---- synthetic data, resident in HBM before timing (rank-specific frames: weak scaling)
-    X_u8, labels = F.generate(args.pool, seed=1 + rank)
+    X_u8, labels = F.generate(args.pool, seed=1 + rank, workers=max(2, min(16, (os.cpu_count() or 8) // world)))
     Y_host = labels_to_Y(labels)
     X_pool = torch.from_numpy(F.to_network_input(X_u8)).to(dev)
     Y_pool = torch.from_numpy(Y_host).to(dev)

@@ -148,8 +148,18 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
     }
     const float* as = cur;
     const float* bs = cur + SA::SIZE;
+    // The next tile's registers are written to the idle LDS buffer in the MIDDLE of the MFMA stream:
+    // nobody reads that buffer during this iteration, so its ds_write latency (and the vmcnt wait in
+    // front of it) hides under the second half of the MFMAs instead of sitting in front of the barrier.
+#ifndef SP_STORE_AT
+#define SP_STORE_AT (BK / 2)
+#endif
 #pragma unroll
     for (int kk = 0; kk < BK; kk += 4) {
+      if (kk == SP_STORE_AT && more) {
+        sa.store(nxt, tid);
+        sb.store(nxt + SA::SIZE, tid);
+      }
       float a[TM], b[TN];
 #pragma unroll
       for (int i = 0; i < TM; ++i) a[i] = SA::fetch(as, arow + i * 16, kk + kq);
@@ -161,7 +171,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
         for (int j = 0; j < TN; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[i][j], 0, 0, 0);
     }
-    if (more) {
+    if (SP_STORE_AT >= BK && more) {
       sa.store(nxt, tid);
       sb.store(nxt + SA::SIZE, tid);
     }
