@@ -31,6 +31,18 @@ DW_TRAIN_BYTES_PER_IMAGE = 157.6e6  # depthwise stack, f
 DW_FWD_BYTES_PER_IMAGE = 63.1e6
 
 
+def measured_traffic():
+    """HBM bytes per launch from the committed PMC pass (profiles/r01_c_hbm_traffic.json: rocprofv3 --pmc
+    FETCH_SIZE / WRITE_SIZE in separate passes over this same command, FETCH_SIZE doubled as
+    MI355X_MICROARCH.md prescribes for gfx950).  Not a live measurement: PMC passes cannot run inside the
+    timed benchmark."""
+    p = os.path.join(ROOT, "profiles", "r01_c_hbm_traffic.json")
+    if not os.path.exists(p):
+        return {}
+    with open(p) as f:
+        return json.load(f)
+
+
 def labels_to_Y(label_rows):
     """Generator rows (cx,cy,a,b,angle,rings) -> normalised grid targets [n,576] (utils.py:260-320 path)."""
     from spnet_amd import utils as U
@@ -179,6 +191,13 @@ def main():
             fam = {}
             for k, (n, ms, work) in tot.items():
                 fam[k] = dict(launches_per_step=n / args.steps, ms_per_step=round(ms / args.steps, 3))
+            tr = measured_traffic()
+            g_traffic = tr.get("gemm", {}).get("hbm_bytes_per_launch")
+            d_traffic = None
+            if "dw_fwd" in tr and "dw_bwd" in tr:
+                d_traffic = (tr["dw_fwd"]["hbm_bytes_per_launch"] * tr["dw_fwd"]["launches"] +
+                             tr["dw_bwd"]["hbm_bytes_per_launch"] * tr["dw_bwd"]["launches"]) / \
+                            (tr["dw_fwd"]["launches"] + tr["dw_bwd"]["launches"])
             g_n, g_ms, g_flop = tot["gemm"]
             d_n, d_ms, d_bytes = tot["dw"]
             gemm_tflops = g_flop / (g_ms * 1e-3) / 1e12
@@ -186,12 +205,15 @@ def main():
             roof_gemm = {"kernel": "gemm_f32_kernel (pointwise / residual / block1_conv2 / Dense GEMMs, fwd+dgrad+wgrad, "
                                    "incl. split-K slab reduce)",
                          "bound": "mfma", "achieved": round(gemm_tflops, 2), "peak": FP32_MFMA_PEAK_TFLOPS,
-                         "unit": "TFLOP/s", "frac": round(gemm_tflops / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                         "unit": "TFLOP/s", "frac": round(gemm_tflops / FP32_MFMA_PEAK_TFLOPS, 4),
+                         "traffic": None if g_traffic is None else round(g_traffic),
                          "avg_launch_us": round(1e3 * g_ms / g_n, 2), "launches_per_step": g_n / args.steps,
                          "ms_per_step": round(g_ms / args.steps, 3)}
-            roof_dw = {"kernel": "dw3x3_kernel<0/1> + dw3x3_bwd_weight_partial_kernel (34 depthwise layers, fwd+bwd)",
+            roof_dw = {"kernel": "dw3x3_tile_fwd_kernel + dw3x3_tile_bwd_kernel (34 depthwise layers, fwd + fused bwd)",
                        "bound": "hbm", "achieved": round(dw_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                       "frac": round(dw_gbs / HBM_PEAK_GBS, 4), "traffic": None,
+                       "frac": round(dw_gbs / HBM_PEAK_GBS, 4),
+                       "traffic": None if d_traffic is None else round(d_traffic),
+                       "algorithmic_bytes_per_launch": round(DW_TRAIN_BYTES_PER_IMAGE * BATCH * args.steps / d_n),
                        "avg_launch_us": round(1e3 * d_ms / d_n, 2), "launches_per_step": d_n / args.steps,
                        "ms_per_step": round(d_ms / args.steps, 3)}
             result["roofline"] = roof_gemm if g_ms >= d_ms else roof_dw
