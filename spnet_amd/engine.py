@@ -33,6 +33,8 @@ WS_GEMM = (0, 16 * 1024 * 1024)                       # split-K slabs
 WS_DW = (16 * 1024 * 1024, 16 * 1024 * 1024)          # depthwise weight-gradient partials
 WS_BNP = (32 * 1024 * 1024, 8 * 1024 * 1024)          # BatchNorm partial sums from GEMM / depthwise epilogues
 WS_MISC = (40 * 1024 * 1024, 8 * 1024 * 1024)         # stand-alone BN reductions, small-conv partials
+WS_GEMM2 = (48 * 1024 * 1024, 16 * 1024 * 1024)       # split-K slabs of the weight-gradient stream
+WS_TOTAL = 64 * 1024 * 1024
 ALIGN = 64
 
 
@@ -155,6 +157,7 @@ class Engine:
         self.adam_eps = adam_eps
         self.t = 0                      # optimizer iterations done
         self.prof = None                # KernelTimer or None
+        self.overlap_wgrad = True       # pointwise weight gradients on a side stream (joined before Adam)
         self.drop_seed = 12345
         torch.cuda.set_device(self.dev)
         if share_from is not None:      # second plan (other batch size / inference) over the SAME weights
@@ -269,7 +272,9 @@ class Engine:
     def _build_graph(self):
         B, H, W = self.B, self.H, self.W
         tr = self.train_capable
-        self.ws = self.new(WS_FLOATS)
+        self.ws = self.new(WS_TOTAL)
+        # weight-gradient GEMMs run on a second HIP stream, concurrently with the data-gradient chain
+        self.wgrad_stream = torch.cuda.Stream(device=self.dev) if (tr and self.overlap_wgrad) else None
         self.small = self.new(8 * 4096)          # BN scale/shift + backward coefficient scratch
         self.nodes = []
         self.x_in = self.new(B, H, W, 1)
@@ -334,6 +339,8 @@ class Engine:
             g = node.bwd(g)
             if on_node_done is not None:
                 on_node_done(node)
+        if self.wgrad_stream is not None:      # every weight gradient must have landed before the optimizer
+            torch.cuda.current_stream().wait_stream(self.wgrad_stream)
 
     def loss(self, Y=None, with_grad=True):
         if Y is not None:
@@ -385,12 +392,12 @@ class Node:
         raise NotImplementedError
 
 
-def _gemm(A, a_major, lda, Bm, b_major, ldb, C, ldc, M, N, K, eng, bias=None, split_k=0, tile=0):
+def _gemm(A, a_major, lda, Bm, b_major, ldb, C, ldc, M, N, K, eng, bias=None, split_k=0, tile=0, region=WS_GEMM):
     prof = eng.prof
     if prof is not None:
         t0 = prof.start()
     L.spnet_gemm_f32(L.ptr(A), a_major, lda, L.ptr(Bm), b_major, ldb, L.ptr(C), ldc, M, N, K, split_k,
-                     eng.ws_ptr(WS_GEMM), WS_GEMM[1], L.ptr(bias), tile, _stream())
+                     eng.ws_ptr(region), region[1], L.ptr(bias), tile, _stream())
     if prof is not None:
         prof.stop("gemm", t0, 2.0 * M * N * K)
 
@@ -536,10 +543,21 @@ class Pointwise:
         return _gemm_colstats(x, self.cin, self.w, self.cout, y, self.cout, self.M, self.cout, self.cin, self.e)
 
     def bwd(self, x, dy, dx):
-        # dW[cin,cout] = x^T dy ; dx[M,cin] = dy W^T
-        _gemm(x, OUT_MAJOR, self.cin, dy, OUT_MAJOR, self.cout, self.gw, self.cout, self.cin, self.cout, self.M, self.e)
+        """dW[cin,cout] = x^T dy ; dx[M,cin] = dy W^T.  The two products are independent: dW goes to the
+        engine's weight-gradient stream (own split-K workspace) and overlaps everything that follows on
+        the main stream until Engine.backward() joins the streams in front of the optimizer.  x and dy
+        are not rewritten before that join (they are only produced once per step)."""
+        e = self.e
+        side = e.wgrad_stream
+        if side is None:
+            _gemm(x, OUT_MAJOR, self.cin, dy, OUT_MAJOR, self.cout, self.gw, self.cout, self.cin, self.cout, self.M, e)
+        else:
+            side.wait_stream(torch.cuda.current_stream())      # dy has just been produced on the main stream
+            with torch.cuda.stream(side):
+                _gemm(x, OUT_MAJOR, self.cin, dy, OUT_MAJOR, self.cout, self.gw, self.cout, self.cin, self.cout,
+                      self.M, e, region=WS_GEMM2)
         if dx is not None:
-            _gemm(dy, K_MAJOR, self.cout, self.w, K_MAJOR, self.cout, dx, self.cin, self.M, self.cin, self.cout, self.e)
+            _gemm(dy, K_MAJOR, self.cout, self.w, K_MAJOR, self.cout, dx, self.cin, self.M, self.cin, self.cout, e)
 
 
 class Conv3x3Gemm(Node):
