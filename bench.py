@@ -166,6 +166,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         out = step()
+    t_host = time.perf_counter() - t0          # host time to ENQUEUE the K steps (launches are asynchronous)
     fence()
     dt = time.perf_counter() - t0
     loss = float(out[5])
@@ -202,7 +203,8 @@ def main():
                                    "batch 32 per GPU, full train step (augment+fwd+custom_loss+bwd+Adam+l2)",
                        "global_batch": BATCH * world, "frame_hw": [H, W], "pool_frames_per_gpu": args.pool,
                        "parallelism": "dp%d" % world, "final_loss": round(loss, 6),
-                       "wgrad_overlap": not args.no_overlap},
+                       "wgrad_overlap": not args.no_overlap,
+                       "host_enqueue_ms_per_step": round(1e3 * t_host / args.steps, 3)},
         }
         if timer is not None:
             tot = timer.totals()

@@ -130,10 +130,11 @@ int spnet_decode(const float* y_norm, const float* means, const float* ranges, f
 
 /* ---- optimizer ---------------------------------------------------------------------------------- */
 /* Keras Adam + l2 on the first l2_n elements (spnet/models.py:494, 47-71).  sq_scratch >= 2048 floats.
- * mask (or NULL): n floats, 0 = frozen element (layer.trainable=False, spnet/models.py:361-373). */
+ * mask (or NULL): n floats, 0 = frozen element (layer.trainable=False, spnet/models.py:361-373).
+ * lr_t_dev (or NULL): device float overriding lr_t, so a captured hipGraph of the step can be replayed. */
 int spnet_adam_step(float* p, const float* g, float* m, float* v, long n, long l2_n, float lr_t,
                     float beta1, float beta2, float eps, float l2, float grad_scale, const float* mask,
-                    float* sq_scratch, float* l2_loss_out, void* stream);
+                    float* sq_scratch, float* l2_loss_out, const float* lr_t_dev, void* stream);
 
 /* ---- augmentation (spnet/callbacks.py:272-341, spnet/augmentation.py) ---------------------------- */
 /* per-frame min/max -> mm[N][2]; scratch: N*32 floats */
@@ -145,7 +146,8 @@ int spnet_saltpepper(float* x, int N, int H, int W, const int* coords, int n_sal
 int spnet_warp_affine(const float* src, float* dst, int N, int H, int W, int C, const float* minv,
                       void* stream);
 /* Dropout(0.1) of the stem (spnet/models.py:340); same call with dy regenerates the mask in backward. */
-int spnet_dropout(const float* x, float* y, long n, unsigned seed, float rate, void* stream);
+int spnet_dropout(const float* x, float* y, long n, unsigned seed, float rate, const unsigned* seed_dev,
+                  void* stream);   /* seed_dev (or NULL): device uint32 overriding seed (hipGraph replay) */
 
 #ifdef __cplusplus
 }

@@ -141,7 +141,9 @@ __device__ __forceinline__ uint32_t hash_u32(uint32_t x) {
 }
 __global__ __launch_bounds__(256) void dropout_kernel(const float* __restrict__ x,
                                                       float* __restrict__ y, long n, uint32_t seed,
-                                                      uint32_t thresh, float scale) {
+                                                      uint32_t thresh, float scale,
+                                                      const uint32_t* __restrict__ seed_dev) {
+  if (seed_dev) seed = seed_dev[0];   // per-step seed read from device memory (hipGraph replay)
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
     const uint32_t h = hash_u32((uint32_t)i * 0x9e3779b9U + seed);
     y[i] = (h >= thresh) ? x[i] * scale : 0.f;
@@ -183,10 +185,11 @@ extern "C" int spnet_warp_affine(const float* src, float* dst, int N, int H, int
 }
 
 // rate in [0,1): elements with hash < rate*2^32 are dropped, survivors scaled by 1/(1-rate).
-extern "C" int spnet_dropout(const float* x, float* y, long n, unsigned seed, float rate, void* stream) {
+extern "C" int spnet_dropout(const float* x, float* y, long n, unsigned seed, float rate,
+                             const unsigned* seed_dev, void* stream) {
   const double t = (double)rate * 4294967296.0;
   const uint32_t thresh = (uint32_t)(t > 4294967295.0 ? 4294967295.0 : t);
   hipLaunchKernelGGL(dropout_kernel, dim3(spnet_ew_grid(n, 256)), dim3(256), 0, (hipStream_t)stream, x,
-                     y, n, seed, thresh, 1.0f / (1.0f - rate));
+                     y, n, seed, thresh, 1.0f / (1.0f - rate), seed_dev);
   SPNET_RETURN_LAUNCH_STATUS();
 }

@@ -17,8 +17,10 @@ __global__ __launch_bounds__(256) void adam_l2_kernel(float* __restrict__ p, con
                                                       long n, long l2_n, float lr_t, float beta1,
                                                       float beta2, float eps, float l2,
                                                       float grad_scale, const float* __restrict__ mask,
-                                                      float* __restrict__ sq_partial) {
+                                                      float* __restrict__ sq_partial,
+                                                      const float* __restrict__ lr_dev) {
   __shared__ float red[4];
+  if (lr_dev) lr_t = lr_dev[0];   // step size kept in device memory so a captured hipGraph can be replayed
   const long n4 = n >> 2;
   float sq = 0.f;
   const float twol2 = 2.f * l2;
@@ -77,13 +79,13 @@ __global__ __launch_bounds__(256) void sum_partials_kernel(const float* __restri
 extern "C" int spnet_adam_step(float* p, const float* g, float* m, float* v, long n, long l2_n,
                                float lr_t, float beta1, float beta2, float eps, float l2,
                                float grad_scale, const float* mask, float* sq_scratch,
-                               float* l2_loss_out, void* stream) {
+                               float* l2_loss_out, const float* lr_t_dev, void* stream) {
   if (n & 3) return (int)hipErrorInvalidValue;
   hipStream_t st = (hipStream_t)stream;
   long g4 = (n / 4 + 255) / 256;
   int grid = (int)(g4 > ADAM_BLOCKS ? ADAM_BLOCKS : (g4 < 1 ? 1 : g4));
   hipLaunchKernelGGL(adam_l2_kernel, dim3(grid), dim3(256), 0, st, p, g, m, v, n, l2_n, lr_t, beta1,
-                     beta2, eps, l2, grad_scale, mask, sq_scratch);
+                     beta2, eps, l2, grad_scale, mask, sq_scratch, lr_t_dev);
   if (sq_scratch && l2_loss_out)
     hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, st, sq_scratch, grid, l2, l2_loss_out);
   SPNET_RETURN_LAUNCH_STATUS();

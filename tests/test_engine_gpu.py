@@ -79,7 +79,7 @@ def test_training_forward_and_gradients(setup):
     eng, P, X, Y = setup
     eng.load_state_dict(P)
     seed = 424242
-    eng.drop_seed = seed
+    eng.set_drop_seed(seed)
     h2, w2 = H // 2, W // 2
     mask = torch.tensor(dropout_mask(B * h2 * w2 * 3, seed).reshape(B, h2, w2, 3))
     Pc = {k: v.clone() for k, v in P.items()}

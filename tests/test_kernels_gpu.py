@@ -407,7 +407,7 @@ def test_adam_matches_keras_form(L):
     import math
     lr_t = lr * math.sqrt(1 - 0.999 ** t) / (1 - 0.9 ** t)
     L.spnet_adam_step(pd.data_ptr(), gd.data_ptr(), md.data_ptr(), vd.data_ptr(), n, l2n, lr_t, 0.9, 0.999, 1e-7, 1e-4, 0.5,
-                      None, sq.data_ptr(), l2out.data_ptr(), st())
+                      None, sq.data_ptr(), l2out.data_ptr(), None, st())
     wp, wm, wv = p.copy(), m.copy(), v.copy()
     wp[:l2n], wm[:l2n], wv[:l2n] = R.adam_step(p[:l2n], g[:l2n] * 0.5, m[:l2n], v[:l2n], t, lr, l2=1e-4)
     wp[l2n:], wm[l2n:], wv[l2n:] = R.adam_step(p[l2n:], g[l2n:] * 0.5, m[l2n:], v[l2n:], t, lr)
@@ -420,8 +420,9 @@ def test_adam_matches_keras_form(L):
 def test_dropout_mask_is_reproducible(L):
     x = torch.ones(100000, device="cuda")
     y1, y2 = torch.empty_like(x), torch.empty_like(x)
-    L.spnet_dropout(x.data_ptr(), y1.data_ptr(), x.numel(), 77, 0.1, st())
-    L.spnet_dropout(x.data_ptr(), y2.data_ptr(), x.numel(), 77, 0.1, st())
+    L.spnet_dropout(x.data_ptr(), y1.data_ptr(), x.numel(), 77, 0.1, None, st())
+    sd = torch.tensor([77], dtype=torch.int32, device="cuda")
+    L.spnet_dropout(x.data_ptr(), y2.data_ptr(), x.numel(), 1, 0.1, sd.data_ptr(), st())   # seed from device memory
     assert torch.equal(y1, y2)
     keep = (y1 > 0).float().mean().item()
     assert abs(keep - 0.9) < 0.01
