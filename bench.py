@@ -100,6 +100,37 @@ def cpu_baseline(X_u8, Y, steps, batch):
                        "oracle/numpy_ref.py on %d threads, %.1f s" % (steps, batch, W, H, cores, dt))
 
 
+def secondary(args):
+    """Secondary measurements (single GPU): other frame sizes / batch sizes, or inference throughput as
+    predict_spnet.py measures it (model.predict over device-resident frames, FPS)."""
+    import torch
+    from spnet_amd.engine import Engine
+    h, w, b = args.height, args.width, args.batch
+    dev = torch.device("cuda", 0)
+    eng = Engine(h, w, b, device="cuda:0", seed=0, train=(args.mode == "train"))
+    X = torch.rand(b, h, w, 1, device=dev) * 2 - 1
+    Y = torch.rand(b, 576, device=dev)
+
+    def step():
+        if args.mode == "train":
+            eng.train_step(X, Y, 1e-5)
+        else:
+            eng.forward(X, training=False)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    print(json.dumps({"metric": "%s images/sec, Xception backbone (secondary measurement)" % args.mode,
+                      "value": round(b * args.steps / dt, 2), "unit": "images/sec", "n_gpus": 1, "steps": args.steps,
+                      "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3), "dtype": "f32",
+                      "data": "synthetic (uniform noise)", "config": {"workload": "%s, %dx%d frames, batch %d" % (args.mode, w, h, b)}}))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -110,6 +141,11 @@ def main():
     ap.add_argument("--cpu-baseline-batch", type=int, default=8)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timers", action="store_true")
+    ap.add_argument("--mode", choices=["train", "predict"], default="train",
+                    help="predict: inference-only forward (BASELINE configs[4]); secondary, not the headline metric")
+    ap.add_argument("--height", type=int, default=H)
+    ap.add_argument("--width", type=int, default=W)
+    ap.add_argument("--batch", type=int, default=BATCH)
     ap.add_argument("--no-overlap", action="store_true",
                     help="run the weight-gradient GEMMs on the main stream (the roofline leg always does)")
     args = ap.parse_args()
@@ -122,6 +158,8 @@ def main():
     from spnet_amd.callbacks import get_1cycle_schedule
     from spnet_amd.engine import Engine, KernelTimer
 
+    if (args.height, args.width, args.batch, args.mode) != (H, W, BATCH, "train"):
+        return secondary(args)
     rank, local_rank, world = parallel.init_distributed()
     if world != args.gpus:
         raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, world))

@@ -76,9 +76,77 @@ struct TileStage {
 
   // element (row r of the tile, reduction index k of the tile)
   static __device__ __forceinline__ float fetch(const float* __restrict__ S, int r, int k) {
+#if defined(SP_ABLATE) && SP_ABLATE == 1
+    return (float)(r + k) * 1e-3f;     // ablation build: no LDS operand reads
+#else
     return (MAJ == SP_K_MAJOR) ? S[r * LD + k] : S[k * LD + r];
+#endif
   }
 };
+
+template <int BM, int BN, int WM, int WN, int TM, int TN>
+__device__ __forceinline__ void gemm_epilogue(f32x4 (&acc)[TM][TN], float* __restrict__ smem,
+                                              float* __restrict__ C, int ldc, int M, int N, int m0, int n0,
+                                              int tm, int z, long slab_stride, const float* __restrict__ bias,
+                                              float* __restrict__ colstats, int tid, int lane, int wm, int wn) {
+  // Optional BatchNorm statistics of the output tile: per column sum and sum of squares over this
+  // workgroup's BM rows -> colstats[tm][2][N] (rows past M hold zeros and contribute nothing).
+  // Fixed reduction order: registers (i, r) -> lanes (xor 16, 32) -> waves (wm order) through LDS.
+  if (colstats) {
+    float* sred = smem;                       // [2][WM][BN], the staging buffers are idle now
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      float sv = 0.f, qv = 0.f;
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = m0 + wm * (TM * 16) + i * 16 + 4 * (lane >> 4) + r;
+          const float v = row < M ? acc[i][j][r] : 0.f;
+          sv += v;
+          qv = fmaf(v, v, qv);
+        }
+      sv += __shfl_xor(sv, 16, 64);
+      qv += __shfl_xor(qv, 16, 64);
+      sv += __shfl_xor(sv, 32, 64);
+      qv += __shfl_xor(qv, 32, 64);
+      if (lane < 16) {
+        const int cl = wn * (TN * 16) + j * 16 + lane;
+        sred[(0 * WM + wm) * BN + cl] = sv;
+        sred[(1 * WM + wm) * BN + cl] = qv;
+      }
+    }
+    __syncthreads();
+    for (int c = tid; c < 2 * BN; c += 256) {
+      const int q = c / BN, cl = c % BN;
+      const int col = n0 + cl;
+      if (col < N) {
+        float t = sred[(q * WM) * BN + cl];
+#pragma unroll
+        for (int w = 1; w < WM; ++w) t += sred[(q * WM + w) * BN + cl];
+        colstats[((long)tm * 2 + q) * N + col] = t;
+      }
+    }
+  }
+
+  float* Cz = C + (long)z * slab_stride;
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int col = n0 + wn * (TN * 16) + j * 16 + (lane & 15);
+      const int rbase = m0 + wm * (TM * 16) + i * 16 + 4 * (lane >> 4);
+      if (col < N) {
+        const float bv = bias ? bias[col] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = rbase + r;
+          if (row < M) Cz[(long)row * ldc + col] = acc[i][j][r] + bv;
+        }
+      }
+    }
+  }
+}
 
 // 4 waves (WM x WN), each wave owns a (BM/WM) x (BN/WN) block built from 16x16 MFMA tiles
 // (v_mfma_f32_16x16x4_f32: A[l&15][k=l>>4], B[k=l>>4][l&15], D col=l&15,row=4*(l>>4)+reg).
@@ -142,10 +210,12 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
     const float* cur = smem + (t & 1) * STAGE;
     float* nxt = smem + ((t + 1) & 1) * STAGE;
     const bool more = (t + 1 < nt);
+#if !(defined(SP_ABLATE) && SP_ABLATE == 2)
     if (more) {
       sa.load(A, lda, m0, M, kbeg + (t + 1) * BK, kend, tid);
       sb.load(B, ldb, n0, N, kbeg + (t + 1) * BK, kend, tid);
     }
+#endif
     const float* as = cur;
     const float* bs = cur + SA::SIZE;
     // The next tile's registers are written to the idle LDS buffer in the MIDDLE of the MFMA stream:
@@ -156,10 +226,12 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
 #endif
 #pragma unroll
     for (int kk = 0; kk < BK; kk += 4) {
+#if !(defined(SP_ABLATE) && SP_ABLATE == 3)
       if (kk == SP_STORE_AT && more) {
         sa.store(nxt, tid);
         sb.store(nxt + SA::SIZE, tid);
       }
+#endif
       float a[TM], b[TN];
 #pragma unroll
       for (int i = 0; i < TM; ++i) a[i] = SA::fetch(as, arow + i * 16, kk + kq);
@@ -175,65 +247,137 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
       sa.store(nxt, tid);
       sb.store(nxt + SA::SIZE, tid);
     }
+#if !(defined(SP_ABLATE) && SP_ABLATE == 3)
     __syncthreads();
+#endif
   }
 
-  // Optional BatchNorm statistics of the output tile: per column sum and sum of squares over this
-  // workgroup's BM rows -> colstats[tm][2][N] (rows past M hold zeros and contribute nothing).
-  // Fixed reduction order: registers (i, r) -> lanes (xor 16, 32) -> waves (wm order) through LDS.
-  if (colstats) {
-    float* sred = smem;                       // [2][WM][BN], the staging buffers are idle now
+  gemm_epilogue<BM, BN, WM, WN, TM, TN>(acc, smem, C, ldc, M, N, m0, n0, tm, z, slab_stride, bias, colstats, tid, lane,
+                                        wm, wn);
+}
+
+// ------------------------------------------------------------------------------------------------
+// LDS-DMA variant (global_load_lds_dwordx4): tiles go HBM/L2 -> LDS without passing through VGPRs, so
+// the K loop carries no staging registers, no ds_write and no VALU for them; the loads of tile t+1 are in
+// flight underneath the MFMAs of tile t and are retired by the vmcnt(0) of the closing barrier.
+// A wave-instruction writes 64 x 16 B = 1 KiB of CONSECUTIVE LDS, so the image is addressed as a linear
+// sequence of 16-byte chunks: chunk c -> (row c / CPR, column 4*(c % CPR)); lanes that fall into a row's
+// padding fetch a dummy element.  No bounds handling exists in this path, therefore:
+//   * K % BK == 0 (BK = 32, or 28 for the 728-channel layers) -- checked by the host,
+//   * rows / columns past M / N are CLAMPED to the last valid one; their results are masked by the
+//     epilogue (and by the column statistics).
+// K-major rows are 36 floats apart (16-B aligned; 2-way bank conflict on the 16x2 operand fetch).
+// ------------------------------------------------------------------------------------------------
+template <int BR, int BK, int MAJ>
+struct TileDma {
+  static constexpr int WIDTH = (MAJ == SP_K_MAJOR) ? BK : BR;     // valid floats per LDS row
+  static constexpr int ROWS = (MAJ == SP_K_MAJOR) ? BR : BK;
+  static constexpr int LD = (MAJ == SP_K_MAJOR) ? 36 : (BR + 16);
+  static constexpr int CPR = LD / 4;                               // 16-byte chunks per LDS row
+  static constexpr int NCH = ROWS * CPR;
+  static constexpr int NINSTR = (NCH + 63) / 64;                   // wave-instructions per tile
+  static constexpr int SIZE = NINSTR * 256;                        // floats (whole wave-instructions)
+  static_assert(BK <= 32, "K-major rows hold at most 32 reduction steps");
+
+  static __device__ __forceinline__ void issue(float* __restrict__ S, const float* __restrict__ P, int ld,
+                                               int r0, int R, int k0, int wave, int lane) {
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
-      float sv = 0.f, qv = 0.f;
+    for (int i = 0; i < (NINSTR + 3) / 4; ++i) {
+      const int ins = wave + i * 4;                                // wave-uniform
+      if (ins < NINSTR) {
+        const int c = ins * 64 + lane;
+        const int row = c / CPR, col = (c % CPR) * 4;
+        const float* g = P;                                        // padding lanes: any valid address
+        if (col < WIDTH && row < ROWS) {
+          if (MAJ == SP_K_MAJOR) g = P + (long)min(r0 + row, R - 1) * ld + (k0 + col);
+          else g = P + (long)(k0 + row) * ld + min(r0 + col, R - 4);
+        }
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                         (__attribute__((address_space(3))) void*)(S + ins * 256), 16, 0, 0);
+      }
+    }
+  }
+  static __device__ __forceinline__ float fetch(const float* __restrict__ S, int r, int k) {
+    return (MAJ == SP_K_MAJOR) ? S[r * LD + k] : S[k * LD + r];
+  }
+};
+
+template <int BM, int BN, int BK, int WM, int WN, int AMAJ, int BMAJ>
+__global__ __launch_bounds__(256) void gemm_f32_dma_kernel(const float* __restrict__ A, int lda,
+                                                           const float* __restrict__ B, int ldb,
+                                                           float* __restrict__ C, int ldc, int M, int N,
+                                                           int K, int k_chunk, long slab_stride,
+                                                           int tiles_m, int tiles_n, int nsplit,
+                                                           const float* __restrict__ bias,
+                                                           float* __restrict__ colstats) {
+  static_assert(WM * WN == 4, "4 waves per workgroup");
+  constexpr int TM = BM / WM / 16, TN = BN / WN / 16;
+  typedef TileDma<BM, BK, AMAJ> SA;
+  typedef TileDma<BN, BK, BMAJ> SB;
+  constexpr int STAGE = SA::SIZE + SB::SIZE;
+  __shared__ __attribute__((aligned(16))) float smem[2 * STAGE];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN, wn = wave % WN;
+
+  const int nblk = tiles_m * tiles_n * nsplit;
+  int lid = xcd_remap(blockIdx.x, nblk);
+  const int tn = lid % tiles_n;
+  lid /= tiles_n;
+  const int tm = lid % tiles_m;
+  const int z = lid / tiles_m;
+
+  const int m0 = tm * BM, n0 = tn * BN;
+  const int kbeg = z * k_chunk;
+  const int kend = min(K, kbeg + k_chunk);
+  const int nt = (kend - kbeg) / BK;               // exact: K and k_chunk are multiples of BK
+
+  f32x4 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[i][j][r] = 0.f;
+
+  if (nt > 0) {
+    SA::issue(smem, A, lda, m0, M, kbeg, wave, lane);
+    SB::issue(smem + SA::SIZE, B, ldb, n0, N, kbeg, wave, lane);
+  }
+  __syncthreads();                                  // vmcnt(0) + barrier: tile 0 has landed
+
+  const int arow = wm * (TM * 16) + (lane & 15);
+  const int bcol = wn * (TN * 16) + (lane & 15);
+  const int kq = lane >> 4;
+
+  for (int t = 0; t < nt; ++t) {
+    const float* cur = smem + (t & 1) * STAGE;
+    float* nxt = smem + ((t + 1) & 1) * STAGE;
+    if (t + 1 < nt) {                               // the idle buffer was last read before the previous barrier
+      SA::issue(nxt, A, lda, m0, M, kbeg + (t + 1) * BK, wave, lane);
+      SB::issue(nxt + SA::SIZE, B, ldb, n0, N, kbeg + (t + 1) * BK, wave, lane);
+    }
+    const float* as = cur;
+    const float* bs = cur + SA::SIZE;
+#pragma unroll
+    for (int kk = 0; kk < BK; kk += 4) {
+      float a[TM], b[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) a[i] = SA::fetch(as, arow + i * 16, kk + kq);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) b[j] = SB::fetch(bs, bcol + j * 16, kk + kq);
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float v = acc[i][j][r];
-          sv += v;
-          qv = fmaf(v, v, qv);
-        }
-      sv += __shfl_xor(sv, 16, 64);
-      qv += __shfl_xor(qv, 16, 64);
-      sv += __shfl_xor(sv, 32, 64);
-      qv += __shfl_xor(qv, 32, 64);
-      if (lane < 16) {
-        const int cl = wn * (TN * 16) + j * 16 + lane;
-        sred[(0 * WM + wm) * BN + cl] = sv;
-        sred[(1 * WM + wm) * BN + cl] = qv;
-      }
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[i][j], 0, 0, 0);
     }
-    __syncthreads();
-    for (int c = tid; c < 2 * BN; c += 256) {
-      const int q = c / BN, cl = c % BN;
-      const int col = n0 + cl;
-      if (col < N) {
-        float t = sred[(q * WM) * BN + cl];
-#pragma unroll
-        for (int w = 1; w < WM; ++w) t += sred[(q * WM + w) * BN + cl];
-        colstats[((long)tm * 2 + q) * N + col] = t;
-      }
-    }
+    __syncthreads();                                // retires this wave's DMA (vmcnt(0)) and publishes it
   }
-
-  float* Cz = C + (long)z * slab_stride;
-#pragma unroll
-  for (int i = 0; i < TM; ++i) {
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-      const int col = n0 + wn * (TN * 16) + j * 16 + (lane & 15);
-      const int rbase = m0 + wm * (TM * 16) + i * 16 + 4 * (lane >> 4);
-      if (col < N) {
-        const float bv = bias ? bias[col] : 0.f;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int row = rbase + r;
-          if (row < M) Cz[(long)row * ldc + col] = acc[i][j][r] + bv;
-        }
-      }
-    }
-  }
+  gemm_epilogue<BM, BN, WM, WN, TM, TN>(acc, smem, C, ldc, M, N, m0, n0, tm, z, slab_stride, bias, colstats, tid, lane,
+                                        wm, wn);
 }
 
 // out[row*ldc + col] = sum_z ws[z*M*N + row*N + col] (+ bias[col]); N % 4 == 0, ldc % 4 == 0.
@@ -263,21 +407,27 @@ __global__ __launch_bounds__(256) void reduce_slabs_kernel(const float* __restri
 #define SP_BK 32
 #endif
 
+// bk_dma: 32 / 28 -> LDS-DMA kernel with that K tile; 0 -> register-staged kernel (any K % 4 == 0)
 template <int BM, int BN, int WM, int WN>
 static int launch_tile(const float* A, int amaj, int lda, const float* B, int bmaj, int ldb, float* C,
                        int ldc, int M, int N, int K, int nsplit, int k_chunk, long slab_stride,
-                       const float* bias, float* colstats, hipStream_t st) {
-  constexpr int BK = SP_BK;
+                       const float* bias, float* colstats, int bk_dma, hipStream_t st) {
   const int tm = spnet_cdiv(M, BM), tn = spnet_cdiv(N, BN);
   dim3 grid(tm * tn * nsplit), block(256);
-#define SP_LAUNCH(AM, BMJ)                                                                          \
-  hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, BK, WM, WN, AM, BMJ>), grid, block, 0, st, A, lda, B, \
-                     ldb, C, ldc, M, N, K, k_chunk, slab_stride, tm, tn, nsplit, bias, colstats)
-  if (amaj == SP_K_MAJOR && bmaj == SP_OUT_MAJOR) SP_LAUNCH(SP_K_MAJOR, SP_OUT_MAJOR);
-  else if (amaj == SP_K_MAJOR && bmaj == SP_K_MAJOR) SP_LAUNCH(SP_K_MAJOR, SP_K_MAJOR);
-  else if (amaj == SP_OUT_MAJOR && bmaj == SP_OUT_MAJOR) SP_LAUNCH(SP_OUT_MAJOR, SP_OUT_MAJOR);
-  else return (int)hipErrorInvalidValue;
+#define SP_ARGS A, lda, B, ldb, C, ldc, M, N, K, k_chunk, slab_stride, tm, tn, nsplit, bias, colstats
+#define SP_LAUNCH(KERNEL, BKV, AM, BMJ) \
+  hipLaunchKernelGGL((KERNEL<BM, BN, BKV, WM, WN, AM, BMJ>), grid, block, 0, st, SP_ARGS)
+#define SP_FORMS(KERNEL, BKV)                                                                             \
+  if (amaj == SP_K_MAJOR && bmaj == SP_OUT_MAJOR) SP_LAUNCH(KERNEL, BKV, SP_K_MAJOR, SP_OUT_MAJOR);       \
+  else if (amaj == SP_K_MAJOR && bmaj == SP_K_MAJOR) SP_LAUNCH(KERNEL, BKV, SP_K_MAJOR, SP_K_MAJOR);      \
+  else if (amaj == SP_OUT_MAJOR && bmaj == SP_OUT_MAJOR) SP_LAUNCH(KERNEL, BKV, SP_OUT_MAJOR, SP_OUT_MAJOR); \
+  else return (int)hipErrorInvalidValue
+  if (bk_dma == 32) { SP_FORMS(gemm_f32_dma_kernel, 32); }
+  else if (bk_dma == 28) { SP_FORMS(gemm_f32_dma_kernel, 28); }
+  else { SP_FORMS(gemm_f32_kernel, SP_BK); }
+#undef SP_FORMS
 #undef SP_LAUNCH
+#undef SP_ARGS
   return 0;
 }
 
@@ -344,7 +494,17 @@ static int gemm_impl(const float* A, int a_major, int lda, const float* B, int b
   const int BK = SP_BK;
   int nsplit = split_k;
   if (nsplit <= 0) nsplit = auto_split(tiles, M, N, K, workspace != nullptr, ws_floats);
-  int k_chunk = ((K + nsplit - 1) / nsplit + BK - 1) / BK * BK;
+  // LDS-DMA path: needs K to be a whole number of K tiles (no bounds handling) and >= 4 rows/columns to
+  // clamp to; otherwise the register-staged kernel (any K % 4 == 0) is used.
+  int bk_dma = 0;
+#ifndef SP_NO_DMA
+  if (M >= 4 && N >= 4 && tile != 4) {
+    if (K % 32 == 0) bk_dma = 32;
+    else if (K % 28 == 0) bk_dma = 28;
+  }
+#endif
+  const int bkt = bk_dma ? bk_dma : BK;
+  int k_chunk = ((K + nsplit - 1) / nsplit + bkt - 1) / bkt * bkt;
   nsplit = (K + k_chunk - 1) / k_chunk;
   float* out = C;
   int out_ld = ldc;
@@ -361,11 +521,11 @@ static int gemm_impl(const float* A, int a_major, int lda, const float* B, int b
   if (stat_rows) *stat_rows = spnet_cdiv(M, bm);
   int rc;
   switch (tile) {
-    case 1: rc = launch_tile<128, 128, 2, 2>(A, a_major, lda, B, b_major, ldb, out, out_ld, M, N, K, nsplit, k_chunk, slab, kbias, colstats, st); break;
-    case 2: rc = launch_tile<128, 64, 2, 2>(A, a_major, lda, B, b_major, ldb, out, out_ld, M, N, K, nsplit, k_chunk, slab, kbias, colstats, st); break;
-    case 3: rc = launch_tile<64, 64, 2, 2>(A, a_major, lda, B, b_major, ldb, out, out_ld, M, N, K, nsplit, k_chunk, slab, kbias, colstats, st); break;
-    case 5: rc = launch_tile<96, 96, 2, 2>(A, a_major, lda, B, b_major, ldb, out, out_ld, M, N, K, nsplit, k_chunk, slab, kbias, colstats, st); break;
-    default: rc = launch_tile<32, 128, 1, 4>(A, a_major, lda, B, b_major, ldb, out, out_ld, M, N, K, nsplit, k_chunk, slab, kbias, colstats, st); break;
+    case 1: rc = launch_tile<128, 128, 2, 2>(A, a_major, lda, B, b_major, ldb, out, out_ld, M, N, K, nsplit, k_chunk, slab, kbias, colstats, bk_dma, st); break;
+    case 2: rc = launch_tile<128, 64, 2, 2>(A, a_major, lda, B, b_major, ldb, out, out_ld, M, N, K, nsplit, k_chunk, slab, kbias, colstats, bk_dma, st); break;
+    case 3: rc = launch_tile<64, 64, 2, 2>(A, a_major, lda, B, b_major, ldb, out, out_ld, M, N, K, nsplit, k_chunk, slab, kbias, colstats, bk_dma, st); break;
+    case 5: rc = launch_tile<96, 96, 2, 2>(A, a_major, lda, B, b_major, ldb, out, out_ld, M, N, K, nsplit, k_chunk, slab, kbias, colstats, bk_dma, st); break;
+    default: rc = launch_tile<32, 128, 1, 4>(A, a_major, lda, B, b_major, ldb, out, out_ld, M, N, K, nsplit, k_chunk, slab, kbias, colstats, bk_dma, st); break;
   }
   if (rc) return rc;
   if (nsplit > 1) {
