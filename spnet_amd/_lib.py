@@ -15,6 +15,10 @@ if not os.path.exists(LIB_PATH):
         "spnet_amd: %s is missing -- build it with `python -c 'import __graft_entry__ as g; g.build()'` "
         "or `make -C spnet_amd/csrc` (hipcc, gfx950).  There is no CPU fallback." % LIB_PATH)
 
+# torch first: libspnet_hip.so must bind to the SAME HIP runtime (libamdhip64) that torch has loaded, or
+# the two runtimes would not share devices / streams (kernels then fail with hipErrorNoDevice).
+import torch  # noqa: E402,F401
+
 _lib = ctypes.CDLL(LIB_PATH)
 
 P = c_void_p  # device pointers travel as integers
