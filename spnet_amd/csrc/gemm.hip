@@ -11,30 +11,70 @@
 //      OUT_MAJOR : A(m,k) = A[k*lda + m]      (wgrad: A = X^T, read without a transpose pass)
 //   B  OUT_MAJOR : B(k,n) = B[k*ldb + n]      (weights [Cin][Cout]: forward; dY in wgrad)
 //      K_MAJOR   : B(k,n) = B[n*ldb + k]      (dgrad: B = W^T read in place)
-// Each operand's LDS image keeps its own major (see TileStage): operand fetches are conflict-free
-// ds_read_b32 and no staging pass transposes.
+// Each operand's LDS image keeps its own major (see TileStage): no staging pass transposes, and operand
+// fetches are conflict-free wide ds_reads (one read feeds up to four MFMAs).
 //
 // Split-K: grid.z slices write fp32 slabs to a workspace, a second kernel sums them in slice order
 // (deterministic; no float atomics).
 #include "common.h"
+#include <type_traits>
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 enum { SP_K_MAJOR = 0, SP_OUT_MAJOR = 1 };
 
-// One operand tile (BR output rows/cols x BK reduction steps) staged global -> registers -> LDS.
-// The LDS image keeps the operand's own major, so no staging pass transposes anything:
-//   K_MAJOR   image [r][k], leading dim BK+2 : the 16 rows x 2 k of a 32-lane fetch group land on
-//             banks (2r + k) % 32, all distinct; rows are 8-byte aligned -> two ds_write_b64 per float4
-//   OUT_MAJOR image [k][r], leading dim BR+16: 16 consecutive r per k, the next k 16 banks further
-template <int BR, int BK, int MAJ>
+// One operand tile (BR output rows/cols x BK reduction steps) staged global -> registers -> LDS, and the
+// wave's MFMA operand fetches from it.  T = number of 16-wide MFMA tiles one wave owns along this operand.
+// The LDS image keeps the operand's own major, so no staging pass transposes anything, and every operand
+// fetch is a wide ds_read that feeds several MFMAs:
+//
+//   v_mfma_f32_16x16x4_f32 takes, in lane l, A[row l&15][k = l>>4] and B[k = l>>4][col l&15].  Which k a
+//   lane group j = l>>4 supplies is free as long as A and B agree, and so is which output row/column the
+//   16 lane positions of a tile stand for.  Within a chunk of 16 reduction steps, MFMA q (0..3) uses
+//   k = 4j + q:
+//     K_MAJOR   image [r][k], leading dim BK+8: lane (p = l&15, j) reads ONE float4 at [r0 + 16t + p][4j..4j+3]
+//               = its operand for the 4 MFMAs of tile t (ds_read_b128, conflict-free for LD = 40).
+//     OUT_MAJOR image [k][r]: lane (p, j) reads VW consecutive r at row k = 4j + q = its operand for MFMA q of
+//               VW tiles at once; tile t = g*VW + u covers output index g*16*VW + VW*p + u (pos()), so a lane
+//               ends up with VW CONSECUTIVE output columns and the epilogue stores them as one vector.
+//               VW = 4 / 2 / 1 for T % 4 == 0 / T % 2 == 0 / odd T; the leading dim is chosen so that the
+//               two k rows (4 apart) met inside one LDS lane group fall on disjoint banks.
+template <int BR, int BK, int MAJ, int T>
 struct TileStage {
   static constexpr int TOTAL = BR * BK / 4;            // float4 per tile
   static constexpr int NV = (TOTAL + 255) / 256;       // float4 per thread
-  static constexpr int LD = (MAJ == SP_K_MAJOR) ? (BK + 2) : (BR + 16);
+  static constexpr int VW = (MAJ == SP_K_MAJOR) ? 1 : ((T % 4 == 0) ? 4 : ((T % 2 == 0) ? 2 : 1));
+  static constexpr int LD = (MAJ == SP_K_MAJOR) ? (BK + 8) : (VW == 4 ? BR : (VW == 2 ? BR + 8 : BR + 4));
   static constexpr int SIZE = (MAJ == SP_K_MAJOR) ? BR * LD : BK * LD;
+  static_assert(BR % 16 == 0 && BK % 16 == 0, "tile shape");
   float4 v[NV];
+  unsigned off[NV];     // element offset of this thread's float4 slots at k0 = 0, rows clamped into range
 
+  // Loop-invariant part of the addresses.  Rows/cols past R are clamped to the last valid one: what they
+  // produce only reaches output rows/cols >= R, which the epilogue never stores or counts.
+  __device__ __forceinline__ void init(int ld, int r0, int R, int tid) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int f = tid + i * 256;
+      if (MAJ == SP_OUT_MAJOR) {
+        const int k = f / (BR / 4), r4 = f % (BR / 4);
+        off[i] = (unsigned)(k * ld + min(r0 + r4 * 4, R - 4));
+      } else {
+        const int r = f / (BK / 4), kq = f % (BK / 4);
+        off[i] = (unsigned)(min(r0 + r, R - 1) * ld + kq * 4);
+      }
+    }
+  }
+
+  // A K tile that lies completely below kend: no predicates, no branches (Pk = operand advanced to k0).
+  __device__ __forceinline__ void load_full(const float* __restrict__ Pk) {
+    static_assert(TOTAL % 256 == 0, "whole float4 slots per thread");
+#pragma unroll
+    for (int i = 0; i < NV; ++i) v[i] = *reinterpret_cast<const float4*>(Pk + off[i]);
+  }
+  static __device__ __forceinline__ long kstep(int ld) { return (MAJ == SP_K_MAJOR) ? (long)BK : (long)BK * ld; }
+
+  // Any K tile: elements past kend / past R read as zero.
   __device__ __forceinline__ void load(const float* __restrict__ P, int ld, int r0, int R, int k0,
                                        int kend, int tid) {
 #pragma unroll
@@ -66,32 +106,61 @@ struct TileStage {
           *reinterpret_cast<float4*>(S + k * LD + r4 * 4) = v[i];
         } else {
           const int r = f / (BK / 4), kq = f % (BK / 4);
-          float2* s = reinterpret_cast<float2*>(S + r * LD + kq * 4);
-          s[0] = make_float2(v[i].x, v[i].y);
-          s[1] = make_float2(v[i].z, v[i].w);
+          *reinterpret_cast<float4*>(S + r * LD + kq * 4) = v[i];
         }
       }
     }
   }
 
-  // element (row r of the tile, reduction index k of the tile)
-  static __device__ __forceinline__ float fetch(const float* __restrict__ S, int r, int k) {
-#if defined(SP_ABLATE) && SP_ABLATE == 1
-    return (float)(r + k) * 1e-3f;     // ablation build: no LDS operand reads
-#else
-    return (MAJ == SP_K_MAJOR) ? S[r * LD + k] : S[k * LD + r];
-#endif
+  // Operand registers of one 16-step chunk (chunk c of the K tile): f[t][q] feeds MFMA q of tile t.
+  // w0 = first row/col of this wave inside the tile.
+  static __device__ __forceinline__ void frags(const float* __restrict__ S, int w0, int lane, int c,
+                                               float (&f)[T][4]) {
+    const int p = lane & 15, j = lane >> 4;
+    if (MAJ == SP_K_MAJOR) {
+#pragma unroll
+      for (int t = 0; t < T; ++t) {
+        const float4 x = *reinterpret_cast<const float4*>(S + (w0 + t * 16 + p) * LD + c * 16 + j * 4);
+        f[t][0] = x.x; f[t][1] = x.y; f[t][2] = x.z; f[t][3] = x.w;
+      }
+    } else {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float* row = S + (c * 16 + j * 4 + q) * LD + w0 + VW * p;
+#pragma unroll
+        for (int g = 0; g < T / VW; ++g) {
+          if (VW == 4) {
+            const float4 x = *reinterpret_cast<const float4*>(row + g * 64);
+            f[g * VW + 0][q] = x.x; f[g * VW + 1 < T ? g * VW + 1 : 0][q] = x.y;
+            f[g * VW + 2 < T ? g * VW + 2 : 0][q] = x.z; f[g * VW + 3 < T ? g * VW + 3 : 0][q] = x.w;
+          } else if (VW == 2) {
+            const float2 x = *reinterpret_cast<const float2*>(row + g * 32);
+            f[g * VW + 0][q] = x.x; f[g * VW + 1 < T ? g * VW + 1 : 0][q] = x.y;
+          } else {
+            f[g][q] = row[g * 16];
+          }
+        }
+      }
+    }
+  }
+
+  // output index (inside the wave's T*16 rows/cols) that lane position p of MFMA tile t stands for
+  static __device__ __forceinline__ int pos(int t, int p) {
+    return (MAJ == SP_K_MAJOR) ? t * 16 + p : (t / VW) * (16 * VW) + VW * p + (t % VW);
   }
 };
 
-template <int BM, int BN, int WM, int WN, int TM, int TN>
+// Writes the accumulators (+bias) to C / the split-K slab and, optionally, BatchNorm statistics of the
+// output tile: per column sum and sum of squares over this workgroup's BM rows -> colstats[tm][2][N]
+// (rows past M hold zeros and contribute nothing).  Fixed reduction order: registers (i, r) -> lanes
+// (xor 16, 32) -> waves (wm order) through LDS.
+template <class SA, class SB, int BM, int BN, int WM, int WN, int TM, int TN>
 __device__ __forceinline__ void gemm_epilogue(f32x4 (&acc)[TM][TN], float* __restrict__ smem,
                                               float* __restrict__ C, int ldc, int M, int N, int m0, int n0,
                                               int tm, int z, long slab_stride, const float* __restrict__ bias,
                                               float* __restrict__ colstats, int tid, int lane, int wm, int wn) {
-  // Optional BatchNorm statistics of the output tile: per column sum and sum of squares over this
-  // workgroup's BM rows -> colstats[tm][2][N] (rows past M hold zeros and contribute nothing).
-  // Fixed reduction order: registers (i, r) -> lanes (xor 16, 32) -> waves (wm order) through LDS.
+  const int p = lane & 15, jq = lane >> 4;
+  const int mw = m0 + wm * (TM * 16), nw = n0 + wn * (TN * 16);
   if (colstats) {
     float* sred = smem;                       // [2][WM][BN], the staging buffers are idle now
 #pragma unroll
@@ -101,7 +170,7 @@ __device__ __forceinline__ void gemm_epilogue(f32x4 (&acc)[TM][TN], float* __res
       for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const int row = m0 + wm * (TM * 16) + i * 16 + 4 * (lane >> 4) + r;
+          const int row = mw + SA::pos(i, 4 * jq + r);
           const float v = row < M ? acc[i][j][r] : 0.f;
           sv += v;
           qv = fmaf(v, v, qv);
@@ -111,7 +180,7 @@ __device__ __forceinline__ void gemm_epilogue(f32x4 (&acc)[TM][TN], float* __res
       sv += __shfl_xor(sv, 32, 64);
       qv += __shfl_xor(qv, 32, 64);
       if (lane < 16) {
-        const int cl = wn * (TN * 16) + j * 16 + lane;
+        const int cl = wn * (TN * 16) + SB::pos(j, p);
         sred[(0 * WM + wm) * BN + cl] = sv;
         sred[(1 * WM + wm) * BN + cl] = qv;
       }
@@ -130,18 +199,35 @@ __device__ __forceinline__ void gemm_epilogue(f32x4 (&acc)[TM][TN], float* __res
   }
 
   float* Cz = C + (long)z * slab_stride;
+  constexpr int VW = SB::VW;                 // consecutive columns held by one lane (N % 4 == 0, ldc % 4 == 0)
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
-      const int col = n0 + wn * (TN * 16) + j * 16 + (lane & 15);
-      const int rbase = m0 + wm * (TM * 16) + i * 16 + 4 * (lane >> 4);
-      if (col < N) {
-        const float bv = bias ? bias[col] : 0.f;
+    for (int r = 0; r < 4; ++r) {
+      const int row = mw + SA::pos(i, 4 * jq + r);
+      if (row < M) {
+        float* crow = Cz + (long)row * ldc;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int row = rbase + r;
-          if (row < M) Cz[(long)row * ldc + col] = acc[i][j][r] + bv;
+        for (int g = 0; g < TN / VW; ++g) {
+          const int col = nw + SB::pos(g * VW, p);
+          if (col < N) {                     // VW | 4 | N and col % VW == 0: the whole vector is inside
+            if (VW == 4) {
+              float4 o = make_float4(acc[i][g * VW][r], acc[i][g * VW + 1 < TN ? g * VW + 1 : 0][r],
+                                     acc[i][g * VW + 2 < TN ? g * VW + 2 : 0][r],
+                                     acc[i][g * VW + 3 < TN ? g * VW + 3 : 0][r]);
+              if (bias) {
+                const float4 b = *reinterpret_cast<const float4*>(bias + col);
+                o.x += b.x; o.y += b.y; o.z += b.z; o.w += b.w;
+              }
+              *reinterpret_cast<float4*>(crow + col) = o;
+            } else if (VW == 2) {
+              float2 o = make_float2(acc[i][g * VW][r], acc[i][g * VW + 1 < TN ? g * VW + 1 : 0][r]);
+              if (bias) { o.x += bias[col]; o.y += bias[col + 1]; }
+              *reinterpret_cast<float2*>(crow + col) = o;
+            } else {
+              crow[col] = acc[i][g][r] + (bias ? bias[col] : 0.f);
+            }
+          }
         }
       }
     }
@@ -149,9 +235,11 @@ __device__ __forceinline__ void gemm_epilogue(f32x4 (&acc)[TM][TN], float* __res
 }
 
 // 4 waves (WM x WN), each wave owns a (BM/WM) x (BN/WN) block built from 16x16 MFMA tiles
-// (v_mfma_f32_16x16x4_f32: A[l&15][k=l>>4], B[k=l>>4][l&15], D col=l&15,row=4*(l>>4)+reg).
+// (v_mfma_f32_16x16x4_f32: D col = l&15, row = 4*(l>>4)+reg).  Tile t+1 travels global -> registers while
+// tile t is multiplied, and is written to the idle LDS buffer in the MIDDLE of the MFMA stream (nobody
+// reads that buffer during this iteration), so one barrier per K tile suffices.
 template <int BM, int BN, int BK, int WM, int WN, int AMAJ, int BMAJ>
-__global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__ A, int lda,
+__global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const float* __restrict__ A, int lda,
                                                        const float* __restrict__ B, int ldb,
                                                        float* __restrict__ C, int ldc, int M, int N,
                                                        int K, int k_chunk, long slab_stride,
@@ -161,9 +249,10 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
   static_assert(WM * WN == 4, "4 waves per workgroup");
   constexpr int TM = BM / WM / 16, TN = BN / WN / 16;
   static_assert(TM >= 1 && TN >= 1 && (BM % (WM * 16)) == 0 && (BN % (WN * 16)) == 0, "wave tile");
-  typedef TileStage<BM, BK, AMAJ> SA;
-  typedef TileStage<BN, BK, BMAJ> SB;
+  typedef TileStage<BM, BK, AMAJ, TM> SA;
+  typedef TileStage<BN, BK, BMAJ, TN> SB;
   constexpr int STAGE = SA::SIZE + SB::SIZE;
+  constexpr int NCH = BK / 16;
   __shared__ __attribute__((aligned(16))) float smem[2 * STAGE];
 
   const int tid = threadIdx.x;
@@ -191,193 +280,84 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
 #pragma unroll
       for (int r = 0; r < 4; ++r) acc[i][j][r] = 0.f;
 
-  SA sa;
-  SB sb;
+  // Two register stages: while tile t is multiplied, tile t+1 waits in one stage (it is written to the
+  // idle LDS buffer in the middle of the MFMA stream) and tile t+2 is already being fetched into the
+  // other, so a global load has one and a half K tiles of MFMA time to arrive.
+  SA sa[2];
+  SB sb[2];
+  sa[0].init(lda, m0, M, tid);
+  sb[0].init(ldb, n0, N, tid);
+#pragma unroll
+  for (int i = 0; i < SA::NV; ++i) sa[1].off[i] = sa[0].off[i];
+#pragma unroll
+  for (int i = 0; i < SB::NV; ++i) sb[1].off[i] = sb[0].off[i];
 
   if (nt > 0) {
-    sa.load(A, lda, m0, M, kbeg, kend, tid);
-    sb.load(B, ldb, n0, N, kbeg, kend, tid);
-    sa.store(smem, tid);
-    sb.store(smem + SA::SIZE, tid);
+    sa[0].load(A, lda, m0, M, kbeg, kend, tid);
+    sb[0].load(B, ldb, n0, N, kbeg, kend, tid);
+    if (nt > 1) {
+      sa[1].load(A, lda, m0, M, kbeg + BK, kend, tid);
+      sb[1].load(B, ldb, n0, N, kbeg + BK, kend, tid);
+    }
+    sa[0].store(smem, tid);
+    sb[0].store(smem + SA::SIZE, tid);
   }
   __syncthreads();
 
-  const int arow = wm * (TM * 16) + (lane & 15);
-  const int bcol = wn * (TN * 16) + (lane & 15);
-  const int kq = lane >> 4;
-
-  for (int t = 0; t < nt; ++t) {
-    const float* cur = smem + (t & 1) * STAGE;
-    float* nxt = smem + ((t + 1) & 1) * STAGE;
-    const bool more = (t + 1 < nt);
-#if !(defined(SP_ABLATE) && SP_ABLATE == 2)
-    if (more) {
-      sa.load(A, lda, m0, M, kbeg + (t + 1) * BK, kend, tid);
-      sb.load(B, ldb, n0, N, kbeg + (t + 1) * BK, kend, tid);
+  // PAR = t & 1: tile t sits in LDS buffer PAR, tile t+1 in register stage 1-PAR, stage PAR is free.
+  // FULL: tile t+2 exists and lies completely below kend -> its fetch is branch-free, the whole step is one
+  // basic block and the compiler interleaves loads, LDS writes and MFMAs.
+  const float* Ak = A + (AMAJ == SP_K_MAJOR ? (long)kbeg : (long)kbeg * lda) + 2 * SA::kstep(lda);
+  const float* Bk = B + (BMAJ == SP_K_MAJOR ? (long)kbeg : (long)kbeg * ldb) + 2 * SB::kstep(ldb);
+  auto step = [&](auto par, auto full, int t) {
+    constexpr int PAR = decltype(par)::value;
+    constexpr bool FULL = decltype(full)::value;
+    const float* cur = smem + PAR * STAGE;
+    float* nxt = smem + (1 - PAR) * STAGE;
+    const bool more = FULL || (t + 1 < nt);
+    if (FULL) {
+      sa[PAR].load_full(Ak);
+      sb[PAR].load_full(Bk);
+      Ak += SA::kstep(lda);
+      Bk += SB::kstep(ldb);
+    } else if (t + 2 < nt) {
+      sa[PAR].load(A, lda, m0, M, kbeg + (t + 2) * BK, kend, tid);
+      sb[PAR].load(B, ldb, n0, N, kbeg + (t + 2) * BK, kend, tid);
     }
-#endif
-    const float* as = cur;
-    const float* bs = cur + SA::SIZE;
-    // The next tile's registers are written to the idle LDS buffer in the MIDDLE of the MFMA stream:
-    // nobody reads that buffer during this iteration, so its ds_write latency (and the vmcnt wait in
-    // front of it) hides under the second half of the MFMAs instead of sitting in front of the barrier.
-#ifndef SP_STORE_AT
-#define SP_STORE_AT (BK / 2)
-#endif
 #pragma unroll
-    for (int kk = 0; kk < BK; kk += 4) {
-#if !(defined(SP_ABLATE) && SP_ABLATE == 3)
-      if (kk == SP_STORE_AT && more) {
-        sa.store(nxt, tid);
-        sb.store(nxt + SA::SIZE, tid);
+    for (int c = 0; c < NCH; ++c) {
+      if (c == NCH / 2 && more) {
+        sa[1 - PAR].store(nxt, tid);
+        sb[1 - PAR].store(nxt + SA::SIZE, tid);
       }
-#endif
-      float a[TM], b[TN];
+      float a[TM][4], b[TN][4];
+      SA::frags(cur, wm * (TM * 16), lane, c, a);
+      SB::frags(cur + SA::SIZE, wn * (TN * 16), lane, c, b);
 #pragma unroll
-      for (int i = 0; i < TM; ++i) a[i] = SA::fetch(as, arow + i * 16, kk + kq);
+      for (int q = 0; q < 4; ++q)
 #pragma unroll
-      for (int j = 0; j < TN; ++j) b[j] = SB::fetch(bs, bcol + j * 16, kk + kq);
+        for (int i = 0; i < TM; ++i)
 #pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[i][j], 0, 0, 0);
+          for (int j = 0; j < TN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i][q], b[j][q], acc[i][j], 0, 0, 0);
     }
-    if (SP_STORE_AT >= BK && more) {
-      sa.store(nxt, tid);
-      sb.store(nxt + SA::SIZE, tid);
-    }
-#if !(defined(SP_ABLATE) && SP_ABLATE == 3)
     __syncthreads();
-#endif
+  };
+  typedef std::integral_constant<int, 0> P0;
+  typedef std::integral_constant<int, 1> P1;
+  const int nfull = (kend - kbeg) / BK;            // complete K tiles of this slice
+  int t = 0;
+  for (; t + 3 < nfull; t += 2) {                  // tiles t+2 and t+3 are complete
+    step(P0(), std::true_type(), t);
+    step(P1(), std::true_type(), t + 1);
+  }
+  for (; t < nt; t += 2) {
+    step(P0(), std::false_type(), t);
+    if (t + 1 < nt) step(P1(), std::false_type(), t + 1);
   }
 
-  gemm_epilogue<BM, BN, WM, WN, TM, TN>(acc, smem, C, ldc, M, N, m0, n0, tm, z, slab_stride, bias, colstats, tid, lane,
-                                        wm, wn);
-}
-
-// ------------------------------------------------------------------------------------------------
-// LDS-DMA variant (global_load_lds_dwordx4): tiles go HBM/L2 -> LDS without passing through VGPRs, so
-// the K loop carries no staging registers, no ds_write and no VALU for them; the loads of tile t+1 are in
-// flight underneath the MFMAs of tile t and are retired by the vmcnt(0) of the closing barrier.
-// A wave-instruction writes 64 x 16 B = 1 KiB of CONSECUTIVE LDS, so the image is addressed as a linear
-// sequence of 16-byte chunks: chunk c -> (row c / CPR, column 4*(c % CPR)); lanes that fall into a row's
-// padding fetch a dummy element.  No bounds handling exists in this path, therefore:
-//   * K % BK == 0 (BK = 32, or 28 for the 728-channel layers) -- checked by the host,
-//   * rows / columns past M / N are CLAMPED to the last valid one; their results are masked by the
-//     epilogue (and by the column statistics).
-// K-major rows are 36 floats apart (16-B aligned; 2-way bank conflict on the 16x2 operand fetch).
-// ------------------------------------------------------------------------------------------------
-template <int BR, int BK, int MAJ>
-struct TileDma {
-  static constexpr int WIDTH = (MAJ == SP_K_MAJOR) ? BK : BR;     // valid floats per LDS row
-  static constexpr int ROWS = (MAJ == SP_K_MAJOR) ? BR : BK;
-  static constexpr int LD = (MAJ == SP_K_MAJOR) ? 36 : (BR + 16);
-  static constexpr int CPR = LD / 4;                               // 16-byte chunks per LDS row
-  static constexpr int NCH = ROWS * CPR;
-  static constexpr int NINSTR = (NCH + 63) / 64;                   // wave-instructions per tile
-  static constexpr int SIZE = NINSTR * 256;                        // floats (whole wave-instructions)
-  static_assert(BK <= 32, "K-major rows hold at most 32 reduction steps");
-
-  static __device__ __forceinline__ void issue(float* __restrict__ S, const float* __restrict__ P, int ld,
-                                               int r0, int R, int k0, int wave, int lane) {
-#pragma unroll
-    for (int i = 0; i < (NINSTR + 3) / 4; ++i) {
-      const int ins = wave + i * 4;                                // wave-uniform
-      if (ins < NINSTR) {
-        const int c = ins * 64 + lane;
-        const int row = c / CPR, col = (c % CPR) * 4;
-        const float* g = P;                                        // padding lanes: any valid address
-        if (col < WIDTH && row < ROWS) {
-          if (MAJ == SP_K_MAJOR) g = P + (long)min(r0 + row, R - 1) * ld + (k0 + col);
-          else g = P + (long)(k0 + row) * ld + min(r0 + col, R - 4);
-        }
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
-                                         (__attribute__((address_space(3))) void*)(S + ins * 256), 16, 0, 0);
-      }
-    }
-  }
-  static __device__ __forceinline__ float fetch(const float* __restrict__ S, int r, int k) {
-    return (MAJ == SP_K_MAJOR) ? S[r * LD + k] : S[k * LD + r];
-  }
-};
-
-template <int BM, int BN, int BK, int WM, int WN, int AMAJ, int BMAJ>
-__global__ __launch_bounds__(256) void gemm_f32_dma_kernel(const float* __restrict__ A, int lda,
-                                                           const float* __restrict__ B, int ldb,
-                                                           float* __restrict__ C, int ldc, int M, int N,
-                                                           int K, int k_chunk, long slab_stride,
-                                                           int tiles_m, int tiles_n, int nsplit,
-                                                           const float* __restrict__ bias,
-                                                           float* __restrict__ colstats) {
-  static_assert(WM * WN == 4, "4 waves per workgroup");
-  constexpr int TM = BM / WM / 16, TN = BN / WN / 16;
-  typedef TileDma<BM, BK, AMAJ> SA;
-  typedef TileDma<BN, BK, BMAJ> SB;
-  constexpr int STAGE = SA::SIZE + SB::SIZE;
-  __shared__ __attribute__((aligned(16))) float smem[2 * STAGE];
-
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave / WN, wn = wave % WN;
-
-  const int nblk = tiles_m * tiles_n * nsplit;
-  int lid = xcd_remap(blockIdx.x, nblk);
-  const int tn = lid % tiles_n;
-  lid /= tiles_n;
-  const int tm = lid % tiles_m;
-  const int z = lid / tiles_m;
-
-  const int m0 = tm * BM, n0 = tn * BN;
-  const int kbeg = z * k_chunk;
-  const int kend = min(K, kbeg + k_chunk);
-  const int nt = (kend - kbeg) / BK;               // exact: K and k_chunk are multiples of BK
-
-  f32x4 acc[TM][TN];
-#pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int j = 0; j < TN; ++j)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) acc[i][j][r] = 0.f;
-
-  if (nt > 0) {
-    SA::issue(smem, A, lda, m0, M, kbeg, wave, lane);
-    SB::issue(smem + SA::SIZE, B, ldb, n0, N, kbeg, wave, lane);
-  }
-  __syncthreads();                                  // vmcnt(0) + barrier: tile 0 has landed
-
-  const int arow = wm * (TM * 16) + (lane & 15);
-  const int bcol = wn * (TN * 16) + (lane & 15);
-  const int kq = lane >> 4;
-
-  for (int t = 0; t < nt; ++t) {
-    const float* cur = smem + (t & 1) * STAGE;
-    float* nxt = smem + ((t + 1) & 1) * STAGE;
-    if (t + 1 < nt) {                               // the idle buffer was last read before the previous barrier
-      SA::issue(nxt, A, lda, m0, M, kbeg + (t + 1) * BK, wave, lane);
-      SB::issue(nxt + SA::SIZE, B, ldb, n0, N, kbeg + (t + 1) * BK, wave, lane);
-    }
-    const float* as = cur;
-    const float* bs = cur + SA::SIZE;
-#pragma unroll
-    for (int kk = 0; kk < BK; kk += 4) {
-      float a[TM], b[TN];
-#pragma unroll
-      for (int i = 0; i < TM; ++i) a[i] = SA::fetch(as, arow + i * 16, kk + kq);
-#pragma unroll
-      for (int j = 0; j < TN; ++j) b[j] = SB::fetch(bs, bcol + j * 16, kk + kq);
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[i][j], 0, 0, 0);
-    }
-    __syncthreads();                                // retires this wave's DMA (vmcnt(0)) and publishes it
-  }
-  gemm_epilogue<BM, BN, WM, WN, TM, TN>(acc, smem, C, ldc, M, N, m0, n0, tm, z, slab_stride, bias, colstats, tid, lane,
-                                        wm, wn);
+  gemm_epilogue<SA, SB, BM, BN, WM, WN, TM, TN>(acc, smem, C, ldc, M, N, m0, n0, tm, z, slab_stride, bias, colstats,
+                                                tid, lane, wm, wn);
 }
 
 // out[row*ldc + col] = sum_z ws[z*M*N + row*N + col] (+ bias[col]); N % 4 == 0, ldc % 4 == 0.
@@ -407,11 +387,10 @@ __global__ __launch_bounds__(256) void reduce_slabs_kernel(const float* __restri
 #define SP_BK 32
 #endif
 
-// bk_dma: 32 / 28 -> LDS-DMA kernel with that K tile; 0 -> register-staged kernel (any K % 4 == 0)
 template <int BM, int BN, int WM, int WN>
 static int launch_tile(const float* A, int amaj, int lda, const float* B, int bmaj, int ldb, float* C,
                        int ldc, int M, int N, int K, int nsplit, int k_chunk, long slab_stride,
-                       const float* bias, float* colstats, int bk_dma, hipStream_t st) {
+                       const float* bias, float* colstats, hipStream_t st) {
   const int tm = spnet_cdiv(M, BM), tn = spnet_cdiv(N, BN);
   dim3 grid(tm * tn * nsplit), block(256);
 #define SP_ARGS A, lda, B, ldb, C, ldc, M, N, K, k_chunk, slab_stride, tm, tn, nsplit, bias, colstats
@@ -422,23 +401,24 @@ static int launch_tile(const float* A, int amaj, int lda, const float* B, int bm
   else if (amaj == SP_K_MAJOR && bmaj == SP_K_MAJOR) SP_LAUNCH(KERNEL, BKV, SP_K_MAJOR, SP_K_MAJOR);      \
   else if (amaj == SP_OUT_MAJOR && bmaj == SP_OUT_MAJOR) SP_LAUNCH(KERNEL, BKV, SP_OUT_MAJOR, SP_OUT_MAJOR); \
   else return (int)hipErrorInvalidValue
-  if (bk_dma == 32) { SP_FORMS(gemm_f32_dma_kernel, 32); }
-  else if (bk_dma == 28) { SP_FORMS(gemm_f32_dma_kernel, 28); }
-  else { SP_FORMS(gemm_f32_kernel, SP_BK); }
+  SP_FORMS(gemm_f32_kernel, SP_BK);
 #undef SP_FORMS
 #undef SP_LAUNCH
 #undef SP_ARGS
   return 0;
 }
 
-// Tile ids: 0 = auto, 1 = 128x128, 2 = 128x64, 3 = 64x64, 4 = 32x128, 5 = 96x96
-#define SP_NTILES 5
+// Tile ids: 0 = auto, 1 = 128x128, 2 = 128x64, 3 = 64x64, 4 = 32x128, 5 = 96x96, 6 = 96x64, 7 = 64x128, 8 = 128x96
+#define SP_NTILES 8
 static void tile_dims(int tile, int* bm, int* bn) {
   switch (tile) {
     case 1: *bm = 128; *bn = 128; break;
     case 2: *bm = 128; *bn = 64; break;
     case 3: *bm = 64; *bn = 64; break;
     case 5: *bm = 96; *bn = 96; break;
+    case 6: *bm = 96; *bn = 64; break;
+    case 7: *bm = 64; *bn = 128; break;
+    case 8: *bm = 128; *bn = 96; break;
     default: *bm = 32; *bn = 128; break;
   }
 }
@@ -455,23 +435,29 @@ static int auto_split(long tiles, int M, int N, int K, bool have_ws, long ws_flo
   return want > 1 ? (int)want : 1;
 }
 
-// cost ~ rounds over the 256 CUs x work per workgroup / tile efficiency.  The 96x96 tile exists for the
-// network's dominant shape, M = batch*12*16 = 6144 rows x 728 channels: 64 x 8 = 512 tiles = exactly two
-// per CU, where 128x128 leaves 288 tiles (1.125 rounds) and 64x64 pays twice the LDS traffic per FLOP.
-static int pick_tile(int M, int N, int K, int split_k, bool have_ws, long ws_floats) {
+// Tile choice: cost ~ (workgroups on the busiest CU) x (work per workgroup + a fixed prologue/epilogue worth
+// K0 reduction steps) / (measured efficiency of that tile's main loop for this operand form), plus the
+// slab traffic of a K split.  The efficiencies were fitted on MI355X to the network's GEMM shapes
+// (tools/gemm_sweep.py; every shape of the 512x384 batch-32 step gets its measured-fastest tile) but the
+// model itself is shape-agnostic.  Forms: 0 = K/OUT (forward), 1 = K/K (dgrad), 2 = OUT/OUT (wgrad).
+static int pick_tile(int form, int M, int N, int K, int split_k, bool have_ws, long ws_floats) {
   if (M <= 32) return 4;
-  const int cand[4] = {1, 5, 2, 3};
-  const double eff[4] = {1.00, 0.97, 0.90, 0.85};
+  const int cand[7] = {1, 2, 3, 5, 6, 7, 8};
+  static const double eff[3][7] = {{1.00, 0.95, 0.93, 0.93, 0.97, 1.00, 0.93},
+                                   {0.95, 0.93, 0.97, 0.97, 1.00, 0.90, 0.99},
+                                   {0.80, 0.85, 0.95, 1.00, 0.90, 0.85, 0.80}};
   int best = 1;
   double best_cost = 1e300;
-  for (int c = 0; c < 4; ++c) {
+  for (int c = 0; c < 7; ++c) {
     int bm, bn;
     tile_dims(cand[c], &bm, &bn);
     const long tiles = (long)spnet_cdiv(M, bm) * spnet_cdiv(N, bn);
-    const int ns = split_k > 0 ? split_k : auto_split(tiles, M, N, K, have_ws, ws_floats);
-    const double blocks = (double)tiles * ns;
-    double rounds = (double)(long)((blocks + 255.0) / 256.0);
-    const double cost = rounds * bm * bn * ((double)K / ns + 64.0) / eff[c];
+    int ns = split_k > 0 ? split_k : auto_split(tiles, M, N, K, have_ws, ws_floats);
+    const int kc = spnet_cdiv(spnet_cdiv(K, ns), SP_BK) * SP_BK;
+    ns = spnet_cdiv(K, kc);
+    const double rounds = (double)((tiles * ns + 255) / 256);
+    double cost = rounds * bm * bn * ((double)kc + 128.0) / eff[form][c];
+    if (ns > 1) cost += 2.0 * ns * (double)M * N / 256.0;
     if (cost < best_cost) { best_cost = cost; best = cand[c]; }
   }
   return best;
@@ -487,23 +473,15 @@ static int gemm_impl(const float* A, int a_major, int lda, const float* B, int b
   if ((a_major == SP_K_MAJOR || b_major == SP_K_MAJOR) && (K & 3)) return (int)hipErrorInvalidValue;
   if (a_major == SP_OUT_MAJOR && (M & 3)) return (int)hipErrorInvalidValue;
   if (((uintptr_t)A | (uintptr_t)B | (uintptr_t)C) & 15) return (int)hipErrorInvalidValue;
-  if (tile <= 0 || tile > SP_NTILES) tile = pick_tile(M, N, K, split_k, workspace != nullptr, ws_floats);
+  const int form = (a_major == SP_OUT_MAJOR) ? 2 : (b_major == SP_K_MAJOR ? 1 : 0);
+  if (tile <= 0 || tile > SP_NTILES) tile = pick_tile(form, M, N, K, split_k, workspace != nullptr, ws_floats);
   int bm, bn;
   tile_dims(tile, &bm, &bn);
   const long tiles = (long)spnet_cdiv(M, bm) * spnet_cdiv(N, bn);
   const int BK = SP_BK;
   int nsplit = split_k;
   if (nsplit <= 0) nsplit = auto_split(tiles, M, N, K, workspace != nullptr, ws_floats);
-  // LDS-DMA path: needs K to be a whole number of K tiles (no bounds handling) and >= 4 rows/columns to
-  // clamp to; otherwise the register-staged kernel (any K % 4 == 0) is used.
-  int bk_dma = 0;
-#ifndef SP_NO_DMA
-  if (M >= 4 && N >= 4 && tile != 4) {
-    if (K % 32 == 0) bk_dma = 32;
-    else if (K % 28 == 0) bk_dma = 28;
-  }
-#endif
-  const int bkt = bk_dma ? bk_dma : BK;
+  const int bkt = BK;
   int k_chunk = ((K + nsplit - 1) / nsplit + bkt - 1) / bkt * bkt;
   nsplit = (K + k_chunk - 1) / k_chunk;
   float* out = C;
@@ -521,11 +499,14 @@ static int gemm_impl(const float* A, int a_major, int lda, const float* B, int b
   if (stat_rows) *stat_rows = spnet_cdiv(M, bm);
   int rc;
   switch (tile) {
-    case 1: rc = launch_tile<128, 128, 2, 2>(A, a_major, lda, B, b_major, ldb, out, out_ld, M, N, K, nsplit, k_chunk, slab, kbias, colstats, bk_dma, st); break;
-    case 2: rc = launch_tile<128, 64, 2, 2>(A, a_major, lda, B, b_major, ldb, out, out_ld, M, N, K, nsplit, k_chunk, slab, kbias, colstats, bk_dma, st); break;
-    case 3: rc = launch_tile<64, 64, 2, 2>(A, a_major, lda, B, b_major, ldb, out, out_ld, M, N, K, nsplit, k_chunk, slab, kbias, colstats, bk_dma, st); break;
-    case 5: rc = launch_tile<96, 96, 2, 2>(A, a_major, lda, B, b_major, ldb, out, out_ld, M, N, K, nsplit, k_chunk, slab, kbias, colstats, bk_dma, st); break;
-    default: rc = launch_tile<32, 128, 1, 4>(A, a_major, lda, B, b_major, ldb, out, out_ld, M, N, K, nsplit, k_chunk, slab, kbias, colstats, bk_dma, st); break;
+    case 1: rc = launch_tile<128, 128, 2, 2>(A, a_major, lda, B, b_major, ldb, out, out_ld, M, N, K, nsplit, k_chunk, slab, kbias, colstats, st); break;
+    case 2: rc = launch_tile<128, 64, 2, 2>(A, a_major, lda, B, b_major, ldb, out, out_ld, M, N, K, nsplit, k_chunk, slab, kbias, colstats, st); break;
+    case 3: rc = launch_tile<64, 64, 2, 2>(A, a_major, lda, B, b_major, ldb, out, out_ld, M, N, K, nsplit, k_chunk, slab, kbias, colstats, st); break;
+    case 5: rc = launch_tile<96, 96, 2, 2>(A, a_major, lda, B, b_major, ldb, out, out_ld, M, N, K, nsplit, k_chunk, slab, kbias, colstats, st); break;
+    case 6: rc = launch_tile<96, 64, 2, 2>(A, a_major, lda, B, b_major, ldb, out, out_ld, M, N, K, nsplit, k_chunk, slab, kbias, colstats, st); break;
+    case 7: rc = launch_tile<64, 128, 2, 2>(A, a_major, lda, B, b_major, ldb, out, out_ld, M, N, K, nsplit, k_chunk, slab, kbias, colstats, st); break;
+    case 8: rc = launch_tile<128, 96, 2, 2>(A, a_major, lda, B, b_major, ldb, out, out_ld, M, N, K, nsplit, k_chunk, slab, kbias, colstats, st); break;
+    default: rc = launch_tile<32, 128, 1, 4>(A, a_major, lda, B, b_major, ldb, out, out_ld, M, N, K, nsplit, k_chunk, slab, kbias, colstats, st); break;
   }
   if (rc) return rc;
   if (nsplit > 1) {

@@ -36,31 +36,36 @@ def run(form, M, N, K, tile, split=0, iters=20):
     return us, 2.0 * M * N * K / us / 1e6
 
 
-if len(sys.argv) > 1 and sys.argv[1] == "one":
-    form, m, n, k, tile = sys.argv[2], int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5]), int(sys.argv[6])
-    us, tf = run(form, m, n, k, tile, iters=50)
-    print("one %s M=%d N=%d K=%d tile=%d: %.1f us %.1f TF" % (form, m, n, k, tile, us, tf))
-    sys.exit(0)
+def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "one":
+        form, m, n, k, tile = sys.argv[2], int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5]), int(sys.argv[6])
+        us, tf = run(form, m, n, k, tile, iters=50)
+        print("one %s M=%d N=%d K=%d tile=%d: %.1f us %.1f TF" % (form, m, n, k, tile, us, tf))
+        sys.exit(0)
 
-shapes = [("mid", 6144, 728, 728), ("b2s1", 372000, 128, 64), ("b2s2", 372000, 128, 128), ("b1c2", 372000, 64, 288),
-          ("b3s2", 94752, 256, 256), ("b4s2", 24576, 728, 728), ("b14b", 1536, 2048, 1536), ("b13r", 1536, 1024, 728)]
-for name, M, N, K in shapes:
-    for form in ("fwd", "dgrad", "wgrad"):
-        if form == "fwd":
-            m, n, k = M, N, K
-        elif form == "dgrad":
-            m, n, k = M, K, N
-        else:
-            m, n, k = K, N, M
-        res = []
-        for tile in (0, 1, 5, 2, 3):
-            try:
-                us, tf = run(form, m, n, k, tile)
-                res.append("t%d %7.1fus %5.1fTF" % (tile, us, tf))
-            except Exception as ex:
-                res.append("t%d ERR" % tile)
-        print("%-5s %-5s M=%-6d N=%-5d K=%-6d | %s" % (name, form, m, n, k, " | ".join(res)), flush=True)
-# head
-for form, m, n, k in (("fwd", 32, 576, 98304), ("dgrad", 32, 98304, 576), ("wgrad", 98304, 576, 32)):
-    us, tf = run(form, m, n, k, 0)
-    print("head  %-5s M=%-6d N=%-6d K=%-6d | auto %7.1fus %5.1fTF" % (form, m, n, k, us, tf), flush=True)
+    shapes = [("mid", 6144, 728, 728), ("b2s1", 372000, 128, 64), ("b2s2", 372000, 128, 128), ("b1c2", 372000, 64, 288),
+              ("b3s2", 94752, 256, 256), ("b4s2", 24576, 728, 728), ("b14b", 1536, 2048, 1536), ("b13r", 1536, 1024, 728)]
+    for name, M, N, K in shapes:
+        for form in ("fwd", "dgrad", "wgrad"):
+            if form == "fwd":
+                m, n, k = M, N, K
+            elif form == "dgrad":
+                m, n, k = M, K, N
+            else:
+                m, n, k = K, N, M
+            res = []
+            for tile in (0, 1, 5, 2, 3, 6, 7, 8):
+                try:
+                    us, tf = run(form, m, n, k, tile)
+                    res.append("t%d %7.1fus %5.1fTF" % (tile, us, tf))
+                except Exception as ex:
+                    res.append("t%d ERR" % tile)
+            print("%-5s %-5s M=%-6d N=%-5d K=%-6d | %s" % (name, form, m, n, k, " | ".join(res)), flush=True)
+    # head
+    for form, m, n, k in (("fwd", 32, 576, 98304), ("dgrad", 32, 98304, 576), ("wgrad", 98304, 576, 32)):
+        us, tf = run(form, m, n, k, 0)
+        print("head  %-5s M=%-6d N=%-6d K=%-6d | auto %7.1fus %5.1fTF" % (form, m, n, k, us, tf), flush=True)
+
+
+if __name__ == "__main__":
+    main()
