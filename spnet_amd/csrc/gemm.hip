@@ -39,11 +39,17 @@ enum { SP_K_MAJOR = 0, SP_OUT_MAJOR = 1 };
 //               ends up with VW CONSECUTIVE output columns and the epilogue stores them as one vector.
 //               VW = 4 / 2 / 1 for T % 4 == 0 / T % 2 == 0 / odd T; the leading dim is chosen so that the
 //               two k rows (4 apart) met inside one LDS lane group fall on disjoint banks.
-template <int BR, int BK, int MAJ, int T>
+//   PERM (K_MAJOR only): tile row x of a wave's 16T rows is stored at LDS row 16*(x % T) + x / T, so that lane
+//               position p of MFMA tile t stands for output index T*p + t: a lane then holds T CONSECUTIVE
+//               output columns (dgrad, where B = W^T is K-major) and the epilogue stores them as one vector.
+//               The fetch pattern (and its bank behaviour) is unchanged; only the staging store permutes.
+template <int BR, int BK, int MAJ, int T, int PERM = 0>
 struct TileStage {
   static constexpr int TOTAL = BR * BK / 4;            // float4 per tile
   static constexpr int NV = (TOTAL + 255) / 256;       // float4 per thread
   static constexpr int VW = (MAJ == SP_K_MAJOR) ? 1 : ((T % 4 == 0) ? 4 : ((T % 2 == 0) ? 2 : 1));
+  static constexpr int VWO = (MAJ == SP_K_MAJOR) ? (PERM ? T : 1) : VW;   // consecutive outputs per lane
+  static_assert(!PERM || MAJ == SP_K_MAJOR, "row permutation is for K-major images");
   static constexpr int LD = (MAJ == SP_K_MAJOR) ? (BK + 8) : (VW == 4 ? BR : (VW == 2 ? BR + 8 : BR + 4));
   static constexpr int SIZE = (MAJ == SP_K_MAJOR) ? BR * LD : BK * LD;
   static_assert(BR % 16 == 0 && BK % 16 == 0, "tile shape");
@@ -106,7 +112,9 @@ struct TileStage {
           *reinterpret_cast<float4*>(S + k * LD + r4 * 4) = v[i];
         } else {
           const int r = f / (BK / 4), kq = f % (BK / 4);
-          *reinterpret_cast<float4*>(S + r * LD + kq * 4) = v[i];
+          const int x = r % (16 * T);
+          const int lr = PERM ? (r - x) + 16 * (x % T) + x / T : r;
+          *reinterpret_cast<float4*>(S + lr * LD + kq * 4) = v[i];
         }
       }
     }
@@ -146,7 +154,7 @@ struct TileStage {
 
   // output index (inside the wave's T*16 rows/cols) that lane position p of MFMA tile t stands for
   static __device__ __forceinline__ int pos(int t, int p) {
-    return (MAJ == SP_K_MAJOR) ? t * 16 + p : (t / VW) * (16 * VW) + VW * p + (t % VW);
+    return (MAJ == SP_K_MAJOR) ? (PERM ? T * p + t : t * 16 + p) : (t / VW) * (16 * VW) + VW * p + (t % VW);
   }
 };
 
@@ -199,7 +207,7 @@ __device__ __forceinline__ void gemm_epilogue(f32x4 (&acc)[TM][TN], float* __res
   }
 
   float* Cz = C + (long)z * slab_stride;
-  constexpr int VW = SB::VW;                 // consecutive columns held by one lane (N % 4 == 0, ldc % 4 == 0)
+  constexpr int VW = SB::VWO;                // consecutive columns held by one lane
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -210,23 +218,18 @@ __device__ __forceinline__ void gemm_epilogue(f32x4 (&acc)[TM][TN], float* __res
 #pragma unroll
         for (int g = 0; g < TN / VW; ++g) {
           const int col = nw + SB::pos(g * VW, p);
-          if (col < N) {                     // VW | 4 | N and col % VW == 0: the whole vector is inside
-            if (VW == 4) {
-              float4 o = make_float4(acc[i][g * VW][r], acc[i][g * VW + 1 < TN ? g * VW + 1 : 0][r],
-                                     acc[i][g * VW + 2 < TN ? g * VW + 2 : 0][r],
-                                     acc[i][g * VW + 3 < TN ? g * VW + 3 : 0][r]);
-              if (bias) {
-                const float4 b = *reinterpret_cast<const float4*>(bias + col);
-                o.x += b.x; o.y += b.y; o.z += b.z; o.w += b.w;
-              }
-              *reinterpret_cast<float4*>(crow + col) = o;
-            } else if (VW == 2) {
-              float2 o = make_float2(acc[i][g * VW][r], acc[i][g * VW + 1 < TN ? g * VW + 1 : 0][r]);
-              if (bias) { o.x += bias[col]; o.y += bias[col + 1]; }
-              *reinterpret_cast<float2*>(crow + col) = o;
-            } else {
-              crow[col] = acc[i][g][r] + (bias ? bias[col] : 0.f);
-            }
+          float o[VW];
+#pragma unroll
+          for (int u = 0; u < VW; ++u) o[u] = acc[i][g * VW + u][r] + (bias && col + u < N ? bias[col + u] : 0.f);
+          // N % 4 == 0 and ldc % 4 == 0: an aligned 2- or 4-vector is inside or outside as a whole
+          if (VW == 4) {
+            if (col < N) *reinterpret_cast<float4*>(crow + col) = make_float4(o[0], o[VW > 1 ? 1 : 0], o[VW > 2 ? 2 : 0], o[VW > 3 ? 3 : 0]);
+          } else if (VW == 2) {
+            if (col < N) *reinterpret_cast<float2*>(crow + col) = make_float2(o[0], o[VW > 1 ? 1 : 0]);
+          } else {
+#pragma unroll
+            for (int u = 0; u < VW; ++u)
+              if (col + u < N) crow[col + u] = o[u];
           }
         }
       }
@@ -250,7 +253,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const float* __restric
   constexpr int TM = BM / WM / 16, TN = BN / WN / 16;
   static_assert(TM >= 1 && TN >= 1 && (BM % (WM * 16)) == 0 && (BN % (WN * 16)) == 0, "wave tile");
   typedef TileStage<BM, BK, AMAJ, TM> SA;
-  typedef TileStage<BN, BK, BMAJ, TN> SB;
+  typedef TileStage<BN, BK, BMAJ, TN, (BMAJ == SP_K_MAJOR)> SB;
   constexpr int STAGE = SA::SIZE + SB::SIZE;
   constexpr int NCH = BK / 16;
   __shared__ __attribute__((aligned(16))) float smem[2 * STAGE];

@@ -202,6 +202,168 @@ __global__ __launch_bounds__(256) void conv3x3_wide_bwd_weight_kernel(const floa
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// block1_conv1 (3 -> 32, stride 2, VALID): the one small conv whose OUTPUT is wide (32 channels at
+// half resolution = 2.6x the bytes of its input), so each of its three passes is organised around
+// coalesced 128-byte pixel records of y / dy:
+//   forward   LDS-staged input patch per 4x32-pixel output tile; 8 threads per pixel, each owning one
+//             quad of output channels with its 27 weight quads in registers -> float4 stores, 1 KB per wave
+//   dX        one thread per 2x2 block of input pixels: the 4 dy pixels around it feed its 12 outputs
+//             through all 9 taps with no stride/parity divergence; weights are wave-uniform (scalar loads)
+//   dW        same tile + dy tile in LDS, thread = (tap*ci, channel quad), one partial filter per workgroup
+// ------------------------------------------------------------------------------------------------
+#define C1_TH 4
+#define C1_TW 32
+#define C1_PR (2 * C1_TH + 1)          // patch rows
+#define C1_PC (2 * C1_TW + 1)          // patch pixels per row
+#define C1_PLD (3 * C1_PC + 1)         // floats per patch row (padded)
+
+__device__ __forceinline__ void c1_stage_patch(float* __restrict__ patch, const float* __restrict__ x, int b,
+                                               int H, int W, int oh0, int ow0, int tid) {
+  for (int e = tid; e < C1_PR * 3 * C1_PC; e += 256) {
+    const int r = e / (3 * C1_PC), c = e % (3 * C1_PC);
+    const int h = 2 * oh0 + r, wc = 2 * ow0 * 3 + c;          // wc: float index inside the image row
+    patch[r * C1_PLD + c] = (h < H && wc < 3 * W) ? x[((long)b * H + h) * W * 3 + wc] : 0.f;
+  }
+}
+
+__global__ __launch_bounds__(256) void conv1_fwd_kernel(const float* __restrict__ x,
+                                                        const float* __restrict__ w, float* __restrict__ y,
+                                                        int H, int W, int OH, int OW) {
+  __shared__ float patch[C1_PR * C1_PLD];
+  const int tid = threadIdx.x;
+  const int b = blockIdx.z, oh0 = blockIdx.y * C1_TH, ow0 = blockIdx.x * C1_TW;
+  const int cq = tid & 7, pl = tid >> 3;
+  float4 wr[27];
+#pragma unroll
+  for (int k = 0; k < 27; ++k) wr[k] = *reinterpret_cast<const float4*>(w + k * 32 + cq * 4);
+  c1_stage_patch(patch, x, b, H, W, oh0, ow0, tid);
+  __syncthreads();
+  const int ow = ow0 + pl;
+#pragma unroll
+  for (int r = 0; r < C1_TH; ++r) {
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh) {
+      const float* pp = patch + (2 * r + kh) * C1_PLD + 6 * pl;    // 9 consecutive floats: [kw][ci]
+#pragma unroll
+      for (int q = 0; q < 9; ++q) {
+        const float xv = pp[q];
+        const float4 wv = wr[kh * 9 + q];
+        acc.x = fmaf(xv, wv.x, acc.x); acc.y = fmaf(xv, wv.y, acc.y);
+        acc.z = fmaf(xv, wv.z, acc.z); acc.w = fmaf(xv, wv.w, acc.w);
+      }
+    }
+    const int oh = oh0 + r;
+    if (oh < OH && ow < OW)
+      *reinterpret_cast<float4*>(y + (((long)b * OH + oh) * OW + ow) * 32 + cq * 4) = acc;
+  }
+}
+
+// One thread per 2x2 block (i, j) of input pixels; dy pixel (i - di, j - dj), di, dj in {0, 1}, reaches
+// input pixel (2i + ph, 2j + pw) through tap (ph + 2 di, pw + 2 dj) when that tap index is <= 2.
+__global__ __launch_bounds__(256) void conv1_bwd_data_kernel(const float* __restrict__ dy,
+                                                             const float* __restrict__ w,
+                                                             float* __restrict__ dx, int Bn, int H, int W,
+                                                             int OH, int OW) {
+  const int H2 = (H + 1) >> 1, W2 = (W + 1) >> 1;
+  const long total = (long)Bn * H2 * W2;
+  for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
+    const int j = (int)(t % W2);
+    long u = t / W2;
+    const int i = (int)(u % H2);
+    const int b = (int)(u / H2);
+    float acc[2][2][3];
+#pragma unroll
+    for (int a = 0; a < 12; ++a) (&acc[0][0][0])[a] = 0.f;
+#pragma unroll
+    for (int di = 0; di < 2; ++di) {
+#pragma unroll
+      for (int dj = 0; dj < 2; ++dj) {
+        const int oh = i - di, ow = j - dj;
+        if (oh < 0 || oh >= OH || ow < 0 || ow >= OW) continue;
+        const float4* gp = reinterpret_cast<const float4*>(dy + (((long)b * OH + oh) * OW + ow) * 32);
+        float g[32];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          const float4 v = gp[q];
+          g[4 * q] = v.x; g[4 * q + 1] = v.y; g[4 * q + 2] = v.z; g[4 * q + 3] = v.w;
+        }
+#pragma unroll
+        for (int ph = 0; ph < 2; ++ph) {
+          if (ph + 2 * di > 2) continue;
+#pragma unroll
+          for (int pw = 0; pw < 2; ++pw) {
+            if (pw + 2 * dj > 2) continue;
+            const float* wt = w + (((ph + 2 * di) * 3 + (pw + 2 * dj)) * 3) * 32;   // wave-uniform
+#pragma unroll
+            for (int ci = 0; ci < 3; ++ci) {
+              float s = acc[ph][pw][ci];
+#pragma unroll
+              for (int co = 0; co < 32; ++co) s = fmaf(g[co], wt[ci * 32 + co], s);
+              acc[ph][pw][ci] = s;
+            }
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int ph = 0; ph < 2; ++ph) {
+      const int h = 2 * i + ph;
+      if (h >= H) continue;
+      float* dp = dx + (((long)b * H + h) * W + 2 * j) * 3;
+      if (2 * j + 1 < W) {       // 6 consecutive floats, 8-byte aligned
+        reinterpret_cast<float2*>(dp)[0] = make_float2(acc[ph][0][0], acc[ph][0][1]);
+        reinterpret_cast<float2*>(dp)[1] = make_float2(acc[ph][0][2], acc[ph][1][0]);
+        reinterpret_cast<float2*>(dp)[2] = make_float2(acc[ph][1][1], acc[ph][1][2]);
+      } else {
+        dp[0] = acc[ph][0][0]; dp[1] = acc[ph][0][1]; dp[2] = acc[ph][0][2];
+      }
+    }
+  }
+}
+
+// Workgroups walk over output tiles (grid-stride); thread (tg = tid >> 3, cq = tid & 7) owns
+// dW[tap*3+ci = tg][4 cq .. 4 cq + 3] and adds x_patch(pixel, tg) * dy(pixel, quad) over the tile's pixels.
+__global__ __launch_bounds__(256) void conv1_bwd_weight_kernel(const float* __restrict__ x,
+                                                               const float* __restrict__ dy,
+                                                               float* __restrict__ partial, int Bn, int H,
+                                                               int W, int OH, int OW, int tiles_w,
+                                                               int tiles_h) {
+  __shared__ float patch[C1_PR * C1_PLD];
+  __shared__ __attribute__((aligned(16))) float gt[C1_TH * C1_TW * 32];
+  const int tid = threadIdx.x;
+  const int cq = tid & 7, tg = tid >> 3;
+  const int tc = tg < 27 ? tg : 26;
+  const int toff = (tc / 9) * C1_PLD + (tc % 9);                 // (kh, kw*3+ci) inside the patch
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  const int ntiles = Bn * tiles_h * tiles_w;
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int twi = tile % tiles_w;
+    const int thi = (tile / tiles_w) % tiles_h;
+    const int b = tile / (tiles_w * tiles_h);
+    const int oh0 = thi * C1_TH, ow0 = twi * C1_TW;
+    __syncthreads();                                             // previous tile fully consumed
+    c1_stage_patch(patch, x, b, H, W, oh0, ow0, tid);
+    for (int e = tid; e < C1_TH * C1_TW * 8; e += 256) {         // dy tile, float4 granules, zero outside
+      const int px = e >> 3, q = e & 7;
+      const int oh = oh0 + px / C1_TW, ow = ow0 + px % C1_TW;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (oh < OH && ow < OW) v = *reinterpret_cast<const float4*>(dy + (((long)b * OH + oh) * OW + ow) * 32 + q * 4);
+      *reinterpret_cast<float4*>(gt + px * 32 + q * 4) = v;
+    }
+    __syncthreads();
+#pragma unroll 8
+    for (int px = 0; px < C1_TH * C1_TW; ++px) {
+      const float xv = patch[2 * (px / C1_TW) * C1_PLD + 6 * (px % C1_TW) + toff];
+      const float4 g = *reinterpret_cast<const float4*>(gt + px * 32 + cq * 4);
+      acc.x = fmaf(xv, g.x, acc.x); acc.y = fmaf(xv, g.y, acc.y);
+      acc.z = fmaf(xv, g.z, acc.z); acc.w = fmaf(xv, g.w, acc.w);
+    }
+  }
+  if (tg < 27) *reinterpret_cast<float4*>(partial + (long)blockIdx.x * 864 + tg * 32 + cq * 4) = acc;
+}
+
 extern "C" int spnet_reduce_rows(const float* in, int P, int L, float* out, void* stream);   // dwconv.hip
 
 template <int CIN, int COUT, int STRIDE, int PAD>
@@ -210,6 +372,24 @@ static int conv_small_dispatch(int op, const float* a, const float* b, float* ou
   const int OH = (PAD == 1) ? H : (H - 3) / STRIDE + 1;
   const int OW = (PAD == 1) ? W : (W - 3) / STRIDE + 1;
   constexpr int NW = 9 * CIN * COUT;
+  if constexpr (CIN == 3 && COUT == 32 && STRIDE == 2 && PAD == 0) {
+    const int tw = spnet_cdiv(OW, C1_TW), th = spnet_cdiv(OH, C1_TH);
+    if (op == 0) {
+      hipLaunchKernelGGL(conv1_fwd_kernel, dim3(tw, th, B), dim3(256), 0, st, a, b, out, H, W, OH, OW);
+    } else if (op == 1) {
+      const long total = (long)B * ((H + 1) / 2) * ((W + 1) / 2);
+      hipLaunchKernelGGL(conv1_bwd_data_kernel, dim3(spnet_ew_grid(total, 256)), dim3(256), 0, st, a, b, out, B,
+                         H, W, OH, OW);
+    } else {
+      long parts = (long)B * tw * th;
+      if (parts > 768) parts = 768;
+      if (parts * NW > ws_floats) return (int)hipErrorInvalidValue;
+      hipLaunchKernelGGL(conv1_bwd_weight_kernel, dim3((unsigned)parts), dim3(256), 0, st, a, b, workspace, B, H,
+                         W, OH, OW, tw, th);
+      return spnet_reduce_rows(workspace, (int)parts, NW, out, (void*)st);
+    }
+    return (int)hipGetLastError();
+  }
   if (op == 0) {  // forward: a = x, b = w
     const long total = (long)B * OH * OW;
     hipLaunchKernelGGL((conv3x3_small_fwd_kernel<CIN, COUT, STRIDE, PAD>), dim3(spnet_ew_grid(total, 256)),
