@@ -123,6 +123,65 @@ __global__ void bn_partial_small_kernel(const float* __restrict__ x, const float
   }
 }
 
+// C == 3 (the stem): 4 pixels = 12 floats = three float4 whose channel pattern is fixed
+// ([c0 c1 c2 c0][c1 c2 c0 c1][c2 c0 c1 c2]), so a thread streams 48-byte groups with vector loads and keeps
+// its three channel sums in registers.  M % 4 == 0.  One partial row per workgroup, fixed order:
+// thread -> wave (shuffles) -> workgroup (LDS, wave order).
+template <int MODE>
+__global__ __launch_bounds__(256) void bn_partial_c3_kernel(const float* __restrict__ x,
+                                                            const float* __restrict__ dy, long M,
+                                                            const float* __restrict__ mean,
+                                                            const float* __restrict__ invstd,
+                                                            const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta, int act,
+                                                            float* __restrict__ partial) {
+  __shared__ float red[4][6];
+  float mu[3] = {0.f, 0.f, 0.f}, is[3] = {0.f, 0.f, 0.f}, ga[3] = {0.f, 0.f, 0.f}, be[3] = {0.f, 0.f, 0.f};
+  if (MODE == 1) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { mu[c] = mean[c]; is[c] = invstd[c]; ga[c] = gamma[c]; be[c] = beta[c]; }
+  }
+  float s0[3] = {0.f, 0.f, 0.f}, s1[3] = {0.f, 0.f, 0.f};
+  const long groups = M / 4;
+  for (long gi = (long)blockIdx.x * blockDim.x + threadIdx.x; gi < groups; gi += (long)gridDim.x * blockDim.x) {
+    float v[12], g[12];
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+      const float4 t = *reinterpret_cast<const float4*>(x + gi * 12 + q * 4);
+      v[4 * q] = t.x; v[4 * q + 1] = t.y; v[4 * q + 2] = t.z; v[4 * q + 3] = t.w;
+      if (MODE == 1) {
+        const float4 u = *reinterpret_cast<const float4*>(dy + gi * 12 + q * 4);
+        g[4 * q] = u.x; g[4 * q + 1] = u.y; g[4 * q + 2] = u.z; g[4 * q + 3] = u.w;
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < 12; ++e) {
+      const int c = e % 3;
+      if (MODE == 0) {
+        s0[c] += v[e];
+        s1[c] = fmaf(v[e], v[e], s1[c]);
+      } else {
+        const float xh = (v[e] - mu[c]) * is[c];
+        const float gg = g[e] * act_grad(fmaf(xh, ga[c], be[c]), act);
+        s0[c] += gg;
+        s1[c] = fmaf(gg, xh, s1[c]);
+      }
+    }
+  }
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    const float a = wave_sum(s0[c]), b = wave_sum(s1[c]);
+    if (lane == 0) { red[wv][c] = a; red[wv][3 + c] = b; }
+  }
+  __syncthreads();
+  if (threadIdx.x < 6) {
+    const int q = threadIdx.x / 3, c = threadIdx.x % 3;
+    partial[((long)blockIdx.x * 2 + q) * 3 + c] =
+        (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+  }
+}
+
 // Combine partial [P][2][C] in a fixed order: 256 threads = 16 channels x 16 interleaved groups of
 // partial rows, summed in double (4 independent loads in flight per thread), then the 16 group sums
 // are added in group order.  Returns the channel owned by this thread (group 0 only) or -1.
@@ -307,6 +366,11 @@ static int bn_chan_lanes(int c4n) {
 }
 
 static int bn_parts(long M, int C) {
+  if (C == 3 && (M & 3) == 0) {
+    long g = (M / 4 + 256L * 4 - 1) / (256L * 4);
+    if (g > 1024) g = 1024;
+    return g < 1 ? 1 : (int)g;
+  }
   if (C & 3) {
     long g = (M * C + (64L * C) * 8 - 1) / ((64L * C) * 8);
     if (g > BN_MAX_PARTS) g = BN_MAX_PARTS;
@@ -330,7 +394,10 @@ template <int MODE>
 static void launch_partial(const float* x, const float* dy, long M, int C, const float* mean,
                            const float* invstd, const float* gamma, const float* beta, int act,
                            float* partial, int parts, hipStream_t st) {
-  if (C & 3) {
+  if (C == 3 && (M & 3) == 0) {
+    hipLaunchKernelGGL(bn_partial_c3_kernel<MODE>, dim3(parts), dim3(256), 0, st, x, dy, M, mean, invstd, gamma,
+                       beta, act, partial);
+  } else if (C & 3) {
     const int bd = 64 * C;
     hipLaunchKernelGGL(bn_partial_small_kernel<MODE>, dim3(parts), dim3(bd), 2 * bd * sizeof(float),
                        st, x, dy, M, C, mean, invstd, gamma, beta, act, partial);

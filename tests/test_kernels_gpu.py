@@ -36,7 +36,7 @@ WS = 8 * 1024 * 1024
 
 @pytest.mark.parametrize("M,N,K", [(128, 128, 64), (6144, 728, 728), (100, 728, 256), (37, 64, 288), (32, 576, 4096),
                                    (1000, 128, 64), (4, 12, 8)])
-@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4, 5])
+@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4, 5, 6, 7, 8])
 def test_gemm_forward_form(L, M, N, K, tile):
     rs = np.random.RandomState(M + N + K)
     A, B = rs.randn(M, K).astype(np.float32), rs.randn(K, N).astype(np.float32)
@@ -69,26 +69,30 @@ def test_gemm_split_k_is_deterministic_and_correct(L, split):
 
 
 @pytest.mark.parametrize("M,N,K", [(6144, 728, 728), (200, 64, 128), (32, 4096, 576)])
-def test_gemm_dgrad_form(L, M, N, K):
+@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4, 5, 6, 7, 8])
+def test_gemm_dgrad_form(L, M, N, K, tile):
     # dX[M,N=cin] = dY[M,K=cout] @ W[N,K]^T, W read in place (K-major B)
     rs = np.random.RandomState(1)
     dY, W = rs.randn(M, K).astype(np.float32), rs.randn(N, K).astype(np.float32)
     a, b = dev(dY), dev(W)
     c = torch.empty(M, N, device="cuda")
     ws = torch.empty(WS, device="cuda")
-    L.spnet_gemm_f32(a.data_ptr(), 0, K, b.data_ptr(), 0, K, c.data_ptr(), N, M, N, K, 0, ws.data_ptr(), WS, None, 0, st())
+    c.fill_(float("nan"))
+    L.spnet_gemm_f32(a.data_ptr(), 0, K, b.data_ptr(), 0, K, c.data_ptr(), N, M, N, K, 0, ws.data_ptr(), WS, None, tile, st())
     close(c, dY.astype(np.float64) @ W.astype(np.float64).T, rtol=2e-5, atol=2e-5 * np.sqrt(K))
 
 
 @pytest.mark.parametrize("M,N,K", [(728, 728, 6144), (64, 128, 23250), (4096, 576, 32), (288, 64, 5000)])
-def test_gemm_wgrad_form(L, M, N, K):
+@pytest.mark.parametrize("tile", [0, 1, 2, 3, 5, 6, 7, 8])
+def test_gemm_wgrad_form(L, M, N, K, tile):
     # dW[M=cin,N=cout] = X[K,M]^T @ dY[K,N]; K (pixels) need not be a multiple of 4
     rs = np.random.RandomState(2)
     X, dY = rs.randn(K, M).astype(np.float32), rs.randn(K, N).astype(np.float32)
     a, b = dev(X), dev(dY)
     c = torch.empty(M, N, device="cuda")
     ws = torch.empty(WS, device="cuda")
-    L.spnet_gemm_f32(a.data_ptr(), 1, M, b.data_ptr(), 1, N, c.data_ptr(), N, M, N, K, 0, ws.data_ptr(), WS, None, 0, st())
+    c.fill_(float("nan"))
+    L.spnet_gemm_f32(a.data_ptr(), 1, M, b.data_ptr(), 1, N, c.data_ptr(), N, M, N, K, 0, ws.data_ptr(), WS, None, tile, st())
     close(c, X.astype(np.float64).T @ dY.astype(np.float64), rtol=2e-5, atol=3e-5 * np.sqrt(K))
 
 
@@ -181,7 +185,7 @@ def test_dwconv_tiled(L, B, H, W, C, relu_in, fused_bn):
 
 
 @pytest.mark.parametrize("M,N,K", [(6144, 728, 728), (372, 128, 64), (1536, 2048, 1536), (100, 64, 288), (33, 72, 40)])
-@pytest.mark.parametrize("tile", [0, 1, 2, 3, 5])
+@pytest.mark.parametrize("tile", [0, 1, 2, 3, 5, 6, 7, 8])
 def test_gemm_colstats_and_bn_finalize(L, M, N, K, tile):
     import ctypes
     rs = np.random.RandomState(M + N)
