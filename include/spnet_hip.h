@@ -43,6 +43,18 @@ int spnet_gemm_f32_colstats(const float* A, int a_major, int lda, const float* B
 /* 3x3 VALID stride-1 patch matrix and its adjoint (block1_conv2 of keras Xception). */
 int spnet_im2col3x3(const float* x, float* col, int B, int H, int W, int C, void* stream);
 int spnet_col2im3x3(const float* dcol, float* dx, int B, int H, int W, int C, void* stream);
+/* The same layer as implicit GEMMs that gather their operand tiles from the NHWC tensors (no patch matrix):
+ * x [B][H][W][cin], w / dw HWIO [3][3][cin][cout], y / dy [B][H-2][W-2][cout].  (cin, cout) = (32, 64).
+ * wgrad splits the pixels over workgroups: workspace >= spnet_conv3x3_wgrad_ws() floats. */
+int spnet_conv3x3_fwd(const float* x, const float* w, float* y, int B, int H, int W, int cin, int cout,
+                      void* stream);
+int spnet_conv3x3_dgrad(const float* dy, const float* w, float* dx, int B, int H, int W, int cin, int cout,
+                        void* stream);
+long spnet_conv3x3_wgrad_ws(int B, int H, int W, int cin, int cout);
+int spnet_conv3x3_wgrad(const float* x, const float* dy, float* dw, int B, int H, int W, int cin, int cout,
+                        float* workspace, long ws_floats, void* stream);
+/* out[M][ldc] = sum over nslab slabs of M*N floats, in slab order (the second stage of every K split). */
+int spnet_reduce_slabs(const float* ws, int nslab, int M, int N, float* out, int ldc, void* stream);
 /* Even-pixel gather / scatter-add: TF 'same' 1x1 stride-2 residual convs of Xception blocks 2,3,4,13. */
 int spnet_gather_s2(const float* x, float* xs, int B, int H, int W, int C, void* stream);
 int spnet_scatter_add_s2(const float* dxs, float* dx, int B, int H, int W, int C, void* stream);

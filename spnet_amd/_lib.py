@@ -27,6 +27,11 @@ _SIGS = {
     "spnet_gemm_f32": (c_int, [P, c_int, c_int, P, c_int, c_int, P, c_int, c_int, c_int, c_int, c_int, P, c_long, P, c_int, P]),
     "spnet_im2col3x3": (c_int, [P, P, c_int, c_int, c_int, c_int, P]),
     "spnet_col2im3x3": (c_int, [P, P, c_int, c_int, c_int, c_int, P]),
+    "spnet_conv3x3_fwd": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, P]),
+    "spnet_conv3x3_dgrad": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, P]),
+    "spnet_conv3x3_wgrad_ws": (c_long, [c_int, c_int, c_int, c_int, c_int]),
+    "spnet_conv3x3_wgrad": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, P, c_long, P]),
+    "spnet_reduce_slabs": (c_int, [P, c_int, c_int, c_int, P, c_int, P]),
     "spnet_gather_s2": (c_int, [P, P, c_int, c_int, c_int, c_int, P]),
     "spnet_scatter_add_s2": (c_int, [P, P, c_int, c_int, c_int, c_int, P]),
     "spnet_dwconv3x3_fwd": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, P]),

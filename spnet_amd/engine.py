@@ -618,28 +618,56 @@ class Pointwise:
 
 
 class Conv3x3Gemm(Node):
-    """block1_conv2: 3x3 VALID conv (cin%4==0) as im2col + MFMA GEMM."""
+    """block1_conv2 (3x3 VALID, 32 -> 64): three implicit GEMMs that gather their operand tiles straight
+    from the NHWC tensors -- the 9x patch matrix (428 MB at batch 32, 512x384) is never built."""
 
     def __init__(self, eng, x, cin, cout, name):
         self.e, self.x, self.cin, self.cout = eng, x, cin, cout
         B, H, W, _ = x.shape
         self.H, self.W = H, W
         self.OH, self.OW = H - 2, W - 2
-        self.M = B * self.OH * self.OW
-        self.col = eng.new(self.M, 9 * cin)
         self.y = eng.new(B, self.OH, self.OW, cout)
-        self.pw = Pointwise(eng, self.M, 9 * cin, cout, name + "/kernel")
+        self.w = eng.P(name + "/kernel")
         if eng.train_capable:
-            self.dcol = eng.new(self.M, 9 * cin)
+            self.gw = eng.G(name + "/kernel")
             self.dx = eng.new(*x.shape)
+            if L.spnet_conv3x3_wgrad_ws(B, H, W, cin, cout) > min(WS_GEMM[1], WS_GEMM2[1]):
+                raise RuntimeError("split-K workspace too small for %s" % name)
+
+    def _timed(self, flops, call):
+        """Count the launch in the GEMM family of the kernel timers (same MFMA tile machinery)."""
+        prof = self.e.prof
+        if prof is None:
+            return call()
+        t0 = prof.start()
+        call()
+        prof.stop("gemm", t0, flops)
 
     def fwd(self, training):
-        L.spnet_im2col3x3(L.ptr(self.x), L.ptr(self.col), self.e.B, self.H, self.W, self.cin, _stream())
-        self.pw.fwd(self.col, self.y)
+        e = self.e
+        self._timed(2.0 * e.B * self.OH * self.OW * 9 * self.cin * self.cout,
+                    lambda: L.spnet_conv3x3_fwd(L.ptr(self.x), L.ptr(self.w), L.ptr(self.y), e.B, self.H, self.W,
+                                                self.cin, self.cout, _stream()))
+
+    def _wgrad(self, g, region):
+        e = self.e
+        self._timed(2.0 * e.B * self.OH * self.OW * 9 * self.cin * self.cout,
+                    lambda: L.spnet_conv3x3_wgrad(L.ptr(self.x), L.ptr(g), L.ptr(self.gw), e.B, self.H, self.W,
+                                                  self.cin, self.cout, e.ws_ptr(region), region[1], _stream()))
 
     def bwd(self, g):
-        self.pw.bwd(self.col, g, self.dcol)
-        L.spnet_col2im3x3(L.ptr(self.dcol), L.ptr(self.dx), self.e.B, self.H, self.W, self.cin, _stream())
+        """dW on the weight-gradient stream (independent of dX, like every other layer's), then dX."""
+        e = self.e
+        side = e.wgrad_stream
+        if side is None:
+            self._wgrad(g, WS_GEMM)
+        else:
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                self._wgrad(g, WS_GEMM2)
+        self._timed(2.0 * e.B * self.H * self.W * 9 * self.cout * self.cin,
+                    lambda: L.spnet_conv3x3_dgrad(L.ptr(g), L.ptr(self.w), L.ptr(self.dx), e.B, self.H, self.W,
+                                                  self.cin, self.cout, _stream()))
         return self.dx
 
 

@@ -340,6 +340,37 @@ def test_small_conv(L, cin, cout, stride, same, H, W):
     close(dwd, w.grad, rtol=1e-4, atol=1e-4 * np.sqrt(B * H * W))
 
 
+@pytest.mark.parametrize("B,H,W", [(2, 9, 40), (1, 33, 47), (3, 5, 34), (2, 40, 70)])
+def test_conv3x3_implicit_gemm(L, B, H, W):
+    """block1_conv2 without the im2col matrix: forward, input gradient and weight gradient against the oracle
+    conv and its autograd."""
+    rs = np.random.RandomState(H * W)
+    x = torch.tensor(rs.randn(B, H, W, 32), dtype=torch.float32, requires_grad=True)
+    w = torch.tensor(rs.randn(3, 3, 32, 64) * 0.1, dtype=torch.float32, requires_grad=True)
+    y = T.conv2d(x, w, 1, "valid")
+    dy = torch.tensor(rs.randn(*y.shape), dtype=torch.float32)
+    y.backward(dy)
+    xd, dyd, wd = x.detach().cuda(), dy.cuda(), w.detach().cuda()
+    yd = torch.full(tuple(y.shape), float("nan"), device="cuda")
+    L.spnet_conv3x3_fwd(xd.data_ptr(), wd.data_ptr(), yd.data_ptr(), B, H, W, 32, 64, st())
+    close(yd, y.detach(), rtol=1e-4, atol=1e-4)
+    dxd = torch.full((B, H, W, 32), float("nan"), device="cuda")
+    L.spnet_conv3x3_dgrad(dyd.data_ptr(), wd.data_ptr(), dxd.data_ptr(), B, H, W, 32, 64, st())
+    close(dxd, x.grad, rtol=1e-4, atol=1e-4)
+    n = L.spnet_conv3x3_wgrad_ws(B, H, W, 32, 64)
+    ws = torch.empty(n, device="cuda")
+    dwd = torch.full((3, 3, 32, 64), float("nan"), device="cuda")
+    L.spnet_conv3x3_wgrad(xd.data_ptr(), dyd.data_ptr(), dwd.data_ptr(), B, H, W, 32, 64, ws.data_ptr(), n, st())
+    close(dwd, w.grad, rtol=1e-4, atol=1e-4 * np.sqrt(B * H * W))
+    dw2 = torch.empty_like(dwd)
+    L.spnet_conv3x3_wgrad(xd.data_ptr(), dyd.data_ptr(), dw2.data_ptr(), B, H, W, 32, 64, ws.data_ptr(), n, st())
+    assert torch.equal(dwd, dw2)                     # fixed reduction order
+    with pytest.raises(L.HipError):
+        L.spnet_conv3x3_dgrad(dyd.data_ptr(), wd.data_ptr(), dxd.data_ptr(), B, H, W, 16, 64, st())
+    with pytest.raises(L.HipError):
+        L.spnet_conv3x3_wgrad(xd.data_ptr(), dyd.data_ptr(), dwd.data_ptr(), B, H, W, 32, 64, ws.data_ptr(), n - 1, st())
+
+
 def test_im2col_col2im_gather_scatter(L):
     rs = np.random.RandomState(9)
     B, H, W, C = 2, 9, 11, 32

@@ -39,3 +39,22 @@ for (cin, cout, stride, same, H, W) in [(1, 3, 1, 1, 384, 512), (3, 3, 1, 1, 384
     t2 = timeit(lambda: L.spnet_conv3x3_small(2, cin, cout, stride, same, x.data_ptr(), dy.data_ptr(), dw.data_ptr(), B, H, W, ws.data_ptr(), WS, st()))
     print("conv %d->%d s%d %dx%d: tensors %.1f MB | fwd %.1f us (%.2f TB/s) | dX %.1f us (%.2f TB/s) | dW %.1f us (%.2f TB/s)"
           % (cin, cout, stride, H, W, nb / 1e6, t0, nb / t0 / 1e6, t1, nb / t1 / 1e6, t2, nb / t2 / 1e6), flush=True)
+
+# block1_conv2 input gradient: implicit GEMM vs (dgrad GEMM into dcol + col2im)
+H, W = 95, 127
+dy = torch.randn(B, H - 2, W - 2, 64, device="cuda")
+w = torch.randn(3, 3, 32, 64, device="cuda")
+dx = torch.empty(B, H, W, 32, device="cuda")
+t = timeit(lambda: L.spnet_conv3x3_dgrad(dy.data_ptr(), w.data_ptr(), dx.data_ptr(), B, H, W, 32, 64, st()))
+fl = 2.0 * B * H * W * 576 * 32
+print("block1_conv2 dX implicit GEMM: %.1f us (%.1f TFLOP/s)" % (t, fl / t / 1e6), flush=True)
+x = torch.randn(B, H, W, 32, device="cuda")
+y = torch.empty(B, H - 2, W - 2, 64, device="cuda")
+t = timeit(lambda: L.spnet_conv3x3_fwd(x.data_ptr(), w.data_ptr(), y.data_ptr(), B, H, W, 32, 64, st()))
+fl = 2.0 * B * (H - 2) * (W - 2) * 288 * 64
+print("block1_conv2 Y  implicit GEMM: %.1f us (%.1f TFLOP/s)" % (t, fl / t / 1e6), flush=True)
+n = L.spnet_conv3x3_wgrad_ws(B, H, W, 32, 64)
+wsb = torch.empty(n, device="cuda")
+dw = torch.empty(3, 3, 32, 64, device="cuda")
+t = timeit(lambda: L.spnet_conv3x3_wgrad(x.data_ptr(), dy.data_ptr(), dw.data_ptr(), B, H, W, 32, 64, wsb.data_ptr(), n, st()))
+print("block1_conv2 dW implicit GEMM: %.1f us (%.1f TFLOP/s)" % (t, fl / t / 1e6), flush=True)
