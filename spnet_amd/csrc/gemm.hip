@@ -23,13 +23,14 @@
 // tile t is multiplied, and is written to the idle LDS buffer in the MIDDLE of the MFMA stream (nobody
 // reads that buffer during this iteration), so one barrier per K tile suffices.
 template <int BM, int BN, int BK, int WM, int WN, int AMAJ, int BMAJ>
-__global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const float* __restrict__ A, int lda,
-                                                       const float* __restrict__ B, int ldb,
-                                                       float* __restrict__ C, int ldc, int M, int N,
+__global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const float* __restrict__ A_, int lda,
+                                                       const float* __restrict__ B_, int ldb,
+                                                       float* __restrict__ C_, int ldc, int M, int N,
                                                        int K, int k_chunk, long slab_stride,
                                                        int tiles_m, int tiles_n, int nsplit,
                                                        const float* __restrict__ bias,
-                                                       float* __restrict__ colstats) {
+                                                       float* __restrict__ colstats,
+                                                       const float* const* __restrict__ batch) {
   static_assert(WM * WN == 4, "4 waves per workgroup");
   constexpr int TM = BM / WM / 16, TN = BN / WN / 16;
   static_assert(TM >= 1 && TN >= 1 && (BM % (WM * 16)) == 0 && (BN % (WN * 16)) == 0, "wave tile");
@@ -52,9 +53,15 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const float* __restric
   const int z = lid / tiles_m;
 
   const int m0 = tm * BM, n0 = tn * BN;
-  const int kbeg = z * k_chunk;
+  // batch != NULL: grid.z-like index z selects one of `nsplit` independent problems of identical shape
+  // (operand pointers from the table {A0,B0,C0,A1,B1,C1,...}); otherwise z is the K slice.
+  const float* __restrict__ A = batch ? batch[3 * z] : A_;
+  const float* __restrict__ B = batch ? batch[3 * z + 1] : B_;
+  float* __restrict__ C = batch ? const_cast<float*>(batch[3 * z + 2]) : C_;
+  const int kbeg = batch ? 0 : z * k_chunk;
   const int kend = min(K, kbeg + k_chunk);
   const int nt = (kend - kbeg + BK - 1) / BK;
+  const int zs = batch ? 0 : z;                    // slab index
 
   f32x4 acc[TM][TN];
 #pragma unroll
@@ -140,7 +147,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const float* __restric
     if (t + 1 < nt) step(P1(), std::false_type(), t + 1);
   }
 
-  gemm_epilogue<SA, SB, BM, BN, WM, WN, TM, TN>(acc, smem, C, ldc, M, N, m0, n0, tm, z, slab_stride, bias, colstats,
+  gemm_epilogue<SA, SB, BM, BN, WM, WN, TM, TN>(acc, smem, C, ldc, M, N, m0, n0, tm, zs, slab_stride, bias, colstats,
                                                 tid, lane, wm, wn);
 }
 
@@ -183,10 +190,10 @@ extern "C" int spnet_reduce_slabs(const float* ws, int nslab, int M, int N, floa
 template <int BM, int BN, int WM, int WN>
 static int launch_tile(const float* A, int amaj, int lda, const float* B, int bmaj, int ldb, float* C,
                        int ldc, int M, int N, int K, int nsplit, int k_chunk, long slab_stride,
-                       const float* bias, float* colstats, hipStream_t st) {
+                       const float* bias, float* colstats, const float* const* batch, hipStream_t st) {
   const int tm = spnet_cdiv(M, BM), tn = spnet_cdiv(N, BN);
   dim3 grid(tm * tn * nsplit), block(256);
-#define SP_ARGS A, lda, B, ldb, C, ldc, M, N, K, k_chunk, slab_stride, tm, tn, nsplit, bias, colstats
+#define SP_ARGS A, lda, B, ldb, C, ldc, M, N, K, k_chunk, slab_stride, tm, tn, nsplit, bias, colstats, batch
 #define SP_LAUNCH(KERNEL, BKV, AM, BMJ) \
   hipLaunchKernelGGL((KERNEL<BM, BN, BKV, WM, WN, AM, BMJ>), grid, block, 0, st, SP_ARGS)
 #define SP_FORMS(KERNEL, BKV)                                                                             \
@@ -233,7 +240,7 @@ static int auto_split(long tiles, int M, int N, int K, bool have_ws, long ws_flo
 // slab traffic of a K split.  The efficiencies were fitted on MI355X to the network's GEMM shapes
 // (tools/gemm_sweep.py; every shape of the 512x384 batch-32 step gets its measured-fastest tile) but the
 // model itself is shape-agnostic.  Forms: 0 = K/OUT (forward), 1 = K/K (dgrad), 2 = OUT/OUT (wgrad).
-static int pick_tile(int form, int M, int N, int K, int split_k, bool have_ws, long ws_floats) {
+static int pick_tile(int form, int M, int N, int K, int split_k, bool have_ws, long ws_floats, int nbatch = 1) {
   if (M <= 32) return 4;
   const int cand[7] = {1, 2, 3, 5, 6, 7, 8};
   static const double eff[3][7] = {{1.00, 0.95, 0.93, 0.93, 0.97, 1.00, 0.93},
@@ -248,7 +255,7 @@ static int pick_tile(int form, int M, int N, int K, int split_k, bool have_ws, l
     int ns = split_k > 0 ? split_k : auto_split(tiles, M, N, K, have_ws, ws_floats);
     const int kc = spnet_cdiv(spnet_cdiv(K, ns), SP_BK) * SP_BK;
     ns = spnet_cdiv(K, kc);
-    const double rounds = (double)((tiles * ns + 255) / 256);
+    const double rounds = (double)((tiles * ns * nbatch + 255) / 256) / nbatch;
     double cost = rounds * bm * bn * ((double)kc + 128.0) / eff[form][c];
     if (ns > 1) cost += 2.0 * ns * (double)M * N / 256.0;
     if (cost < best_cost) { best_cost = cost; best = cand[c]; }
@@ -258,16 +265,24 @@ static int pick_tile(int form, int M, int N, int K, int split_k, bool have_ws, l
 
 static int gemm_impl(const float* A, int a_major, int lda, const float* B, int b_major, int ldb, float* C,
                      int ldc, int M, int N, int K, int split_k, float* workspace, long ws_floats,
-                     const float* bias, int tile, float* colstats, int* stat_rows, void* stream) {
+                     const float* bias, int tile, float* colstats, int* stat_rows, void* stream,
+                     const float* const* batch = nullptr, int nbatch = 0) {
   hipStream_t st = (hipStream_t)stream;
+  if (batch) {                       // nbatch whole problems side by side: no K split, no workspace
+    if (nbatch < 1 || bias || colstats) return (int)hipErrorInvalidValue;
+    split_k = 1;
+    workspace = nullptr;
+    ws_floats = 0;
+  }
   if (colstats) split_k = 1;   // statistics are taken from complete dot products
   if (M <= 0 || N <= 0 || K <= 0) return (int)hipErrorInvalidValue;
   if ((lda & 3) || (ldb & 3) || (N & 3) || (ldc & 3)) return (int)hipErrorInvalidValue;
   if ((a_major == SP_K_MAJOR || b_major == SP_K_MAJOR) && (K & 3)) return (int)hipErrorInvalidValue;
   if (a_major == SP_OUT_MAJOR && (M & 3)) return (int)hipErrorInvalidValue;
-  if (((uintptr_t)A | (uintptr_t)B | (uintptr_t)C) & 15) return (int)hipErrorInvalidValue;
+  if (!batch && (((uintptr_t)A | (uintptr_t)B | (uintptr_t)C) & 15)) return (int)hipErrorInvalidValue;
   const int form = (a_major == SP_OUT_MAJOR) ? 2 : (b_major == SP_K_MAJOR ? 1 : 0);
-  if (tile <= 0 || tile > SP_NTILES) tile = pick_tile(form, M, N, K, split_k, workspace != nullptr, ws_floats);
+  if (tile <= 0 || tile > SP_NTILES)
+    tile = pick_tile(form, M, N, K, split_k, workspace != nullptr, ws_floats, batch ? nbatch : 1);
   int bm, bn;
   tile_dims(tile, &bm, &bn);
   const long tiles = (long)spnet_cdiv(M, bm) * spnet_cdiv(N, bn);
@@ -290,19 +305,20 @@ static int gemm_impl(const float* A, int a_major, int lda, const float* B, int b
     kbias = nullptr;
   }
   if (stat_rows) *stat_rows = spnet_cdiv(M, bm);
+  if (batch) nsplit = nbatch;        // the kernel's slice index selects the problem
   int rc;
   switch (tile) {
-    case 1: rc = launch_tile<128, 128, 2, 2>(A, a_major, lda, B, b_major, ldb, out, out_ld, M, N, K, nsplit, k_chunk, slab, kbias, colstats, st); break;
-    case 2: rc = launch_tile<128, 64, 2, 2>(A, a_major, lda, B, b_major, ldb, out, out_ld, M, N, K, nsplit, k_chunk, slab, kbias, colstats, st); break;
-    case 3: rc = launch_tile<64, 64, 2, 2>(A, a_major, lda, B, b_major, ldb, out, out_ld, M, N, K, nsplit, k_chunk, slab, kbias, colstats, st); break;
-    case 5: rc = launch_tile<96, 96, 2, 2>(A, a_major, lda, B, b_major, ldb, out, out_ld, M, N, K, nsplit, k_chunk, slab, kbias, colstats, st); break;
-    case 6: rc = launch_tile<96, 64, 2, 2>(A, a_major, lda, B, b_major, ldb, out, out_ld, M, N, K, nsplit, k_chunk, slab, kbias, colstats, st); break;
-    case 7: rc = launch_tile<64, 128, 2, 2>(A, a_major, lda, B, b_major, ldb, out, out_ld, M, N, K, nsplit, k_chunk, slab, kbias, colstats, st); break;
-    case 8: rc = launch_tile<128, 96, 2, 2>(A, a_major, lda, B, b_major, ldb, out, out_ld, M, N, K, nsplit, k_chunk, slab, kbias, colstats, st); break;
-    default: rc = launch_tile<32, 128, 1, 4>(A, a_major, lda, B, b_major, ldb, out, out_ld, M, N, K, nsplit, k_chunk, slab, kbias, colstats, st); break;
+    case 1: rc = launch_tile<128, 128, 2, 2>(A, a_major, lda, B, b_major, ldb, out, out_ld, M, N, K, nsplit, k_chunk, slab, kbias, colstats, batch, st); break;
+    case 2: rc = launch_tile<128, 64, 2, 2>(A, a_major, lda, B, b_major, ldb, out, out_ld, M, N, K, nsplit, k_chunk, slab, kbias, colstats, batch, st); break;
+    case 3: rc = launch_tile<64, 64, 2, 2>(A, a_major, lda, B, b_major, ldb, out, out_ld, M, N, K, nsplit, k_chunk, slab, kbias, colstats, batch, st); break;
+    case 5: rc = launch_tile<96, 96, 2, 2>(A, a_major, lda, B, b_major, ldb, out, out_ld, M, N, K, nsplit, k_chunk, slab, kbias, colstats, batch, st); break;
+    case 6: rc = launch_tile<96, 64, 2, 2>(A, a_major, lda, B, b_major, ldb, out, out_ld, M, N, K, nsplit, k_chunk, slab, kbias, colstats, batch, st); break;
+    case 7: rc = launch_tile<64, 128, 2, 2>(A, a_major, lda, B, b_major, ldb, out, out_ld, M, N, K, nsplit, k_chunk, slab, kbias, colstats, batch, st); break;
+    case 8: rc = launch_tile<128, 96, 2, 2>(A, a_major, lda, B, b_major, ldb, out, out_ld, M, N, K, nsplit, k_chunk, slab, kbias, colstats, batch, st); break;
+    default: rc = launch_tile<32, 128, 1, 4>(A, a_major, lda, B, b_major, ldb, out, out_ld, M, N, K, nsplit, k_chunk, slab, kbias, colstats, batch, st); break;
   }
   if (rc) return rc;
-  if (nsplit > 1) {
+  if (nsplit > 1 && !batch) {
     const long total4 = (long)M * N / 4;
     hipLaunchKernelGGL(reduce_slabs_kernel, dim3(spnet_ew_grid(total4, 256)), dim3(256), 0, st,
                        workspace, nsplit, M, N, C, ldc, bias);
@@ -316,6 +332,16 @@ extern "C" int spnet_gemm_f32(const float* A, int a_major, int lda, const float*
                               void* stream) {
   return gemm_impl(A, a_major, lda, B, b_major, ldb, C, ldc, M, N, K, split_k, workspace, ws_floats, bias,
                    tile, nullptr, nullptr, stream);
+}
+
+// nbatch independent problems of one shape in ONE launch (no K split): ptrs (device memory) holds
+// {A0, B0, C0, A1, B1, C1, ...}.  Used for the weight gradients of the eight middle-flow blocks, which
+// individually are too small to fill the chip without a K split.
+extern "C" int spnet_gemm_f32_batched(const float* const* ptrs, int nbatch, int a_major, int lda, int b_major,
+                                      int ldb, int ldc, int M, int N, int K, int tile, void* stream) {
+  if (!ptrs) return (int)hipErrorInvalidValue;
+  return gemm_impl(nullptr, a_major, lda, nullptr, b_major, ldb, nullptr, ldc, M, N, K, 1, nullptr, 0, nullptr, tile,
+                   nullptr, nullptr, stream, ptrs, nbatch);
 }
 
 // Forward-form GEMM that also emits BatchNorm column statistics of C: colstats[rows][2][N] holds per

@@ -16,6 +16,7 @@ Data layout in HBM
   BN moving statistics in a second flat buffer (non-trainable, not touched by the optimizer)
 """
 import math
+import os
 from collections import OrderedDict
 
 import numpy as np
@@ -158,6 +159,10 @@ class Engine:
         self.adam_eps = adam_eps
         self.t = 0                      # optimizer iterations done
         self.prof = None                # KernelTimer or None
+        self.deferred_wgrads = []       # (x, dy, gw, cin, cout, M) of layers whose dW waits for the batched launch
+        self._wgrad_table = None
+        self._first_middle = None
+        self.defer_mid_wgrad = os.environ.get("SPNET_DEFER_WGRAD", "1") != "0"
         self.overlap_wgrad = True       # pointwise weight gradients on a side stream (joined before Adam)
         # Optional: capture the single-GPU train step as a hipGraph after one eager step.  Off by default:
         # measured on MI355X / ROCm 7.2 the replay of this ~500-node two-stream graph takes 16.9 ms against
@@ -309,6 +314,8 @@ class Engine:
                 node = StridedBlock(self, x, b, cin, c1_, c2_, first_relu, cn, bnn)
             elif blk[0] == "middle":
                 node = MiddleBlock(self, x, blk[1], blk[2])
+                if self._first_middle is None:
+                    self._first_middle = node
             elif blk[0] == "exit":
                 node = ExitBlock(self, x, blk[2], blk[3], blk[4])
             else:
@@ -347,12 +354,52 @@ class Engine:
         """Back-propagates self.dout (filled by loss()) into self.grad.  on_node_done(node) is called
         after each node's launches are enqueued (used to start the gradient all-reduce early)."""
         g = self.dout
+        self.deferred_wgrads = []
         for node in reversed(self.nodes):
             g = node.bwd(g)
+            if node is self._first_middle:      # (flushing in 2 or 4 smaller batches measured no faster)
+                self.flush_deferred_wgrads()
             if on_node_done is not None:
                 on_node_done(node)
+        self.flush_deferred_wgrads()
         if self.wgrad_stream is not None:      # every weight gradient must have landed before the optimizer
             torch.cuda.current_stream().wait_stream(self.wgrad_stream)
+
+    def flush_deferred_wgrads(self):
+        """dW of every deferred pointwise layer in one batched launch (weight-gradient stream).  The operand
+        table lives in device memory and is rebuilt only if a buffer address changed (never, in practice:
+        the plan's buffers are static)."""
+        todo = self.deferred_wgrads
+        if not todo:
+            return
+        self.deferred_wgrads = []
+        x0, dy0, gw0, cin, cout, M = todo[0]
+        if any((t[3], t[4], t[5]) != (cin, cout, M) for t in todo):
+            raise RuntimeError("deferred weight gradients must share one shape")
+        ptrs = [p for (x, dy, gw, _, _, _) in todo for p in (x.data_ptr(), dy.data_ptr(), gw.data_ptr())]
+        if self._wgrad_table is None:
+            self._wgrad_table = {}
+        key = tuple(ptrs)
+        if key not in self._wgrad_table:
+            self._wgrad_table[key] = torch.tensor(ptrs, dtype=torch.int64, device=self.dev)
+        table = self._wgrad_table[key]
+        nb = len(todo)
+
+        def launch():
+            prof = self.prof
+            t0 = prof.start() if prof is not None else None
+            L.spnet_gemm_f32_batched(table.data_ptr(), nb, OUT_MAJOR, cin, OUT_MAJOR, cout, cout, cin, cout, M, 5,
+                                     _stream())
+            if prof is not None:
+                prof.stop("gemm", t0, 2.0 * nb * cin * cout * M)
+
+        side = self.wgrad_stream
+        if side is None:
+            launch()
+        else:
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                launch()
 
     def loss(self, Y=None, with_grad=True):
         if Y is not None:
@@ -586,10 +633,11 @@ class Dropout(Node):
 class Pointwise:
     """1x1 conv as GEMM over flattened pixels: y[M,cout] = x[M,cin] @ W[cin,cout]."""
 
-    def __init__(self, eng, M, cin, cout, wname):
+    def __init__(self, eng, M, cin, cout, wname, defer_wgrad=False):
         self.e, self.M, self.cin, self.cout = eng, M, cin, cout
         self.w = eng.P(wname)
         self.gw = eng.G(wname) if eng.train_capable else None
+        self.defer_wgrad = defer_wgrad      # dW is left to Engine.flush_deferred_wgrads() (one batched launch)
 
     def fwd(self, x, y):
         _gemm(x, K_MAJOR, self.cin, self.w, OUT_MAJOR, self.cout, y, self.cout, self.M, self.cout, self.cin, self.e)
@@ -606,7 +654,9 @@ class Pointwise:
         are not rewritten before that join (they are only produced once per step)."""
         e = self.e
         side = e.wgrad_stream
-        if side is None:
+        if self.defer_wgrad:
+            e.deferred_wgrads.append((x, dy, self.gw, self.cin, self.cout, self.M))
+        elif side is None:
             _gemm(x, OUT_MAJOR, self.cin, dy, OUT_MAJOR, self.cout, self.gw, self.cout, self.cin, self.cout, self.M, e)
         else:
             side.wait_stream(torch.cuda.current_stream())      # dy has just been produced on the main stream
@@ -751,7 +801,7 @@ class SepConvBN:
     """
 
     def __init__(self, eng, src, cin, cout, name, relu_in, mode="lazy", act=ACT_NONE, residual=None,
-                 bwd_inplace=True):
+                 bwd_inplace=True, defer_wgrad=False):
         self.e, self.src, self.cin, self.cout, self.relu_in = eng, src, cin, cout, int(relu_in)
         self.mode, self.act, self.residual, self.bwd_inplace = mode, act, residual, bwd_inplace
         B, H, W, _ = src.t.shape
@@ -760,7 +810,7 @@ class SepConvBN:
         self.wd = eng.P(name + "/depthwise_kernel")
         self.z = eng.new(B, H, W, cin)
         self.yp = eng.new(B, H, W, cout)
-        self.pw = Pointwise(eng, self.M, cin, cout, name + "/pointwise_kernel")
+        self.pw = Pointwise(eng, self.M, cin, cout, name + "/pointwise_kernel", defer_wgrad=defer_wgrad)
         self.bn = BN(eng, cout, self.M, name + "_bn")
         self.y = eng.new(B, H, W, cout) if mode == "apply" else None
         self.rows_src = L.spnet_dwconv3x3_tiled_rows(B, H, W, cin)   # partial rows this unit emits for src.bn
@@ -828,12 +878,16 @@ class MiddleBlock(Node):
 
     def __init__(self, eng, x, b, C):
         self.x = x
-        self.u1 = SepConvBN(eng, Ref(x), C, C, "block%d_sepconv1" % b, True, mode="lazy")
-        self.u2 = SepConvBN(eng, self.u1.ref(), C, C, "block%d_sepconv2" % b, True, mode="lazy")
+        # The 24 middle-flow weight gradients (728 x 728, K = batch*12*16 pixels) are each too small to fill
+        # the chip without a K split; their operands (z, dy) stay intact until the next step, so they are
+        # collected here and run as ONE batched GEMM once block 5 has been back-propagated.
+        d = eng.train_capable and eng.defer_mid_wgrad
+        self.u1 = SepConvBN(eng, Ref(x), C, C, "block%d_sepconv1" % b, True, mode="lazy", defer_wgrad=d)
+        self.u2 = SepConvBN(eng, self.u1.ref(), C, C, "block%d_sepconv2" % b, True, mode="lazy", defer_wgrad=d)
         # u3's BN backward writes to its own buffer: the incoming gradient is also the identity branch's
         # gradient and is added back in u1's depthwise backward.
         self.u3 = SepConvBN(eng, self.u2.ref(), C, C, "block%d_sepconv3" % b, True, mode="apply", residual=x,
-                            bwd_inplace=False)
+                            bwd_inplace=False, defer_wgrad=d)
         self.y = self.u3.y
 
     def fwd(self, training):

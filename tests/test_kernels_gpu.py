@@ -96,6 +96,28 @@ def test_gemm_wgrad_form(L, M, N, K, tile):
     close(c, X.astype(np.float64).T @ dY.astype(np.float64), rtol=2e-5, atol=3e-5 * np.sqrt(K))
 
 
+@pytest.mark.parametrize("tile", [0, 3, 5, 6])
+def test_gemm_batched_wgrad_form(L, tile):
+    """Several weight-gradient problems of one shape in one launch == the same problems one by one."""
+    rs = np.random.RandomState(11)
+    nb, M, N, K = 5, 72, 136, 700
+    Xs = [dev(rs.randn(K, M).astype(np.float32)) for _ in range(nb)]
+    Ds = [dev(rs.randn(K, N).astype(np.float32)) for _ in range(nb)]
+    Cs = [torch.full((M, N), float("nan"), device="cuda") for _ in range(nb)]
+    table = torch.tensor([p for b in range(nb) for p in (Xs[b].data_ptr(), Ds[b].data_ptr(), Cs[b].data_ptr())],
+                         dtype=torch.int64, device="cuda")
+    L.spnet_gemm_f32_batched(table.data_ptr(), nb, 1, M, 1, N, N, M, N, K, tile, st())
+    ws = torch.empty(WS, device="cuda")
+    for b in range(nb):
+        want = Xs[b].cpu().double().numpy().T @ Ds[b].cpu().double().numpy()
+        close(Cs[b], want, rtol=2e-5, atol=3e-5 * np.sqrt(K))
+        one = torch.empty(M, N, device="cuda")
+        L.spnet_gemm_f32(Xs[b].data_ptr(), 1, M, Ds[b].data_ptr(), 1, N, one.data_ptr(), N, M, N, K, 1, ws.data_ptr(), WS,
+                         None, tile if tile else 3, st())
+        if tile:
+            assert torch.equal(one, Cs[b])           # same tile, same k order -> same bits
+
+
 def test_gemm_rejects_misaligned(L):
     a = torch.zeros(64, 6, device="cuda")
     with pytest.raises(L.HipError):
