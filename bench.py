@@ -32,11 +32,12 @@ DW_FWD_BYTES_PER_IMAGE = 63.1e6
 
 
 def measured_traffic():
-    """HBM bytes per launch from the committed PMC pass (profiles/r01_c_hbm_traffic.json: rocprofv3 --pmc
+    """HBM bytes per family from the committed PMC pass (profiles/r01_m_hbm_traffic.json, folded by
+    tools/pmc_traffic.py: rocprofv3 --pmc
     FETCH_SIZE / WRITE_SIZE in separate passes over this same command, FETCH_SIZE doubled as
     MI355X_MICROARCH.md prescribes for gfx950).  Not a live measurement: PMC passes cannot run inside the
     timed benchmark."""
-    p = os.path.join(ROOT, "profiles", "r01_c_hbm_traffic.json")
+    p = os.path.join(ROOT, "profiles", "r01_m_hbm_traffic.json")
     if not os.path.exists(p):
         return {}
     with open(p) as f:
@@ -250,7 +251,10 @@ def main():
             for k, (n, ms, work) in tot.items():
                 fam[k] = dict(launches_per_step=n / args.steps, ms_per_step=round(ms / args.steps, 3))
             tr = measured_traffic()
-            g_traffic = tr.get("gemm", {}).get("hbm_bytes_per_launch")
+            g_traffic = None
+            if "gemm" in tr:    # PMC bytes of the family per step / this run's family launches per step
+                g_traffic = (tr["gemm"]["hbm_read_bytes_per_step"] + tr["gemm"]["hbm_write_bytes_per_step"]) / \
+                            (tot["gemm"][0] / args.steps)
             d_traffic = None
             if "dw_fwd" in tr and "dw_bwd" in tr:
                 d_traffic = (tr["dw_fwd"]["hbm_bytes_per_launch"] * tr["dw_fwd"]["launches"] +
@@ -260,11 +264,13 @@ def main():
             d_n, d_ms, d_bytes = tot["dw"]
             gemm_tflops = g_flop / (g_ms * 1e-3) / 1e12
             dw_gbs = DW_TRAIN_BYTES_PER_IMAGE * BATCH * args.steps / (d_ms * 1e-3) / 1e9
-            roof_gemm = {"kernel": "gemm_f32_kernel (pointwise / residual / block1_conv2 / Dense GEMMs, fwd+dgrad+wgrad, "
-                                   "incl. split-K slab reduce)",
+            roof_gemm = {"kernel": "fp32 MFMA GEMM family: gemm_f32_kernel (pointwise / residual / Dense, fwd+dgrad+wgrad, "
+                                   "incl. split-K slab reduce and the batched middle-flow dW launch) + "
+                                   "conv3x3_{fwd,dgrad,wgrad}_kernel (block1_conv2 implicit GEMMs)",
                          "bound": "mfma", "achieved": round(gemm_tflops, 2), "peak": FP32_MFMA_PEAK_TFLOPS,
                          "unit": "TFLOP/s", "frac": round(gemm_tflops / FP32_MFMA_PEAK_TFLOPS, 4),
                          "traffic": None if g_traffic is None else round(g_traffic),
+                         "algorithmic_flops_per_launch": round(g_flop / g_n),
                          "avg_launch_us": round(1e3 * g_ms / g_n, 2), "launches_per_step": g_n / args.steps,
                          "ms_per_step": round(g_ms / args.steps, 3)}
             roof_dw = {"kernel": "dw3x3_tile_fwd_kernel + dw3x3_tile_bwd_kernel (34 depthwise layers, fwd + fused bwd)",
