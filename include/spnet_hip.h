@@ -81,11 +81,12 @@ int spnet_dwconv3x3_tiled_fwd(const float* x, const float* w, float* y, int B, i
 long spnet_dwconv3x3_tiled_bwd_ws(int B, int H, int W, int C);
 long spnet_dwconv3x3_tiled_rows(int B, int H, int W, int C);
 /* in_scale/in_shift (or NULL): the producer BatchNorm's affine applied on load (x_fwd is then the PRE-BN
- * tensor); bn_partial (or NULL): also emit that BatchNorm's backward sums [rows][2][C]. */
+ * tensor); bn_partial (or NULL): also emit that BatchNorm's backward sums [rows][2][C]; bn_x (or NULL =
+ * x_fwd): the pre-BN tensor those sums refer to when x_fwd is not it (a block output BN(yp)+residual). */
 int spnet_dwconv3x3_tiled_bwd(const float* dy, const float* x_fwd, const float* w, float* dx, float* dw,
                               int B, int H, int W, int C, int relu_in, const float* add, float* workspace,
                               const float* in_scale, const float* in_shift, const float* bn_mean,
-                              const float* bn_invstd, float* bn_partial, void* stream);
+                              const float* bn_invstd, float* bn_partial, const float* bn_x, void* stream);
 
 /* ---- BatchNormalization(axis=-1, momentum .99, eps 1e-3) (spnet/models.py:326-336 + 40 in Xception) --- */
 /* act: 0 none, 1 ReLU, 2 LeakyReLU(0.1) fused behind the affine; residual (or NULL) added last;

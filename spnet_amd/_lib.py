@@ -42,7 +42,7 @@ _SIGS = {
     "spnet_dwconv3x3_tiled_fwd": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, P, P, P]),
     "spnet_dwconv3x3_tiled_bwd_ws": (c_long, [c_int, c_int, c_int, c_int]),
     "spnet_dwconv3x3_tiled_rows": (c_long, [c_int, c_int, c_int, c_int]),
-    "spnet_dwconv3x3_tiled_bwd": (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, P, P, P, P, P, P, P, P]),
+    "spnet_dwconv3x3_tiled_bwd": (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, P, P, P, P, P, P, P, P, P]),
     "spnet_bn_finalize_fwd": (c_int, [P, c_int, c_long, c_int, P, P, P, P, P, P, P, c_float, c_float, P]),
     "spnet_bn_infer_coeffs": (c_int, [c_int, P, P, P, P, P, c_float, P]),
     "spnet_bn_apply": (c_int, [P, c_long, c_int, P, c_int, P, c_int, P, P]),

@@ -311,7 +311,7 @@ __global__ __launch_bounds__(256) void dw3x3_tile_bwd_kernel(
     float* __restrict__ dx, float* __restrict__ partial, const float* __restrict__ add, int H, int W,
     int C, int relu_in, int tiles_h, int tiles_w, int cchunks, const float* __restrict__ in_scale,
     const float* __restrict__ in_shift, const float* __restrict__ bn_mean,
-    const float* __restrict__ bn_invstd, float* __restrict__ bn_partial) {
+    const float* __restrict__ bn_invstd, float* __restrict__ bn_partial, const float* __restrict__ bn_x) {
   constexpr int PW = TW + 2;
   constexpr int CC2 = 2 * CC4;
   constexpr int TILE = (TH + 2) * PW * CC4;          // float4 per tile
@@ -361,10 +361,11 @@ __global__ __launch_bounds__(256) void dw3x3_tile_bwd_kernel(
       m0 = tdz[o0]; m1 = tdz[o0 + CC2]; m2 = tdz[o0 + 2 * CC2];
       c0 = tdz[o1]; c1 = tdz[o1 + CC2]; c2r = tdz[o1 + 2 * CC2];
     }
-    float2 x_nxt = zero2, add_nxt = zero2;
+    float2 x_nxt = zero2, add_nxt = zero2, bx_nxt = zero2;
     if (h0 < H) {
       x_nxt = *reinterpret_cast<const float2*>(x + cbase + (long)h0 * W * C);
       if (add) add_nxt = *reinterpret_cast<const float2*>(add + cbase + (long)h0 * W * C);
+      if (bn_x) bx_nxt = *reinterpret_cast<const float2*>(bn_x + cbase + (long)h0 * W * C);
     }
 #pragma unroll 2
     for (int t = 1; t <= TH; ++t) {
@@ -373,9 +374,11 @@ __global__ __launch_bounds__(256) void dw3x3_tile_bwd_kernel(
       const int o2 = (((t + 1) * PW + tcol) * CC4) * 2 + l2;
       n0 = tdz[o2]; n1 = tdz[o2 + CC2]; n2 = tdz[o2 + 2 * CC2];
       const float2 raw = x_nxt, ad = add_nxt;
+      const float2 pre = bn_x ? bx_nxt : raw;         // pre-BN value the statistics' BatchNorm normalised
       if (t < TH && ho + 1 < H) {                     // next centre row, one iteration ahead
         x_nxt = *reinterpret_cast<const float2*>(x + cbase + (long)(ho + 1) * W * C);
         if (add) add_nxt = *reinterpret_cast<const float2*>(add + cbase + (long)(ho + 1) * W * C);
+        if (bn_x) bx_nxt = *reinterpret_cast<const float2*>(bn_x + cbase + (long)(ho + 1) * W * C);
       }
       float2 a = raw;
       if (affine) a = make_float2(fmaf(raw.x, sc.x, sh.x), fmaf(raw.y, sc.y, sh.y));
@@ -395,10 +398,10 @@ __global__ __launch_bounds__(256) void dw3x3_tile_bwd_kernel(
       }
       if (add) { res.x += ad.x; res.y += ad.y; }
       *reinterpret_cast<float2*>(dx + cbase + (long)ho * W * C) = res;
-      if (bn_partial) {   // res = dL/d(BN output of the producer); xhat from the raw pre-BN value
+      if (bn_partial) {   // res = dL/d(BN output of the producer); xhat from the pre-BN value
         bsg.x += res.x; bsg.y += res.y;
-        bsgx.x = fmaf(res.x, (raw.x - mu.x) * is.x, bsgx.x);
-        bsgx.y = fmaf(res.y, (raw.y - mu.y) * is.y, bsgx.y);
+        bsgx.x = fmaf(res.x, (pre.x - mu.x) * is.x, bsgx.x);
+        bsgx.y = fmaf(res.y, (pre.y - mu.y) * is.y, bsgx.y);
       }
       m0 = c0; m1 = c1; m2 = c2r;
       c0 = n0; c1 = n1; c2r = n2;
@@ -573,23 +576,27 @@ extern "C" long spnet_dwconv3x3_tiled_bwd_ws(int B, int H, int W, int C) {
 // Fused backward: dx = dw3x3(dy, flip w) * (xin > 0 if relu_in) (+ add);  dw[3][3][C] = weight gradient,
 // xin = x_fwd*in_scale + in_shift when the producer's BatchNorm affine is fused (else x_fwd).  With
 // bn_partial != NULL the kernel also emits the producer BatchNorm's backward sums (sum dx, sum dx*xhat)
-// as [rows][2][C] partials, rows = spnet_dwconv3x3_tiled_rows().
+// as [rows][2][C] partials, rows = spnet_dwconv3x3_tiled_rows().  bn_x (or NULL = x_fwd): the tensor that
+// BatchNorm normalised, when it is not this layer's input itself -- a middle block's first unit reads the
+// previous block's OUTPUT y = BN(yp) + residual, and produces the sums of that BN from yp.
 extern "C" int spnet_dwconv3x3_tiled_bwd(const float* dy, const float* x_fwd, const float* w, float* dx,
                                          float* dw, int B, int H, int W, int C, int relu_in,
                                          const float* add, float* workspace, const float* in_scale,
                                          const float* in_shift, const float* bn_mean,
-                                         const float* bn_invstd, float* bn_partial, void* stream) {
+                                         const float* bn_invstd, float* bn_partial, const float* bn_x,
+                                         void* stream) {
   if (bn_partial && (!bn_mean || !bn_invstd)) return (int)hipErrorInvalidValue;
+  if (bn_x && !bn_partial) return (int)hipErrorInvalidValue;
   if (C & 3) return (int)hipErrorInvalidValue;
   const DwGeom g = dw_geom(B, H, W, C, false);
   if (g.cfg == 1)
     hipLaunchKernelGGL((dw3x3_tile_bwd_kernel<16, 8, 6>), dim3((unsigned)g.nblk), dim3(256), g.lds_bwd,
                        (hipStream_t)stream, dy, x_fwd, w, dx, workspace, add, H, W, C, relu_in, g.tiles_h,
-                       g.tiles_w, g.cchunks, in_scale, in_shift, bn_mean, bn_invstd, bn_partial);
+                       g.tiles_w, g.cchunks, in_scale, in_shift, bn_mean, bn_invstd, bn_partial, bn_x);
   else
     hipLaunchKernelGGL((dw3x3_tile_bwd_kernel<8, 16, 12>), dim3((unsigned)g.nblk), dim3(256), g.lds_bwd,
                        (hipStream_t)stream, dy, x_fwd, w, dx, workspace, add, H, W, C, relu_in, g.tiles_h,
-                       g.tiles_w, g.cchunks, in_scale, in_shift, bn_mean, bn_invstd, bn_partial);
+                       g.tiles_w, g.cchunks, in_scale, in_shift, bn_mean, bn_invstd, bn_partial, bn_x);
   const int P = B * g.tiles_h * g.tiles_w, L = 9 * C;
   launch_reduce_rows(workspace, P, L, dw, workspace + (long)P * L, (hipStream_t)stream);
   SPNET_RETURN_LAUNCH_STATUS();

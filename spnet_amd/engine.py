@@ -308,12 +308,14 @@ class Engine:
         e2 = Conv3x3Gemm(self, b1.y, 32, 64, "block1_conv2"); n.append(e2)
         b2 = BatchNorm(self, e2.y, 64, "block1_conv2_bn", ACT_RELU); n.append(b2)
         x = b2.y
+        prev_middle = None
         for blk in xception_plan():
             if blk[0] == "strided":
                 _, b, cin, c1_, c2_, first_relu, cn, bnn = blk
                 node = StridedBlock(self, x, b, cin, c1_, c2_, first_relu, cn, bnn)
             elif blk[0] == "middle":
-                node = MiddleBlock(self, x, blk[1], blk[2])
+                node = MiddleBlock(self, x, blk[1], blk[2], prev=prev_middle)
+                prev_middle = node
                 if self._first_middle is None:
                     self._first_middle = node
             elif blk[0] == "exit":
@@ -321,6 +323,7 @@ class Engine:
             else:
                 continue
             n.append(node)
+            prev_middle = node if blk[0] == "middle" else None
             x = node.y
         self.backbone_out = x
         head = Dense(self, x, self.n_out, "FinalOutput"); n.append(head)
@@ -787,8 +790,11 @@ class Ref:
     """A tensor as consumers see it: `t` in HBM, plus (optionally) the BatchNorm whose affine still has to
     be applied on load because the normalised tensor was never materialised."""
 
-    def __init__(self, t, bn=None):
+    def __init__(self, t, bn=None, stats_bn=None, stats_x=None):
         self.t, self.bn = t, bn
+        # A consumer's fused depthwise backward emits the backward sums of `stats_bn` (default: bn), whose
+        # pre-normalisation tensor is `stats_x` (default: t).  Set when t is a block OUTPUT BN(stats_x)+residual.
+        self.stats_bn, self.stats_x = stats_bn, stats_x
 
 
 class SepConvBN:
@@ -855,19 +861,20 @@ class SepConvBN:
         the source as its consumers see it (wrt src's BN output when src is lazy), plus `add`."""
         e, sb = self.e, self.src.bn
         out = g if self.bwd_inplace else self.dbn
-        if self.mode == "lazy":
+        if self.mode == "lazy" or (self.consumer_rows and self.act == ACT_NONE):
             dy = self.bn.bwd_from_partials(self.yp, g, out, self.consumer_rows)
         else:
             dy = self.bn.bwd_full(self.yp, g, out, self.act if self.mode == "apply" else ACT_NONE)
         self.pw.bwd(self.z, dy, self.dz)
+        st = self.src.stats_bn if self.src.stats_bn is not None else sb     # whose backward sums to emit
         prof = e.prof
         if prof is not None:
             t0 = prof.start()
         L.spnet_dwconv3x3_tiled_bwd(L.ptr(self.dz), L.ptr(self.src.t), L.ptr(self.wd), L.ptr(self.dx), L.ptr(self.gwd),
                                     e.B, self.H, self.W, self.cin, self.relu_in, L.ptr(add), e.ws_ptr(WS_DW),
                                     sb.scale_ptr if sb else None, sb.shift_ptr if sb else None,
-                                    sb.mean_ptr if sb else None, sb.invstd_ptr if sb else None,
-                                    e.ws_ptr(WS_BNP) if sb else None, _stream())
+                                    st.mean_ptr if st else None, st.invstd_ptr if st else None,
+                                    e.ws_ptr(WS_BNP) if st else None, L.ptr(self.src.stats_x), _stream())
         if prof is not None:
             prof.stop("dw", t0, 3.0 * 4 * self.M * self.cin)        # read dz, read x, write dx
         return self.dx
@@ -876,13 +883,20 @@ class SepConvBN:
 class MiddleBlock(Node):
     """Xception blocks 5-12: x + [relu, sepconv, BN] x 3.  Only the block output is materialised."""
 
-    def __init__(self, eng, x, b, C):
+    def __init__(self, eng, x, b, C, prev=None):
+        """prev: the middle block whose output is x -- its closing BatchNorm's backward sums then come out of
+        this block's first depthwise backward (which reads yp of that BN beside x), saving a reduction pass."""
         self.x = x
+        src = Ref(x)
+        if prev is not None and eng.train_capable:
+            src = Ref(x, stats_bn=prev.u3.bn, stats_x=prev.u3.yp)
         # The 24 middle-flow weight gradients (728 x 728, K = batch*12*16 pixels) are each too small to fill
         # the chip without a K split; their operands (z, dy) stay intact until the next step, so they are
         # collected here and run as ONE batched GEMM once block 5 has been back-propagated.
         d = eng.train_capable and eng.defer_mid_wgrad
-        self.u1 = SepConvBN(eng, Ref(x), C, C, "block%d_sepconv1" % b, True, mode="lazy", defer_wgrad=d)
+        self.u1 = SepConvBN(eng, src, C, C, "block%d_sepconv1" % b, True, mode="lazy", defer_wgrad=d)
+        if src.stats_bn is not None:
+            prev.u3.consumer_rows = self.u1.rows_src
         self.u2 = SepConvBN(eng, self.u1.ref(), C, C, "block%d_sepconv2" % b, True, mode="lazy", defer_wgrad=d)
         # u3's BN backward writes to its own buffer: the incoming gradient is also the identity branch's
         # gradient and is added back in u1's depthwise backward.

@@ -191,7 +191,7 @@ def test_dwconv_tiled(L, B, H, W, C, relu_in, fused_bn):
     bnp = torch.full((rows, 2, C), float("nan"), device="cuda") if fused_bn else None
     dxd, dwd = torch.full_like(xd, float("nan")), torch.full((3, 3, C), float("nan"), device="cuda")
     L.spnet_dwconv3x3_tiled_bwd(dyd.data_ptr(), xd.data_ptr(), wd.data_ptr(), dxd.data_ptr(), dwd.data_ptr(), B, H, W, C,
-                                relu_in, addd.data_ptr(), ws.data_ptr(), P(scd), P(shd), P(mud), P(isd), P(bnp), st())
+                                relu_in, addd.data_ptr(), ws.data_ptr(), P(scd), P(shd), P(mud), P(isd), P(bnp), None, st())
     if fused_bn:
         # dx is the gradient wrt the BatchNorm OUTPUT a (incl. the added branch); the two sums are dbeta / dgamma/gamma-free
         close(dxd, a.grad, rtol=1e-5, atol=2e-5)
@@ -201,9 +201,45 @@ def test_dwconv_tiled(L, B, H, W, C, relu_in, fused_bn):
     else:
         close(dxd, x.grad + add, rtol=1e-5, atol=1e-5)
         L.spnet_dwconv3x3_tiled_bwd(dyd.data_ptr(), xd.data_ptr(), wd.data_ptr(), dxd.data_ptr(), dwd.data_ptr(), B, H, W,
-                                    C, relu_in, None, ws.data_ptr(), None, None, None, None, None, st())
+                                    C, relu_in, None, ws.data_ptr(), None, None, None, None, None, None, st())
         close(dxd, x.grad, rtol=1e-5, atol=1e-5)
     close(dwd, w.grad, rtol=1e-4, atol=1e-4 * np.sqrt(B * H * W))
+
+
+@pytest.mark.parametrize("B,H,W,C", [(2, 12, 16, 728), (2, 6, 8, 1536), (1, 13, 17, 40)])
+def test_dwconv_tiled_bwd_sums_for_a_block_output(L, B, H, W, C):
+    """bn_x: the layer reads a block OUTPUT y = BN(yp) + residual (ReLU on load, no affine) and still emits the
+    backward sums of that BatchNorm, taking xhat from yp."""
+    rs = np.random.RandomState(C + W)
+    yp = torch.tensor(rs.randn(B, H, W, C), dtype=torch.float32)
+    res = torch.tensor(rs.randn(B, H, W, C), dtype=torch.float32)
+    w = torch.tensor(rs.randn(3, 3, C) * 0.3, dtype=torch.float32)
+    add = torch.tensor(rs.randn(B, H, W, C), dtype=torch.float32)
+    gamma, beta = torch.tensor(rs.rand(C) + 0.5, dtype=torch.float32), torch.tensor(rs.randn(C) * 0.3, dtype=torch.float32)
+    flat = yp.reshape(-1, C)
+    mu, invstd = flat.mean(0), torch.rsqrt(flat.var(0, unbiased=False) + 1e-3)
+    xhat = (yp - mu) * invstd
+    y = (xhat * gamma + beta + res).requires_grad_(True)
+    z = T.dwconv3x3(torch.relu(y), w)
+    dz = torch.tensor(rs.randn(B, H, W, C), dtype=torch.float32)
+    ((z * dz).sum() + (y * add).sum()).backward()
+    g = y.grad                                          # gradient wrt the block output = wrt the BN output
+    yd, ypd, wd, dzd, addd = y.detach().cuda(), yp.cuda(), w.cuda(), dz.cuda(), add.cuda()
+    ws = torch.empty(L.spnet_dwconv3x3_tiled_bwd_ws(B, H, W, C), device="cuda")
+    rows = L.spnet_dwconv3x3_tiled_rows(B, H, W, C)
+    bnp = torch.full((rows, 2, C), float("nan"), device="cuda")
+    dxd, dwd = torch.full_like(yd, float("nan")), torch.full((3, 3, C), float("nan"), device="cuda")
+    mud, isd = mu.cuda(), invstd.cuda()
+    L.spnet_dwconv3x3_tiled_bwd(dzd.data_ptr(), yd.data_ptr(), wd.data_ptr(), dxd.data_ptr(), dwd.data_ptr(), B, H, W, C, 1,
+                                addd.data_ptr(), ws.data_ptr(), None, None, mud.data_ptr(), isd.data_ptr(), bnp.data_ptr(),
+                                ypd.data_ptr(), st())
+    close(dxd, g, rtol=1e-5, atol=2e-5)
+    sums = bnp.sum(0).cpu()
+    close(sums[0], g.reshape(-1, C).sum(0), rtol=1e-4, atol=1e-4 * np.sqrt(B * H * W))
+    close(sums[1], (g * xhat).reshape(-1, C).sum(0), rtol=1e-4, atol=2e-4 * np.sqrt(B * H * W))
+    with pytest.raises(L.HipError):                     # bn_x without bn_partial makes no sense
+        L.spnet_dwconv3x3_tiled_bwd(dzd.data_ptr(), yd.data_ptr(), wd.data_ptr(), dxd.data_ptr(), dwd.data_ptr(), B, H, W, C,
+                                    1, None, ws.data_ptr(), None, None, None, None, None, ypd.data_ptr(), st())
 
 
 @pytest.mark.parametrize("M,N,K", [(6144, 728, 728), (372, 128, 64), (1536, 2048, 1536), (100, 64, 288), (33, 72, 40)])
