@@ -74,6 +74,10 @@ long spnet_dwconv3x3_bwd_weight_ws(int B, int H, int W, int C);
 int spnet_dwconv3x3_bwd_weight(const float* x, const float* dy, float* dw, int B, int H, int W, int C,
                                int relu_in, float* workspace, void* stream);
 int spnet_reduce_rows(const float* in, int P, int L, float* out, void* stream);
+/* njobs independent row reductions in one launch; jobs: DEVICE array of {in, out, P, L} (four 64-bit words
+ * per job), max_L = largest L.  (All depthwise weight gradients of a step: spnet_dwconv3x3_tiled_bwd with
+ * dw == NULL leaves its partial sums in the workspace.) */
+int spnet_reduce_rows_batched(const void* jobs, int njobs, int max_L, void* stream);
 /* LDS-tiled forms used by the engine: forward, and the FUSED backward (data + weight gradient in one
  * pass over x and dy).  workspace: spnet_dwconv3x3_tiled_bwd_ws(B,H,W,C) floats. */
 int spnet_dwconv3x3_tiled_fwd(const float* x, const float* w, float* y, int B, int H, int W, int C,
@@ -82,7 +86,8 @@ long spnet_dwconv3x3_tiled_bwd_ws(int B, int H, int W, int C);
 long spnet_dwconv3x3_tiled_rows(int B, int H, int W, int C);
 /* in_scale/in_shift (or NULL): the producer BatchNorm's affine applied on load (x_fwd is then the PRE-BN
  * tensor); bn_partial (or NULL): also emit that BatchNorm's backward sums [rows][2][C]; bn_x (or NULL =
- * x_fwd): the pre-BN tensor those sums refer to when x_fwd is not it (a block output BN(yp)+residual). */
+ * x_fwd): the pre-BN tensor those sums refer to when x_fwd is not it (a block output BN(yp)+residual).
+ * dw == NULL: the [rows][9][C] weight-gradient partial sums stay in `workspace` for a later reduction. */
 int spnet_dwconv3x3_tiled_bwd(const float* dy, const float* x_fwd, const float* w, float* dx, float* dw,
                               int B, int H, int W, int C, int relu_in, const float* add, float* workspace,
                               const float* in_scale, const float* in_shift, const float* bn_mean,

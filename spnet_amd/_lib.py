@@ -39,6 +39,7 @@ _SIGS = {
     "spnet_dwconv3x3_bwd_weight_ws": (c_long, [c_int, c_int, c_int, c_int]),
     "spnet_dwconv3x3_bwd_weight": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, P, P]),
     "spnet_reduce_rows": (c_int, [P, c_int, c_int, P, P]),
+    "spnet_reduce_rows_batched": (c_int, [P, c_int, c_int, P]),
     "spnet_dwconv3x3_tiled_fwd": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, P, P, P]),
     "spnet_dwconv3x3_tiled_bwd_ws": (c_long, [c_int, c_int, c_int, c_int]),
     "spnet_dwconv3x3_tiled_rows": (c_long, [c_int, c_int, c_int, c_int]),

@@ -522,6 +522,41 @@ extern "C" int spnet_dwconv3x3_bwd_weight(const float* x, const float* dy, float
   SPNET_RETURN_LAUNCH_STATUS();
 }
 
+// Many independent row reductions in one launch: job j folds in_j[P_j][L_j] into out_j[L_j].  jobs (device
+// memory) = njobs x {in pointer, out pointer, P, L} as four 64-bit words.  Same fixed order as
+// reduce_rows_kernel with one slice: 16 interleaved row groups, then the groups in order.
+__global__ __launch_bounds__(256) void reduce_rows_batched_kernel(const long long* __restrict__ jobs) {
+  __shared__ float red[16][16];
+  const long long* jb = jobs + 4 * blockIdx.y;
+  const float* __restrict__ in = reinterpret_cast<const float*>(jb[0]);
+  float* __restrict__ out = reinterpret_cast<float*>(jb[1]);
+  const int P = (int)jb[2], L = (int)jb[3];
+  if ((int)blockIdx.x * 16 >= L) return;           // whole workgroup leaves together
+  const int lane = threadIdx.x & 15, g = threadIdx.x >> 4;
+  const int col = blockIdx.x * 16 + lane;
+  float s = 0.f;
+  if (col < L) {
+#pragma unroll 4
+    for (int p = g; p < P; p += 16) s += in[(long)p * L + col];
+  }
+  red[g][lane] = s;
+  __syncthreads();
+  if (g == 0 && col < L) {
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) t += red[k][lane];
+    out[col] = t;
+  }
+}
+
+// max_L: the largest L_j (sizes the grid).
+extern "C" int spnet_reduce_rows_batched(const void* jobs, int njobs, int max_L, void* stream) {
+  if (!jobs || njobs < 1 || max_L < 1) return (int)hipErrorInvalidValue;
+  hipLaunchKernelGGL(reduce_rows_batched_kernel, dim3((max_L + 15) / 16, njobs), dim3(256), 0, (hipStream_t)stream,
+                     reinterpret_cast<const long long*>(jobs));
+  SPNET_RETURN_LAUNCH_STATUS();
+}
+
 extern "C" int spnet_reduce_rows(const float* in, int P, int L, float* out, void* stream) {
   launch_reduce_rows(in, P, L, out, nullptr, (hipStream_t)stream);
   SPNET_RETURN_LAUNCH_STATUS();
@@ -598,6 +633,8 @@ extern "C" int spnet_dwconv3x3_tiled_bwd(const float* dy, const float* x_fwd, co
                        (hipStream_t)stream, dy, x_fwd, w, dx, workspace, add, H, W, C, relu_in, g.tiles_h,
                        g.tiles_w, g.cchunks, in_scale, in_shift, bn_mean, bn_invstd, bn_partial, bn_x);
   const int P = B * g.tiles_h * g.tiles_w, L = 9 * C;
-  launch_reduce_rows(workspace, P, L, dw, workspace + (long)P * L, (hipStream_t)stream);
+  // dw == NULL: leave the [rows][9][C] partial sums in `workspace`; the caller folds them later
+  // (spnet_reduce_rows_batched does it for all layers of a step in one launch, off the critical path)
+  if (dw) launch_reduce_rows(workspace, P, L, dw, workspace + (long)P * L, (hipStream_t)stream);
   SPNET_RETURN_LAUNCH_STATUS();
 }

@@ -160,6 +160,8 @@ class Engine:
         self.t = 0                      # optimizer iterations done
         self.prof = None                # KernelTimer or None
         self.deferred_wgrads = []       # (x, dy, gw, cin, cout, M) of layers whose dW waits for the batched launch
+        self.dw_reduce_jobs = []        # (partials, grad, rows, 9*C) of every depthwise layer
+        self._dw_reduce_table = None
         self._wgrad_table = None
         self._first_middle = None
         self.defer_mid_wgrad = os.environ.get("SPNET_DEFER_WGRAD", "1") != "0"
@@ -365,8 +367,28 @@ class Engine:
             if on_node_done is not None:
                 on_node_done(node)
         self.flush_deferred_wgrads()
+        self.reduce_depthwise_wgrads()
         if self.wgrad_stream is not None:      # every weight gradient must have landed before the optimizer
             torch.cuda.current_stream().wait_stream(self.wgrad_stream)
+
+    def reduce_depthwise_wgrads(self):
+        """Fold the partial sums every fused depthwise backward left behind into the 34 depthwise weight
+        gradients: one launch (weight-gradient stream) instead of one small kernel per layer on the
+        data-gradient chain."""
+        jobs = self.dw_reduce_jobs
+        if not jobs:
+            return
+        if self._dw_reduce_table is None:
+            flat = [v for (part, grad, rows, Lr) in jobs for v in (part.data_ptr(), grad.data_ptr(), rows, Lr)]
+            self._dw_reduce_table = torch.tensor(flat, dtype=torch.int64, device=self.dev)
+        max_L = max(j[3] for j in jobs)
+        side = self.wgrad_stream
+        if side is None:
+            L.spnet_reduce_rows_batched(self._dw_reduce_table.data_ptr(), len(jobs), max_L, _stream())
+        else:
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                L.spnet_reduce_rows_batched(self._dw_reduce_table.data_ptr(), len(jobs), max_L, _stream())
 
     def flush_deferred_wgrads(self):
         """dW of every deferred pointwise layer in one batched launch (weight-gradient stream).  The operand
@@ -820,13 +842,17 @@ class SepConvBN:
         self.bn = BN(eng, cout, self.M, name + "_bn")
         self.y = eng.new(B, H, W, cout) if mode == "apply" else None
         self.rows_src = L.spnet_dwconv3x3_tiled_rows(B, H, W, cin)   # partial rows this unit emits for src.bn
-        if L.spnet_dwconv3x3_tiled_bwd_ws(B, H, W, cin) > WS_DW[1] or self.rows_src * 2 * cin > WS_BNP[1]:
+        if self.rows_src * 2 * cin > WS_BNP[1]:
             raise RuntimeError("workspace regions too small for %s" % name)
         self.consumer_rows = 0              # set by the consumer (lazy mode)
         if eng.train_capable:
             self.gwd = eng.G(name + "/depthwise_kernel")
             self.dz = eng.new(B, H, W, cin)
             self.dx = eng.new(B, H, W, cin)
+            # This unit's depthwise weight-gradient partial sums [rows][9][cin]: kept in a buffer of its own so
+            # that ALL units' reductions run as one launch at the end of backward, off the dependency chain.
+            self.wpart = eng.new(L.spnet_dwconv3x3_tiled_bwd_ws(B, H, W, cin))
+            eng.dw_reduce_jobs.append((self.wpart, self.gwd, self.rows_src, 9 * cin))
             self.dbn = None if bwd_inplace else eng.new(B, H, W, cout)
         if src.bn is not None and hasattr(src, "owner"):
             src.owner.consumer_rows = self.rows_src
@@ -870,8 +896,8 @@ class SepConvBN:
         prof = e.prof
         if prof is not None:
             t0 = prof.start()
-        L.spnet_dwconv3x3_tiled_bwd(L.ptr(self.dz), L.ptr(self.src.t), L.ptr(self.wd), L.ptr(self.dx), L.ptr(self.gwd),
-                                    e.B, self.H, self.W, self.cin, self.relu_in, L.ptr(add), e.ws_ptr(WS_DW),
+        L.spnet_dwconv3x3_tiled_bwd(L.ptr(self.dz), L.ptr(self.src.t), L.ptr(self.wd), L.ptr(self.dx), None,
+                                    e.B, self.H, self.W, self.cin, self.relu_in, L.ptr(add), L.ptr(self.wpart),
                                     sb.scale_ptr if sb else None, sb.shift_ptr if sb else None,
                                     st.mean_ptr if st else None, st.invstd_ptr if st else None,
                                     e.ws_ptr(WS_BNP) if st else None, L.ptr(self.src.stats_x), _stream())

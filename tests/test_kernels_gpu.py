@@ -118,6 +118,23 @@ def test_gemm_batched_wgrad_form(L, tile):
             assert torch.equal(one, Cs[b])           # same tile, same k order -> same bits
 
 
+def test_reduce_rows_batched(L):
+    """Several [P][L] -> [L] reductions in one launch, same bits as one spnet_reduce_rows call each."""
+    rs = np.random.RandomState(4)
+    shapes = [(32, 9 * 728), (2048, 9 * 64), (1, 40), (130, 9 * 1536), (17, 5)]
+    ins = [dev(rs.randn(P, Lr).astype(np.float32)) for P, Lr in shapes]
+    outs = [torch.full((Lr,), float("nan"), device="cuda") for _, Lr in shapes]
+    jobs = torch.tensor([v for i, (P, Lr) in enumerate(shapes) for v in (ins[i].data_ptr(), outs[i].data_ptr(), P, Lr)],
+                        dtype=torch.int64, device="cuda")
+    L.spnet_reduce_rows_batched(jobs.data_ptr(), len(shapes), max(s[1] for s in shapes), st())
+    for i, (P, Lr) in enumerate(shapes):
+        close(outs[i], ins[i].cpu().double().numpy().sum(0), rtol=1e-5, atol=1e-4)
+        if P <= 128:      # spnet_reduce_rows switches to two passes above 128 rows (different rounding order)
+            one = torch.empty(Lr, device="cuda")
+            L.spnet_reduce_rows(ins[i].data_ptr(), P, Lr, one.data_ptr(), st())
+            assert torch.equal(one, outs[i])
+
+
 def test_gemm_rejects_misaligned(L):
     a = torch.zeros(64, 6, device="cuda")
     with pytest.raises(L.HipError):
