@@ -39,10 +39,12 @@ int spnet_gemm_f32(const float* A, int a_major, int lda, const float* B, int b_m
 int spnet_gemm_f32_colstats(const float* A, int a_major, int lda, const float* B, int b_major, int ldb,
                             float* C, int ldc, int M, int N, int K, int tile, float* colstats,
                             int* stat_rows, void* stream);
-/* nbatch independent problems of ONE shape in one launch, no K split: ptrs is a DEVICE array
- * {A0,B0,C0, A1,B1,C1, ...} of 16-byte aligned operands (the engine's deferred middle-flow weight gradients). */
-int spnet_gemm_f32_batched(const float* const* ptrs, int nbatch, int a_major, int lda, int b_major, int ldb,
-                           int ldc, int M, int N, int K, int tile, void* stream);
+/* nbatch independent problems of ONE shape in one launch, no K split.  A0/B0/C0: operands of problem 0;
+ * offsets: DEVICE array {A_b - A0, B_b - B0, C_b - C0} in floats (multiples of 4), b = 0..nbatch-1
+ * (the engine's deferred middle-flow weight gradients). */
+int spnet_gemm_f32_batched(const float* A0, const float* B0, float* C0, const long long* offsets, int nbatch,
+                           int a_major, int lda, int b_major, int ldb, int ldc, int M, int N, int K, int tile,
+                           void* stream);
 
 /* 3x3 VALID stride-1 patch matrix and its adjoint (block1_conv2 of keras Xception). */
 int spnet_im2col3x3(const float* x, float* col, int B, int H, int W, int C, void* stream);

@@ -49,7 +49,7 @@ _SIGS = {
     "spnet_bn_apply": (c_int, [P, c_long, c_int, P, c_int, P, c_int, P, P]),
     "spnet_bn_bwd_from_partials": (c_int, [P, P, c_long, c_int, P, P, P, P, c_int, P, P, P, P, P, P]),
     "spnet_gemm_f32_colstats": (c_int, [P, c_int, c_int, P, c_int, c_int, P, c_int, c_int, c_int, c_int, c_int, P, P, P]),
-    "spnet_gemm_f32_batched": (c_int, [P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P]),
+    "spnet_gemm_f32_batched": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P]),
     "spnet_bn_ws": (c_long, [c_long, c_int]),
     "spnet_bn_fwd_train": (c_int, [P, c_long, c_int, P, P, P, P, P, P, P, c_int, P, c_int, P, c_float, c_float, P, P]),
     "spnet_bn_fwd_infer": (c_int, [P, c_long, c_int, P, P, P, P, P, c_int, P, c_int, P, c_float, P]),

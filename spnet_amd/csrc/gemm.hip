@@ -30,7 +30,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const float* __restric
                                                        int tiles_m, int tiles_n, int nsplit,
                                                        const float* __restrict__ bias,
                                                        float* __restrict__ colstats,
-                                                       const float* const* __restrict__ batch) {
+                                                       const long long* __restrict__ batch) {
   static_assert(WM * WN == 4, "4 waves per workgroup");
   constexpr int TM = BM / WM / 16, TN = BN / WN / 16;
   static_assert(TM >= 1 && TN >= 1 && (BM % (WM * 16)) == 0 && (BN % (WN * 16)) == 0, "wave tile");
@@ -55,9 +55,12 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const float* __restric
   const int m0 = tm * BM, n0 = tn * BN;
   // batch != NULL: grid.z-like index z selects one of `nsplit` independent problems of identical shape
   // (operand pointers from the table {A0,B0,C0,A1,B1,C1,...}); otherwise z is the K slice.
-  const float* __restrict__ A = batch ? batch[3 * z] : A_;
-  const float* __restrict__ B = batch ? batch[3 * z + 1] : B_;
-  float* __restrict__ C = batch ? const_cast<float*>(batch[3 * z + 2]) : C_;
+  // (the table holds element OFFSETS from problem 0's operands, which arrive as kernel arguments: pointers
+  // read from memory would be generic and turn every operand fetch into a flat_load, which also counts on
+  // lgkmcnt and serialises with the LDS traffic)
+  const float* __restrict__ A = batch ? A_ + batch[3 * z] : A_;
+  const float* __restrict__ B = batch ? B_ + batch[3 * z + 1] : B_;
+  float* __restrict__ C = batch ? C_ + batch[3 * z + 2] : C_;
   const int kbeg = batch ? 0 : z * k_chunk;
   const int kend = min(K, kbeg + k_chunk);
   const int nt = (kend - kbeg + BK - 1) / BK;
@@ -190,7 +193,7 @@ extern "C" int spnet_reduce_slabs(const float* ws, int nslab, int M, int N, floa
 template <int BM, int BN, int WM, int WN>
 static int launch_tile(const float* A, int amaj, int lda, const float* B, int bmaj, int ldb, float* C,
                        int ldc, int M, int N, int K, int nsplit, int k_chunk, long slab_stride,
-                       const float* bias, float* colstats, const float* const* batch, hipStream_t st) {
+                       const float* bias, float* colstats, const long long* batch, hipStream_t st) {
   const int tm = spnet_cdiv(M, BM), tn = spnet_cdiv(N, BN);
   dim3 grid(tm * tn * nsplit), block(256);
 #define SP_ARGS A, lda, B, ldb, C, ldc, M, N, K, k_chunk, slab_stride, tm, tn, nsplit, bias, colstats, batch
@@ -266,7 +269,7 @@ static int pick_tile(int form, int M, int N, int K, int split_k, bool have_ws, l
 static int gemm_impl(const float* A, int a_major, int lda, const float* B, int b_major, int ldb, float* C,
                      int ldc, int M, int N, int K, int split_k, float* workspace, long ws_floats,
                      const float* bias, int tile, float* colstats, int* stat_rows, void* stream,
-                     const float* const* batch = nullptr, int nbatch = 0) {
+                     const long long* batch = nullptr, int nbatch = 0) {
   hipStream_t st = (hipStream_t)stream;
   if (batch) {                       // nbatch whole problems side by side: no K split, no workspace
     if (nbatch < 1 || bias || colstats) return (int)hipErrorInvalidValue;
@@ -279,7 +282,7 @@ static int gemm_impl(const float* A, int a_major, int lda, const float* B, int b
   if ((lda & 3) || (ldb & 3) || (N & 3) || (ldc & 3)) return (int)hipErrorInvalidValue;
   if ((a_major == SP_K_MAJOR || b_major == SP_K_MAJOR) && (K & 3)) return (int)hipErrorInvalidValue;
   if (a_major == SP_OUT_MAJOR && (M & 3)) return (int)hipErrorInvalidValue;
-  if (!batch && (((uintptr_t)A | (uintptr_t)B | (uintptr_t)C) & 15)) return (int)hipErrorInvalidValue;
+  if (((uintptr_t)A | (uintptr_t)B | (uintptr_t)C) & 15) return (int)hipErrorInvalidValue;
   const int form = (a_major == SP_OUT_MAJOR) ? 2 : (b_major == SP_K_MAJOR ? 1 : 0);
   if (tile <= 0 || tile > SP_NTILES)
     tile = pick_tile(form, M, N, K, split_k, workspace != nullptr, ws_floats, batch ? nbatch : 1);
@@ -334,14 +337,16 @@ extern "C" int spnet_gemm_f32(const float* A, int a_major, int lda, const float*
                    tile, nullptr, nullptr, stream);
 }
 
-// nbatch independent problems of one shape in ONE launch (no K split): ptrs (device memory) holds
-// {A0, B0, C0, A1, B1, C1, ...}.  Used for the weight gradients of the eight middle-flow blocks, which
-// individually are too small to fill the chip without a K split.
-extern "C" int spnet_gemm_f32_batched(const float* const* ptrs, int nbatch, int a_major, int lda, int b_major,
-                                      int ldb, int ldc, int M, int N, int K, int tile, void* stream) {
-  if (!ptrs) return (int)hipErrorInvalidValue;
-  return gemm_impl(nullptr, a_major, lda, nullptr, b_major, ldb, nullptr, ldc, M, N, K, 1, nullptr, 0, nullptr, tile,
-                   nullptr, nullptr, stream, ptrs, nbatch);
+// nbatch independent problems of one shape in ONE launch (no K split).  A0/B0/C0: operands of problem 0;
+// offsets (device memory): {A_b - A0, B_b - B0, C_b - C0} in floats for b = 0..nbatch-1 (multiples of 4).
+// Used for the weight gradients of the eight middle-flow blocks, which individually are too small to fill
+// the chip without a K split.
+extern "C" int spnet_gemm_f32_batched(const float* A0, const float* B0, float* C0, const long long* offsets,
+                                      int nbatch, int a_major, int lda, int b_major, int ldb, int ldc, int M,
+                                      int N, int K, int tile, void* stream) {
+  if (!offsets || !A0 || !B0 || !C0) return (int)hipErrorInvalidValue;
+  return gemm_impl(A0, a_major, lda, B0, b_major, ldb, C0, ldc, M, N, K, 1, nullptr, 0, nullptr, tile, nullptr, nullptr,
+                   stream, offsets, nbatch);
 }
 
 // Forward-form GEMM that also emits BatchNorm column statistics of C: colstats[rows][2][N] holds per

@@ -401,20 +401,24 @@ class Engine:
         x0, dy0, gw0, cin, cout, M = todo[0]
         if any((t[3], t[4], t[5]) != (cin, cout, M) for t in todo):
             raise RuntimeError("deferred weight gradients must share one shape")
-        ptrs = [p for (x, dy, gw, _, _, _) in todo for p in (x.data_ptr(), dy.data_ptr(), gw.data_ptr())]
+        # element offsets of every problem's operands from problem 0's (kernel-argument base pointers keep the
+        # operand fetches in the global address space)
+        a0, b0, c0 = x0.data_ptr(), dy0.data_ptr(), gw0.data_ptr()
+        offs = [v for (x, dy, gw, _, _, _) in todo
+                for v in ((x.data_ptr() - a0) // 4, (dy.data_ptr() - b0) // 4, (gw.data_ptr() - c0) // 4)]
         if self._wgrad_table is None:
             self._wgrad_table = {}
-        key = tuple(ptrs)
+        key = (a0, b0, c0) + tuple(offs)
         if key not in self._wgrad_table:
-            self._wgrad_table[key] = torch.tensor(ptrs, dtype=torch.int64, device=self.dev)
+            self._wgrad_table[key] = torch.tensor(offs, dtype=torch.int64, device=self.dev)
         table = self._wgrad_table[key]
         nb = len(todo)
 
         def launch():
             prof = self.prof
             t0 = prof.start() if prof is not None else None
-            L.spnet_gemm_f32_batched(table.data_ptr(), nb, OUT_MAJOR, cin, OUT_MAJOR, cout, cout, cin, cout, M, 5,
-                                     _stream())
+            L.spnet_gemm_f32_batched(a0, b0, c0, table.data_ptr(), nb, OUT_MAJOR, cin, OUT_MAJOR, cout, cout, cin, cout, M,
+                                     5, _stream())
             if prof is not None:
                 prof.stop("gemm", t0, 2.0 * nb * cin * cout * M)
 

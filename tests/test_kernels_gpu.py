@@ -104,9 +104,10 @@ def test_gemm_batched_wgrad_form(L, tile):
     Xs = [dev(rs.randn(K, M).astype(np.float32)) for _ in range(nb)]
     Ds = [dev(rs.randn(K, N).astype(np.float32)) for _ in range(nb)]
     Cs = [torch.full((M, N), float("nan"), device="cuda") for _ in range(nb)]
-    table = torch.tensor([p for b in range(nb) for p in (Xs[b].data_ptr(), Ds[b].data_ptr(), Cs[b].data_ptr())],
-                         dtype=torch.int64, device="cuda")
-    L.spnet_gemm_f32_batched(table.data_ptr(), nb, 1, M, 1, N, N, M, N, K, tile, st())
+    a0, b0, c0 = Xs[0].data_ptr(), Ds[0].data_ptr(), Cs[0].data_ptr()
+    table = torch.tensor([v for b in range(nb) for v in ((Xs[b].data_ptr() - a0) // 4, (Ds[b].data_ptr() - b0) // 4,
+                                                         (Cs[b].data_ptr() - c0) // 4)], dtype=torch.int64, device="cuda")
+    L.spnet_gemm_f32_batched(a0, b0, c0, table.data_ptr(), nb, 1, M, 1, N, N, M, N, K, tile, st())
     ws = torch.empty(WS, device="cuda")
     for b in range(nb):
         want = Xs[b].cpu().double().numpy().T @ Ds[b].cpu().double().numpy()
