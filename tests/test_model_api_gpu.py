@@ -1,0 +1,78 @@
+"""The Keras-like Model surface on the GPU: two-phase training (freeze_fac then unfreeze_model,
+train_spnet.py:71-78 of the reference), weight round trips, predict()."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def data():
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    rs = np.random.RandomState(3)
+    X = (rs.rand(16, 96, 128, 1).astype(np.float32) * 2 - 1)
+    Y = rs.rand(16, 576).astype(np.float32)
+    Y[:, 6::8] = (Y[:, 6::8] > 0.5)
+    return X, Y
+
+
+def _by_prefix(sd, frozen_prefixes):
+    fro = {k: v for k, v in sd.items() if k.split("/")[0] in frozen_prefixes}
+    rest = {k: v for k, v in sd.items() if k.split("/")[0] not in frozen_prefixes}
+    return fro, rest
+
+
+def test_frozen_layers_stay_put_and_unfreeze_trains_them(data):
+    from spnet_amd import models as M
+    X, Y = data
+    np.random.seed(1)
+    model = M.create_model_functional(X, Y0size=576, freeze_fac=0.75)
+    assert model._mask is not None and 0 < int((model._mask == 0).sum()) < model._mask.numel()
+    before = {k: v.clone() for k, v in model.state_dict().items()}
+    model.optimizer.lr = 1e-3
+    model.fit(X, Y, batch_size=8, epochs=2, shuffle=False, verbose=0)
+    after = model.state_dict()
+    trainable = lambda k: not (k.endswith("moving_mean") or k.endswith("moving_variance"))
+    fro_b, rest_b = _by_prefix(before, model._frozen_prefixes)
+    fro_a, rest_a = _by_prefix(after, model._frozen_prefixes)
+    assert fro_b and rest_b
+    for k in fro_b:
+        if trainable(k):                     # layer.trainable=False: kernel/gamma/beta untouched, bit for bit
+            assert np.array_equal(fro_b[k].numpy(), fro_a[k].numpy()), k
+    moved = [k for k in rest_b if trainable(k) and not np.array_equal(rest_b[k].numpy(), rest_a[k].numpy())]
+    assert len(moved) >= 0.9 * sum(trainable(k) for k in rest_b)
+    # BatchNorm moving statistics follow the batches even in frozen layers (Keras 2.1.3 semantics: `trainable`
+    # only removes the weights from the optimizer)
+    assert any(not np.array_equal(before[k].numpy(), after[k].numpy()) for k in before if k.endswith("moving_mean"))
+
+    # phase 2: a fresh, fully trainable model carrying the same weights
+    new = M.unfreeze_model(model, X, Y)
+    assert new._mask is None
+    for k, v in new.state_dict().items():
+        assert np.array_equal(v.numpy(), after[k].numpy()), k
+    new.optimizer.lr = 1e-3
+    new.fit(X, Y, batch_size=8, epochs=1, shuffle=False, verbose=0)
+    final = new.state_dict()
+    fro_f, _ = _by_prefix(final, model._frozen_prefixes)
+    moved = [k for k in fro_f if trainable(k) and not np.array_equal(fro_f[k].numpy(), fro_a[k].numpy())]
+    assert len(moved) >= 0.9 * sum(trainable(k) for k in fro_f)
+
+
+def test_weights_round_trip_and_predict_is_deterministic(data, tmp_path):
+    from spnet_amd import models as M
+    X, Y = data
+    model = M.build_model(X, Y0size=576, freeze_fac=0.0)
+    p1 = model.predict(X, batch_size=5)                     # ragged last batch
+    assert p1.shape == (16, 576) and p1.dtype == np.float32 and np.isfinite(p1).all()
+    path = str(tmp_path / "w.hdf5")
+    model.save_weights(path)
+    other = M.build_model(X, Y0size=576, freeze_fac=0.0)
+    other.load_weights(path)
+    np.testing.assert_array_equal(other.predict(X, batch_size=8), model.predict(X, batch_size=8))
+    np.testing.assert_allclose(p1, model.predict(X, batch_size=8), rtol=0, atol=1e-5)
+    w = model.get_weights()
+    other.set_weights([a * 0 for a in w])
+    assert float(np.abs(other.predict(X[:4], batch_size=4)).max()) < 1e-3
+    assert abs(model.evaluate(X, Y, batch_size=8) - M.custom_loss(Y, p1)) < 1e-5
