@@ -32,7 +32,7 @@ def evaluate_network(model=None, weights_file="", datapath="Test/", fraction=1.0
     if cf.loss_type != 'same':
         Y_pred[:, cf.ind_noobj::cf.vars_per_pred] = 1.0 / (1.0 + np.exp(-Y_pred[:, cf.ind_noobj::cf.vars_per_pred]))
     Yt, Yp = denorm_Y(Y_test), denorm_Y(Y_pred)
-    print("mAP = ", diagnostics.calc_map(Yp, Yt))
+    print("mAP = ", diagnostics.calc_map(Yp, Yt, device=True))      # 72 x N raster IoUs in one HIP launch
 
     (ring_miscounts, ring_truecounts, total_obj, false_obj_pos, false_obj_neg, true_obj_pos, true_obj_neg, pix_err,
      ipem) = diagnostics.calc_errors(Yp, Yt)

@@ -152,6 +152,11 @@ int spnet_ellipse_loss(const float* y_true, const float* y_pred, float* grad, fl
 int spnet_decode(const float* y_norm, const float* means, const float* ranges, float* out, int B,
                  int ncols, int sigmoid_noobj, void* stream);
 
+/* ---- evaluation metric (spnet/diagnostics.py:64-161: compute_iou / calc_map) ----------------------------- */
+/* Raster IoU of npairs (predicted, true) ellipse rows [npairs][8] (denormalised cx,cy,a,b,cos2t,sin2t,noobj,
+ * rings) on an nx x ny canvas; iou[i] = -1 where the true slot is empty or both rasters are. */
+int spnet_ellipse_iou(const float* yp, const float* yt, long npairs, int nx, int ny, double* iou, void* stream);
+
 /* ---- optimizer ---------------------------------------------------------------------------------- */
 /* Keras Adam + l2 on the first l2_n elements (spnet/models.py:494, 47-71).  sq_scratch >= 2048 floats.
  * mask (or NULL): n floats, 0 = frozen element (layer.trainable=False, spnet/models.py:361-373).

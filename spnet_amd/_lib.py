@@ -61,6 +61,7 @@ _SIGS = {
     "spnet_conv3x3_small": (c_int, [c_int, c_int, c_int, c_int, c_int, P, P, P, c_int, c_int, c_int, P, c_long, P]),
     "spnet_ellipse_loss": (c_int, [P, P, P, P, P, c_int, c_int, c_int, P]),
     "spnet_decode": (c_int, [P, P, P, P, c_int, c_int, c_int, P]),
+    "spnet_ellipse_iou": (c_int, [P, P, c_long, c_int, c_int, P, P]),
     "spnet_adam_step": (c_int, [P, P, P, P, c_long, c_long, c_float, c_float, c_float, c_float, c_float, c_float, P, P, P, P, P]),
     "spnet_minmax": (c_int, [P, c_int, c_long, P, P, P]),
     "spnet_cutout": (c_int, [P, P, P, c_int, c_int, c_int, P, P, P, P]),

@@ -9,6 +9,11 @@ The reference rasterises with cv2.ellipse (LINE_AA, shift=10); OpenCV is absent 
 the analytic point-in-ellipse test at pixel centres -- IoU values agree with OpenCV's to about one
 boundary pixel ring (~1e-2 for small ellipses), not bitwise.  Each pair's IoU is computed once and
 shared by the ten mAP thresholds (the reference recomputes it per threshold with the same result).
+
+`calc_map(..., device=True)` / `precision(..., device=True)` run the same raster test for all 72 x N pairs in
+one HIP launch (`spnet_ellipse_iou`, csrc/metrics.hip: the reference spends minutes here on the CPU); without
+the flag the metric is computed on the host exactly as before.  The two agree to a boundary pixel or two per
+pair (fp32 sin/cos of different math libraries).
 """
 import numpy as np
 
@@ -78,6 +83,22 @@ def compute_iou(args_p, args_t, display=False):
     return num_i / num_u
 
 
+def _pair_ious_device(Yp, Yt):
+    """All predictor pairs on the GPU; same list of (iou, noobj_p, noobj_t) as _pair_ious."""
+    import torch
+    from . import _lib as L
+    v = cf.vars_per_pred
+    yp = torch.from_numpy(np.ascontiguousarray(Yp, dtype=np.float32)).cuda().reshape(-1, v)
+    yt = torch.from_numpy(np.ascontiguousarray(Yt, dtype=np.float32)).cuda().reshape(-1, v)
+    iou = torch.empty(yp.shape[0], dtype=torch.float64, device="cuda")
+    L.spnet_ellipse_iou(yp.data_ptr(), yt.data_ptr(), yp.shape[0], 512, 384, iou.data_ptr(),
+                        torch.cuda.current_stream().cuda_stream)
+    iou = iou.cpu().numpy()
+    P, T = np.asarray(Yp, np.float32).reshape(-1, v), np.asarray(Yt, np.float32).reshape(-1, v)
+    keep = np.nonzero(iou >= 0)[0]
+    return [(float(iou[k]), P[k, -2], T[k, -2]) for k in keep]
+
+
 def _pair_ious(Yp, Yt):
     out = []
     for i in range(Yp.shape[0]):
@@ -89,8 +110,8 @@ def _pair_ious(Yp, Yt):
     return out
 
 
-def precision(Yp, Yt, thresh=0.5, _pairs=None):
-    pairs = _pair_ious(Yp, Yt) if _pairs is None else _pairs
+def precision(Yp, Yt, thresh=0.5, _pairs=None, device=False):
+    pairs = ((_pair_ious_device if device else _pair_ious)(Yp, Yt)) if _pairs is None else _pairs
     tp = fp = fn = 0
     for iou, noobj_p, noobj_t in pairs:
         if iou > thresh:
@@ -105,8 +126,8 @@ def precision(Yp, Yt, thresh=0.5, _pairs=None):
     return prec, tp, fp, fn
 
 
-def calc_map(Yp, Yt):
+def calc_map(Yp, Yt, device=False):
     print("\ncalc_map: Calculating mean average precision. Yp.shape[0] =", Yp.shape[0])
-    pairs = _pair_ious(Yp, Yt)
+    pairs = (_pair_ious_device if device else _pair_ious)(Yp, Yt)
     threshes = [0.5, 0.55, 0.6, 0.65, 0.7, 0.75, 0.8, 0.85, 0.9, 0.95]
     return sum(precision(Yp, Yt, thresh=t, _pairs=pairs)[0] for t in threshes) / len(threshes)

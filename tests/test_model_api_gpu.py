@@ -76,3 +76,45 @@ def test_weights_round_trip_and_predict_is_deterministic(data, tmp_path):
     other.set_weights([a * 0 for a in w])
     assert float(np.abs(other.predict(X[:4], batch_size=4)).max()) < 1e-3
     assert abs(model.evaluate(X, Y, batch_size=8) - M.custom_loss(Y, p1)) < 1e-5
+
+
+def test_device_map_matches_host_metric():
+    """spnet_ellipse_iou (all 72 x N pairs in one launch) against the host raster of diagnostics.py, the
+    reference's IoU known-answer, and mAP on a noisy copy of random labels."""
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from spnet_amd import diagnostics as D
+
+    def tup(cx, cy, a_, b_, ang, noobj=0.0):
+        return [cx, cy, a_, b_, np.cos(2 * np.deg2rad(ang)), np.sin(2 * np.deg2rad(ang)), noobj, 1.0]
+
+    # reference tests/test_diagnostics.py pins 0.44227983 for this pair under cv2's rasteriser
+    kp, kt = np.array([tup(100, 140, 120, 60, 90)], np.float32), np.array([tup(120, 123, 120, 60, 149.97)], np.float32)
+    dev_pairs = D._pair_ious_device(kp, kt)
+    assert len(dev_pairs) == 1 and abs(dev_pairs[0][0] - 0.44227983107795693) < 0.01
+    assert abs(dev_pairs[0][0] - D.compute_iou(kp[0], kt[0])) < 1e-3
+
+    rs = np.random.RandomState(8)
+    N = 6
+    Yt = np.zeros((N, 576), np.float32)
+    for i in range(N):
+        for k in range(72):
+            empty = rs.rand() < 0.7
+            Yt[i, 8 * k:8 * k + 8] = tup(rs.uniform(30, 480), rs.uniform(30, 350), rs.uniform(15, 140), rs.uniform(10, 100),
+                                         rs.uniform(0, 180), 1.0 if empty else 0.0)
+    Yp = Yt.copy()
+    Yp[:, 0::8] += rs.randn(N, 72) * 6
+    Yp[:, 1::8] += rs.randn(N, 72) * 6
+    Yp[:, 2::8] *= 1 + rs.randn(N, 72) * 0.1
+    Yp[:, 6::8] = np.clip(Yp[:, 6::8] + rs.randn(N, 72) * 0.3, 0, 1)
+    Yp[0, 2] = -3.0                                  # a degenerate prediction (a <= 0): empty raster
+    host = D._pair_ious(Yp, Yt)
+    dev = D._pair_ious_device(Yp, Yt)
+    assert len(host) == len(dev) > 50
+    h, d = np.array([p[0] for p in host]), np.array([p[0] for p in dev])
+    assert np.abs(h - d).max() < 2e-3, np.abs(h - d).max()
+    assert [(p[1], p[2]) for p in host] == [(p[1], p[2]) for p in dev]
+    m_host, m_dev = D.calc_map(Yp, Yt), D.calc_map(Yp, Yt, device=True)
+    assert abs(m_host - m_dev) < 0.02 and 0.0 < m_dev < 1.0
+    assert D.calc_map(Yt, Yt, device=True) == 1.0
