@@ -155,34 +155,60 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const float* __restric
 }
 
 // out[row*ldc + col] = sum_z ws[z*M*N + row*N + col] (+ bias[col]); N % 4 == 0, ldc % 4 == 0.
+// Workgroup = (256 / sl) output float4 x sl slab lanes (sl = 1..16, a power of two chosen from the slab count):
+// lane g adds slabs g, g+sl, g+2sl, ... (up to 4 loads in flight), then the sl lane sums are added in lane
+// order -- a fixed order, and a K split into hundreds of slabs (the weight gradients of the entry flow:
+// K = 372,000 pixels) is no longer one long serial chain per output element.
 __global__ __launch_bounds__(256) void reduce_slabs_kernel(const float* __restrict__ ws, int nslab,
                                                            int M, int N, float* __restrict__ out,
-                                                           int ldc, const float* __restrict__ bias) {
+                                                           int ldc, const float* __restrict__ bias, int sl) {
+  __shared__ float4 red[256];
   const long total4 = (long)M * N / 4;
   const long mn = (long)M * N;
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total4;
-       i += (long)gridDim.x * blockDim.x) {
-    const long e = i * 4;
-    const int row = (int)(e / N), col = (int)(e % N);
-    float4 s = *reinterpret_cast<const float4*>(ws + e);
-    for (int zz = 1; zz < nslab; ++zz) {
-      const float4 t = *reinterpret_cast<const float4*>(ws + (long)zz * mn + e);
+  const int per = 256 / sl;                         // outputs per workgroup
+  const int lane = threadIdx.x % per, g = threadIdx.x / per;
+  const long i = (long)blockIdx.x * per + lane;
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (i < total4) {
+#pragma unroll 4
+    for (int zz = g; zz < nslab; zz += sl) {
+      const float4 t = *reinterpret_cast<const float4*>(ws + (long)zz * mn + i * 4);
       s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
     }
-    if (bias) {
-      const float4 b = *reinterpret_cast<const float4*>(bias + col);
-      s.x += b.x; s.y += b.y; s.z += b.z; s.w += b.w;
-    }
-    *reinterpret_cast<float4*>(out + (long)row * ldc + col) = s;
   }
+  red[g * per + lane] = s;
+  __syncthreads();
+  if (g == 0 && i < total4) {
+    float4 t = red[lane];
+    for (int k = 1; k < sl; ++k) {
+      const float4 v = red[k * per + lane];
+      t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w;
+    }
+    const long e = i * 4;
+    const int row = (int)(e / N), col = (int)(e % N);
+    if (bias) {
+      const float4 bv = *reinterpret_cast<const float4*>(bias + col);
+      t.x += bv.x; t.y += bv.y; t.z += bv.z; t.w += bv.w;
+    }
+    *reinterpret_cast<float4*>(out + (long)row * ldc + col) = t;
+  }
+}
+
+static void launch_reduce_slabs(const float* ws, int nslab, int M, int N, float* out, int ldc, const float* bias,
+                                hipStream_t st) {
+  const long total4 = (long)M * N / 4;
+  int sl = 1;
+  while (sl < 16 && sl * 4 <= nslab) sl <<= 1;      // >= 4 slabs per lane before another lane pays off
+  const int per = 256 / sl;
+  hipLaunchKernelGGL(reduce_slabs_kernel, dim3((unsigned)((total4 + per - 1) / per)), dim3(256), 0, st, ws, nslab, M, N,
+                     out, ldc, bias, sl);
 }
 
 // out[M][ldc] = sum of nslab slabs of M*N floats (slice order); shared with conv_gemm.hip
 extern "C" int spnet_reduce_slabs(const float* ws, int nslab, int M, int N, float* out, int ldc, void* stream) {
   if ((N & 3) || (ldc & 3) || nslab < 1) return (int)hipErrorInvalidValue;
   const long total4 = (long)M * N / 4;
-  hipLaunchKernelGGL(reduce_slabs_kernel, dim3(spnet_ew_grid(total4, 256)), dim3(256), 0, (hipStream_t)stream, ws,
-                     nslab, M, N, out, ldc, (const float*)nullptr);
+  launch_reduce_slabs(ws, nslab, M, N, out, ldc, nullptr, (hipStream_t)stream);
   SPNET_RETURN_LAUNCH_STATUS();
 }
 
@@ -323,8 +349,7 @@ static int gemm_impl(const float* A, int a_major, int lda, const float* B, int b
   if (rc) return rc;
   if (nsplit > 1 && !batch) {
     const long total4 = (long)M * N / 4;
-    hipLaunchKernelGGL(reduce_slabs_kernel, dim3(spnet_ew_grid(total4, 256)), dim3(256), 0, st,
-                       workspace, nsplit, M, N, C, ldc, bias);
+    launch_reduce_slabs(workspace, nsplit, M, N, C, ldc, bias, st);
   }
   SPNET_RETURN_LAUNCH_STATUS();
 }
