@@ -158,6 +158,7 @@ def main():
     from spnet_amd.augmentation import DeviceAugmenter
     from spnet_amd.callbacks import get_1cycle_schedule
     from spnet_amd.engine import Engine, KernelTimer
+    from spnet_amd import _lib as L
 
     if (args.height, args.width, args.batch, args.mode) != (H, W, BATCH, "train"):
         return secondary(args)
@@ -176,6 +177,7 @@ def main():
 
     eng = Engine(H, W, BATCH, device=str(dev), seed=0)
     aug = DeviceAugmenter(X_pool)
+    upload = L.AsyncUploader(dev)
     reducer = parallel.GradReducer(eng.grad, eng.head_grad_range()) if world > 1 else None
     # 1-cycle table of the reference's own run configuration (lr_max 4e-5, 40k frames, 100 epochs)
     lrs = get_1cycle_schedule(lr_max=4e-5, n_data_points=40000, epochs=100, batch_size=BATCH * world)
@@ -187,7 +189,7 @@ def main():
         it[0] += 1
         idx = order[(np.arange(BATCH) + i * BATCH) % args.pool]
         aug.augment(idx, eng.x_in)
-        torch.index_select(Y_pool, 0, torch.from_numpy(idx).to(dev), out=eng.y_true)
+        torch.index_select(Y_pool, 0, upload("idx", idx), out=eng.y_true)
         return eng.train_step(None, None, float(lrs[i % len(lrs)]), reducer=reducer)
 
     def fence():

@@ -17,6 +17,7 @@ if not os.path.exists(LIB_PATH):
 
 # torch first: libspnet_hip.so must bind to the SAME HIP runtime (libamdhip64) that torch has loaded, or
 # the two runtimes would not share devices / streams (kernels then fail with hipErrorNoDevice).
+import numpy as np  # noqa: E402
 import torch  # noqa: E402,F401
 
 _lib = ctypes.CDLL(LIB_PATH)
@@ -99,3 +100,35 @@ for _n, (_r, _a) in _SIGS.items():
 def ptr(t):
     """Device pointer of a torch tensor (or None -> NULL)."""
     return None if t is None else t.data_ptr()
+
+
+class AsyncUploader:
+    """numpy array -> device tensor WITHOUT synchronising the stream.
+
+    A copy from pageable memory makes torch wait for everything queued before it -- the whole previous train
+    step -- so the host could never run ahead and the GPU idled ~0.4 ms at every step boundary.  Per-step
+    parameters therefore go through a small ring of pinned staging buffers (one ring per key / shape) and
+    asynchronous copies into matching device buffers; a slot is reused only after its own copy has completed
+    (event), and stream order protects the device buffer from being overwritten while kernels still read it."""
+
+    def __init__(self, device, depth=4):
+        self.device, self.depth = device, depth
+        self.rings, self.count = {}, {}
+
+    def __call__(self, key, array):
+        array = np.ascontiguousarray(array)
+        k = (key, array.shape, array.dtype.str)
+        ring = self.rings.get(k)
+        if ring is None:
+            ring = []
+            for _ in range(self.depth):
+                host = torch.from_numpy(np.empty_like(array)).pin_memory()
+                ring.append((host, torch.empty_like(host, device=self.device), torch.cuda.Event()))
+            self.rings[k], self.count[k] = ring, 0
+        host, dev, ev = ring[self.count[k] % self.depth]
+        self.count[k] += 1
+        ev.synchronize()                     # returns at once unless the GPU is `depth` uploads behind
+        host.numpy()[...] = array
+        dev.copy_(host, non_blocking=True)
+        ev.record()
+        return dev

@@ -88,6 +88,7 @@ class DeviceAugmenter:
         L.spnet_minmax(self.X.data_ptr(), self.N, self.H * self.W, mm.data_ptr(), scratch.data_ptr(), _stream())
         self.mm_host = mm.cpu().numpy()     # min/max of the pristine frames: cutout's fill range
         self.n_salt, self.n_pepper = saltpepper_counts(self.shape)
+        self._upload = None
 
     def draw(self, indices):
         """Host-side parameter draw for the given frame indices, reference RNG order per frame."""
@@ -116,7 +117,9 @@ class DeviceAugmenter:
     def apply(self, params, out):
         """out[j] = augmented copy of frame params['index'][j]; out is a device tensor [B,H,W,1]."""
         dev = self.X.device
-        up = {k: torch.from_numpy(v).to(dev, non_blocking=True) for k, v in params.items()}
+        if self._upload is None:
+            self._upload = L.AsyncUploader(dev)
+        up = {k: self._upload(k, v) for k, v in params.items()}   # pinned ring + async copies: the host keeps running ahead
         B = len(params["index"])
         self._keep = up                    # keep the uploads alive until the kernels have consumed them
         L.spnet_cutout(self.X.data_ptr(), up["index"].data_ptr(), out.data_ptr(), B, self.H, self.W,

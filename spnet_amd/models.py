@@ -305,12 +305,14 @@ class Model:
             initial_epoch=0):
         torch = _torch()
         import torch.distributed as dist
+        from . import _lib as L
         from . import parallel
         callbacks = list(callbacks or [])
         for cb in callbacks:
             cb.set_model(self)
         eng = self._engine(batch_size, train=True)
         eng.update_mask = self._mask
+        upload = L.AsyncUploader(eng.dev)
         world = dist.get_world_size() if dist.is_initialized() else 1
         rank = dist.get_rank() if dist.is_initialized() else 0
         reducer = parallel.GradReducer(eng.grad, eng.head_grad_range()) if world > 1 else None
@@ -334,7 +336,7 @@ class Model:
             for b in range(nb):
                 for cb in callbacks:
                     cb.on_batch_begin(b, {})
-                idx = torch.from_numpy(index[b * batch_size:(b + 1) * batch_size]).to(eng.dev)
+                idx = upload("idx", index[b * batch_size:(b + 1) * batch_size])
                 torch.index_select(Xd, 0, idx, out=eng.x_in)
                 torch.index_select(Yd, 0, idx, out=eng.y_true)
                 out = eng.train_step(None, None, float(self.optimizer.lr), reducer=reducer)
