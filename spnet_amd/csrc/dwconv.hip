@@ -361,24 +361,35 @@ __global__ __launch_bounds__(256) void dw3x3_tile_bwd_kernel(
       m0 = tdz[o0]; m1 = tdz[o0 + CC2]; m2 = tdz[o0 + 2 * CC2];
       c0 = tdz[o1]; c1 = tdz[o1 + CC2]; c2r = tdz[o1 + 2 * CC2];
     }
-    float2 x_nxt = zero2, add_nxt = zero2, bx_nxt = zero2;
-    if (h0 < H) {
-      x_nxt = *reinterpret_cast<const float2*>(x + cbase + (long)h0 * W * C);
-      if (add) add_nxt = *reinterpret_cast<const float2*>(add + cbase + (long)h0 * W * C);
-      if (bn_x) bx_nxt = *reinterpret_cast<const float2*>(bn_x + cbase + (long)h0 * W * C);
+    // x / add / bn_x at the centre pixels are read straight from global memory, PD rows ahead of their use
+    // (a ring of PD register slots): one row of FMAs is far too short to cover a global load.
+    constexpr int PD = 3;
+    static_assert(TH % PD == 0, "prefetch ring");
+    float2 xq[PD], aq[PD], bq[PD];
+#pragma unroll
+    for (int d = 0; d < PD; ++d) {
+      xq[d] = zero2; aq[d] = zero2; bq[d] = zero2;
+      const int hh = h0 + d;
+      if (hh < H) {
+        xq[d] = *reinterpret_cast<const float2*>(x + cbase + (long)hh * W * C);
+        if (add) aq[d] = *reinterpret_cast<const float2*>(add + cbase + (long)hh * W * C);
+        if (bn_x) bq[d] = *reinterpret_cast<const float2*>(bn_x + cbase + (long)hh * W * C);
+      }
     }
-#pragma unroll 2
+#pragma unroll
     for (int t = 1; t <= TH; ++t) {
       const int ho = h0 + t - 1;
       if (ho >= H) break;
       const int o2 = (((t + 1) * PW + tcol) * CC4) * 2 + l2;
       n0 = tdz[o2]; n1 = tdz[o2 + CC2]; n2 = tdz[o2 + 2 * CC2];
-      const float2 raw = x_nxt, ad = add_nxt;
-      const float2 pre = bn_x ? bx_nxt : raw;         // pre-BN value the statistics' BatchNorm normalised
-      if (t < TH && ho + 1 < H) {                     // next centre row, one iteration ahead
-        x_nxt = *reinterpret_cast<const float2*>(x + cbase + (long)(ho + 1) * W * C);
-        if (add) add_nxt = *reinterpret_cast<const float2*>(add + cbase + (long)(ho + 1) * W * C);
-        if (bn_x) bx_nxt = *reinterpret_cast<const float2*>(bn_x + cbase + (long)(ho + 1) * W * C);
+      const int slot = (t - 1) % PD;
+      const float2 raw = xq[slot], ad = aq[slot];
+      const float2 pre = bn_x ? bq[slot] : raw;       // pre-BN value the statistics' BatchNorm normalised
+      if (t - 1 + PD < TH && ho + PD < H) {           // refill the slot with the row PD ahead
+        const long ro = cbase + (long)(ho + PD) * W * C;
+        xq[slot] = *reinterpret_cast<const float2*>(x + ro);
+        if (add) aq[slot] = *reinterpret_cast<const float2*>(add + ro);
+        if (bn_x) bq[slot] = *reinterpret_cast<const float2*>(bn_x + ro);
       }
       float2 a = raw;
       if (affine) a = make_float2(fmaf(raw.x, sc.x, sh.x), fmaf(raw.y, sc.y, sh.y));
