@@ -167,8 +167,9 @@ class Engine:
         self.defer_mid_wgrad = os.environ.get("SPNET_DEFER_WGRAD", "1") != "0"
         self.overlap_wgrad = True       # pointwise weight gradients on a side stream (joined before Adam)
         # Optional: capture the single-GPU train step as a hipGraph after one eager step.  Off by default:
-        # measured on MI355X / ROCm 7.2 the replay of this ~500-node two-stream graph takes 16.9 ms against
-        # 15.2 ms for the eager launches (host enqueue is only 4.4 ms per step, the GPU is the limit).
+        # measured on MI355X / ROCm 7.2 the replay of this ~400-node two-stream graph takes 13.8 ms against
+        # 13.4 ms for the eager launches (single stream: 13.5 either way) -- the host enqueues a step in
+        # 4.3 ms and runs ahead of the GPU, so launch overhead is not what limits the step.
         self.use_graph = False
         self.drop_seed = 12345
         torch.cuda.set_device(self.dev)
