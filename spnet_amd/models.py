@@ -273,10 +273,14 @@ class Model:
             return X if X.is_cuda else X.to(self.device)
         if self._train_frames is not None and self._train_frames[0] == id(X):
             return self._train_frames[1]
-        key = id(X)
-        if key not in self._uploaded:
-            self._uploaded = {key: torch.from_numpy(np.ascontiguousarray(X, dtype=np.float32)).to(self.device)}
-        return self._uploaded[key]
+        # One-entry upload cache so that fit() does not re-send an unchanged training array every epoch.  The
+        # entry keeps a reference to the host array: id() of a dead temporary (X[:n]) can be handed to the next
+        # one, and would otherwise return the wrong frames.
+        key = (id(X), X.shape, X.__array_interface__["data"][0])
+        hit = self._uploaded.get(key)
+        if hit is None or hit[0] is not X:
+            self._uploaded = {key: (X, torch.from_numpy(np.ascontiguousarray(X, dtype=np.float32)).to(self.device))}
+        return self._uploaded[key][1]
 
     # -- inference --------------------------------------------------------------------------------
     def predict(self, X, batch_size=32, verbose=0):

@@ -76,6 +76,10 @@ def test_weights_round_trip_and_predict_is_deterministic(data, tmp_path):
     other.set_weights([a * 0 for a in w])
     assert float(np.abs(other.predict(X[:4], batch_size=4)).max()) < 1e-3
     assert abs(model.evaluate(X, Y, batch_size=8) - M.custom_loss(Y, p1)) < 1e-5
+    empty = model.predict(X[:0], batch_size=8)              # no frames: an empty [0, 576] result, no launch
+    assert empty.shape == (0, 576) and empty.dtype == np.float32
+    one = model.predict(X[:1], batch_size=32)               # fewer frames than the batch size
+    np.testing.assert_allclose(one, p1[:1], rtol=0, atol=1e-5)
 
 
 def test_device_map_matches_host_metric():
