@@ -122,3 +122,25 @@ def test_device_map_matches_host_metric():
     m_host, m_dev = D.calc_map(Yp, Yt), D.calc_map(Yp, Yt, device=True)
     assert abs(m_host - m_dev) < 0.02 and 0.0 < m_dev < 1.0
     assert D.calc_map(Yt, Yt, device=True) == 1.0
+
+
+def test_setup_model_checkpoint_semantics_and_whole_model_file(data, tmp_path, monkeypatch):
+    """setup_model (models.py:461-507 of the reference): missing checkpoint -> fresh start or plain Exception
+    with no_cp_fatal; present -> loaded.  Model.save / load_model round trip of the 'whole model' file."""
+    from spnet_amd import models as M
+    X, Y = data
+    monkeypatch.chdir(tmp_path)
+    with pytest.raises(Exception, match="No weights file"):
+        M.setup_model(X, try_checkpoint=True, no_cp_fatal=True, weights_file="missing.hdf5", freeze_fac=0.0)
+    model, serial = M.setup_model(X, try_checkpoint=True, weights_file="missing.hdf5", freeze_fac=0.0)
+    assert model is serial and model.optimizer.lr == pytest.approx(1e-5)
+    model.optimizer.lr = 1e-3
+    model.fit(X, Y, batch_size=8, epochs=1, shuffle=False, verbose=0)
+    want = model.predict(X, batch_size=8)
+    model.save_weights("weights.hdf5")
+    again, _ = M.setup_model(X, try_checkpoint=True, no_cp_fatal=True, weights_file="weights.hdf5", freeze_fac=0.0)
+    np.testing.assert_array_equal(again.predict(X, batch_size=8), want)
+    model.save("full_model.h5")
+    whole = M.load_model("full_model.h5", custom_objects={"custom_loss": M.custom_loss})
+    np.testing.assert_array_equal(whole.predict(X, batch_size=8), want)
+    assert whole.count_params() == model.count_params()
