@@ -31,6 +31,10 @@ DW_TRAIN_BYTES_PER_IMAGE = 157.6e6  # depthwise stack, f
 DW_FWD_BYTES_PER_IMAGE = 63.1e6
 
 
+# BASELINE.json's metric string, verbatim
+METRIC = "training images/sec on 512\u00d7384 fake-ESPI, Xception backbone, 1/2/4/8 GPU"
+
+
 def measured_traffic():
     """HBM bytes per family from the committed PMC pass (profiles/r01_n_hbm_traffic.json, folded by
     tools/pmc_traffic.py: rocprofv3 --pmc
@@ -236,7 +240,7 @@ def main():
     if rank == 0:
         ips = BATCH * world * args.steps / dt
         result = {
-            "metric": "training images/sec on 512x384 fake-ESPI, Xception backbone",
+            "metric": METRIC,
             "value": round(ips, 2), "unit": "images/sec", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
