@@ -173,6 +173,12 @@ class Engine:
         self.use_graph = False
         self.drop_seed = 12345
         torch.cuda.set_device(self.dev)
+        # Inference coefficients (scale|shift from the moving statistics, one tiny kernel per BatchNorm) are
+        # recomputed only when the weights or statistics changed since this plan last did: [version] is shared
+        # by all plans over one weight set and bumped by every training forward / optimizer step / load.
+        self._wver = share_from._wver if share_from is not None else [0]
+        self._coeff_ver = -1
+        self._infer_fresh = True
         if share_from is not None:      # second plan (other batch size / inference) over the SAME weights
             for a in ("p_off", "s_off", "l2_n", "n_theta", "theta", "stats", "spec_order"):
                 setattr(self, a, getattr(share_from, a))
@@ -214,6 +220,7 @@ class Engine:
 
     def init_weights(self, seed=0):
         """Keras defaults: glorot_uniform kernels, zeros bias/beta, ones gamma, moving stats 0/1."""
+        self._wver[0] += 1
         g = torch.Generator().manual_seed(seed)
         host = torch.zeros(self.n_theta, dtype=torch.float32)
         for name, (off, n, shape) in self.p_off.items():
@@ -259,6 +266,7 @@ class Engine:
         return out
 
     def load_state_dict(self, sd):
+        self._wver[0] += 1
         for name in self.spec_order:
             t = torch.as_tensor(np.asarray(sd[name]), dtype=torch.float32).reshape(-1)
             if name in self.p_off:
@@ -352,8 +360,15 @@ class Engine:
             raise RuntimeError("engine was built with train=False")
         if X is not None:
             self.x_in.copy_(X.reshape(self.x_in.shape))
+        if training:
+            self._wver[0] += 1              # moving statistics move; this plan's scale|shift now hold batch statistics
+            self._coeff_ver = -1
+        else:
+            self._infer_fresh = self._coeff_ver != self._wver[0]
         for node in self.nodes:
             node.fwd(training)
+        if not training:
+            self._coeff_ver = self._wver[0]
         return self.out
 
     def backward(self, on_node_done=None):
@@ -462,6 +477,7 @@ class Engine:
         b1, b2 = 0.9, 0.999
         if lr is not None:
             self._upload_step_params(lr)
+        self._wver[0] += 1
         L.spnet_adam_step(L.ptr(self.theta), L.ptr(self.grad), L.ptr(self.m), L.ptr(self.v), self.n_theta,
                           self.l2_n, 0.0, b1, b2, self.adam_eps, L2_COEF, grad_scale, L.ptr(self.update_mask),
                           L.ptr(self.sq_scratch), self.loss_out[6:].data_ptr(), self.lr_ptr, _stream())
@@ -789,6 +805,8 @@ class BN:
                                 BN_EPS, BN_MOMENTUM, _stream())
 
     def infer(self):
+        if not self.e._infer_fresh:          # scale|shift of this plan are still valid for the current weights
+            return
         L.spnet_bn_infer_coeffs(self.C, L.ptr(self.gamma), L.ptr(self.beta), L.ptr(self.mm), L.ptr(self.mv),
                                 L.ptr(self.ss), BN_EPS, _stream())
 

@@ -144,3 +144,27 @@ def test_setup_model_checkpoint_semantics_and_whole_model_file(data, tmp_path, m
     whole = M.load_model("full_model.h5", custom_objects={"custom_loss": M.custom_loss})
     np.testing.assert_array_equal(whole.predict(X, batch_size=8), want)
     assert whole.count_params() == model.count_params()
+
+
+def test_inference_coefficients_follow_weight_changes(data):
+    """The predict plan caches its BatchNorm scale|shift between batches; every way of changing the weights or
+    the moving statistics (fit, load_weights, set_weights) must invalidate that cache."""
+    from spnet_amd import models as M
+    X, Y = data
+    model = M.build_model(X, Y0size=576, freeze_fac=0.0)
+    p0 = model.predict(X, batch_size=8)
+    np.testing.assert_array_equal(model.predict(X, batch_size=8), p0)       # cached coefficients, same result
+    model.optimizer.lr = 1e-3
+    model.fit(X, Y, batch_size=8, epochs=1, shuffle=False, verbose=0)       # weights AND moving statistics move
+    p1 = model.predict(X, batch_size=8)
+    assert np.abs(p1 - p0).max() > 1e-6
+    fresh = M.build_model(X, Y0size=576, freeze_fac=0.0)
+    fresh.set_weights(model.get_weights())
+    np.testing.assert_array_equal(fresh.predict(X, batch_size=8), p1)       # a plan without any cache agrees
+    w = model.get_weights()
+    fresh.predict(X, batch_size=8)
+    fresh.set_weights([a * 0.5 for a in w])
+    q = fresh.predict(X, batch_size=8)
+    ref = M.build_model(X, Y0size=576, freeze_fac=0.0)
+    ref.set_weights([a * 0.5 for a in w])
+    np.testing.assert_array_equal(q, ref.predict(X, batch_size=8))
