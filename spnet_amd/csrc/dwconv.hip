@@ -244,7 +244,11 @@ __global__ __launch_bounds__(256) void dw3x3_tile_fwd_kernel(const float* __rest
   static_assert(CC2 * TW == 256, "thread layout");
   extern __shared__ __attribute__((aligned(16))) float4 tile[];   // [(TH+2)][PW][CC4], raw values
   const int c4n = C >> 2;
-  int bid = blockIdx.x;
+  // XCD-aware order: the workgroups one XCD receives cover a contiguous run of (tile, channel chunk) ids, so
+  // the channel chunks of one pixel tile (whose 128-byte lines interleave) and the halos of neighbouring tiles
+  // meet in ONE L2 instead of eight.  Measured: 728-channel planes -17..-25 %, 256 channels neutral, 128
+  // channels (4 chunks per tile) +3 % -> only from 8 chunks per tile on.
+  int bid = (cchunks >= 8) ? xcd_remap(blockIdx.x, gridDim.x) : (int)blockIdx.x;
   const int cc = bid % cchunks; bid /= cchunks;
   const int tw = bid % tiles_w; bid /= tiles_w;
   const int th = bid % tiles_h;
@@ -318,7 +322,11 @@ __global__ __launch_bounds__(256) void dw3x3_tile_bwd_kernel(
   static_assert(CC2 * TW == 256, "thread layout");
   extern __shared__ __attribute__((aligned(16))) float4 tile[];   // dz halo tile; >= 11*256 float2 of reduction scratch
   const int c4n = C >> 2;
-  int bid = blockIdx.x;
+  // XCD-aware order: the workgroups one XCD receives cover a contiguous run of (tile, channel chunk) ids, so
+  // the channel chunks of one pixel tile (whose 128-byte lines interleave) and the halos of neighbouring tiles
+  // meet in ONE L2 instead of eight.  Measured: 728-channel planes -17..-25 %, 256 channels neutral, 128
+  // channels (4 chunks per tile) +3 % -> only from 8 chunks per tile on.
+  int bid = (cchunks >= 8) ? xcd_remap(blockIdx.x, gridDim.x) : (int)blockIdx.x;
   const int cc = bid % cchunks; bid /= cchunks;
   const int sp = bid;                                // spatial workgroup index = partial row
   const int tw = bid % tiles_w; bid /= tiles_w;
