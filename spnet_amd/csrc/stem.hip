@@ -15,7 +15,9 @@ __global__ __launch_bounds__(256) void conv3x3_small_fwd_kernel(const float* __r
   for (int i = threadIdx.x; i < 9 * CIN * COUT; i += blockDim.x) ws[i] = w[i];
   __syncthreads();
   const long total = (long)Bn * OH * OW;
-  for (long p = (long)blockIdx.x * blockDim.x + threadIdx.x; p < total;
+  // XCD-aware order: an XCD's workgroups cover a contiguous run of pixels, so the image rows that vertically
+  // neighbouring windows share stay in one L2
+  for (long p = (long)xcd_remap(blockIdx.x, gridDim.x) * blockDim.x + threadIdx.x; p < total;
        p += (long)gridDim.x * blockDim.x) {
     const int ow = (int)(p % OW);
     long t = p / OW;
@@ -58,7 +60,9 @@ __global__ __launch_bounds__(256) void conv3x3_small_bwd_data_kernel(const float
   for (int i = threadIdx.x; i < 9 * CIN * COUT; i += blockDim.x) ws[i] = w[i];
   __syncthreads();
   const long total = (long)Bn * H * W;
-  for (long p = (long)blockIdx.x * blockDim.x + threadIdx.x; p < total;
+  // XCD-aware order: an XCD's workgroups cover a contiguous run of pixels, so the image rows that vertically
+  // neighbouring windows share stay in one L2
+  for (long p = (long)xcd_remap(blockIdx.x, gridDim.x) * blockDim.x + threadIdx.x; p < total;
        p += (long)gridDim.x * blockDim.x) {
     const int ww = (int)(p % W);
     long t = p / W;
@@ -109,7 +113,9 @@ __global__ __launch_bounds__(256) void conv3x3_small_bwd_weight_kernel(const flo
 #pragma unroll
   for (int i = 0; i < NW; ++i) acc[i] = 0.f;
   const long total = (long)Bn * OH * OW;
-  for (long p = (long)blockIdx.x * blockDim.x + threadIdx.x; p < total;
+  // XCD-aware order: an XCD's workgroups cover a contiguous run of pixels, so the image rows that vertically
+  // neighbouring windows share stay in one L2
+  for (long p = (long)xcd_remap(blockIdx.x, gridDim.x) * blockDim.x + threadIdx.x; p < total;
        p += (long)gridDim.x * blockDim.x) {
     const int ow = (int)(p % OW);
     long t = p / OW;
