@@ -35,17 +35,39 @@ DW_FWD_BYTES_PER_IMAGE = 63.1e6
 METRIC = "training images/sec on 512\u00d7384 fake-ESPI, Xception backbone, 1/2/4/8 GPU"
 
 
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "hbm_traffic_current.json")
+
+
+def kernel_source_hash():
+    """Fingerprint of everything that decides which kernels run and how they touch memory: the HIP sources and the
+    launch plan.  (The GPU box has no .git, so a commit id is not available at run time; the PMC file is stamped
+    with this hash by tools/pmc_traffic.py and with the commit it was taken at.)"""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    files = sorted(glob.glob(os.path.join(ROOT, "spnet_amd", "csrc", "*.hip")) +
+                   glob.glob(os.path.join(ROOT, "spnet_amd", "csrc", "*.h")) +
+                   [os.path.join(ROOT, "spnet_amd", "engine.py"), os.path.join(ROOT, "include", "spnet_hip.h")])
+    for f in files:
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
 def measured_traffic():
-    """HBM bytes per family from the committed PMC pass (profiles/r01_n_hbm_traffic.json, folded by
-    tools/pmc_traffic.py: rocprofv3 --pmc
-    FETCH_SIZE / WRITE_SIZE in separate passes over this same command, FETCH_SIZE doubled as
-    MI355X_MICROARCH.md prescribes for gfx950).  Not a live measurement: PMC passes cannot run inside the
-    timed benchmark."""
-    p = os.path.join(ROOT, "profiles", "r01_n_hbm_traffic.json")
-    if not os.path.exists(p):
-        return {}
-    with open(p) as f:
-        return json.load(f)
+    """HBM bytes per family from the committed PMC pass (profiles/hbm_traffic_current.json, folded by
+    tools/pmc_traffic.py: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes over this same command,
+    FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950).  PMC passes cannot run inside the timed
+    benchmark, so the file is only used when it was taken with EXACTLY the kernels and launch plan being timed
+    (same kernel_source_hash); otherwise traffic is reported as null."""
+    if not os.path.exists(TRAFFIC_FILE):
+        return {}, "no PMC file"
+    with open(TRAFFIC_FILE) as f:
+        tr = json.load(f)
+    want = kernel_source_hash()
+    if tr.get("kernel_source_hash") != want:
+        return {}, "PMC file is stale: taken at kernel_source_hash %s, running %s" % (tr.get("kernel_source_hash"), want)
+    return tr, "PMC passes at kernel_source_hash %s (commit %s)" % (want, tr.get("commit", "?"))
 
 
 def labels_to_Y(label_rows):
@@ -136,12 +158,97 @@ def secondary(args):
                       "data": "synthetic (uniform noise)", "config": {"workload": "%s, %dx%d frames, batch %d" % (args.mode, w, h, b)}}))
 
 
+def predict_bench(args):
+    """BASELINE configs[4]: predict_spnet.py's inference loop -- Xception, batch 128, 512x384 frames -- on one GPU.
+    A step = one batch of 128 frames through the hipGraph-captured forward (Engine.predict_step); frames are resident
+    in HBM when the timed region starts.  Also reported: the same loop through Model.predict over HOST frames
+    (pinned ring + copy stream: the PCIe-inclusive rate, never `value`), and the eager-launch rate."""
+    import torch
+    from spnet_amd import fake_espi as F
+    from spnet_amd import parallel
+    from spnet_amd.engine import Engine, KernelTimer
+    PB = 128
+    pool = max(PB, min(args.pool, 2048) // PB * PB)
+    X_u8, _ = F.generate(pool, seed=11, workers=max(2, min(16, os.cpu_count() or 8)))
+    parallel.init_distributed()
+    dev = parallel.local_device()
+    torch.cuda.set_device(dev)
+    X_host = F.to_network_input(X_u8)
+    X_pool = torch.from_numpy(X_host).to(dev)
+    eng = Engine(H, W, PB, device=str(dev), seed=0, train=False)
+    it = [0]
+
+    def step(graph=True):
+        lo = (it[0] * PB) % pool
+        it[0] += 1
+        eng.x_in.copy_(X_pool[lo:lo + PB])
+        return eng.predict_step(use_graph=graph)
+
+    def timed(n, graph):
+        for _ in range(args.warmup):
+            step(graph)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            step(graph)
+        torch.cuda.synchronize()
+        return time.perf_counter() - t0
+
+    dt = timed(args.steps, True)
+    dt_eager = timed(args.steps, False)
+    timer = KernelTimer()
+    eng.prof = timer
+    timed(args.steps, False)
+    eng.prof = None
+    tot = timer.totals()
+    g_n, g_ms, g_flop = tot["gemm"]
+    d_n, d_ms, _ = tot["dw"]
+    n_prof = args.steps + args.warmup
+    gemm_tflops = g_flop / (g_ms * 1e-3) / 1e12
+    dw_gbs = DW_FWD_BYTES_PER_IMAGE * PB * n_prof / (d_ms * 1e-3) / 1e9
+    # PCIe-inclusive: model.predict over host frames, as predict_spnet.py calls it
+    from spnet_amd.models import Model
+    m = Model((H, W, 1), Y0size=576, seed=0, device=str(dev))
+    nh = min(pool, 1024)
+    m.predict(X_host[:PB], batch_size=PB)
+    t0 = time.perf_counter()
+    m.predict(X_host[:nh], batch_size=PB)
+    dt_host = time.perf_counter() - t0
+    note = "HIP events around every launch of the family during %d eager forwards after the timed region" % n_prof
+    print(json.dumps({
+        "metric": "inference frames/sec, predict_spnet.py path (model.predict), Xception, batch 128 over 512x384 frames "
+                  "(BASELINE configs[4]; secondary to the training metric)",
+        "value": round(PB * args.steps / dt, 1), "unit": "frames/sec", "n_gpus": 1, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "configs[4]: inference-only forward, Xception, 512x384 fake-ESPI frames, batch 128, "
+                               "hipGraph-captured plan, frames resident in HBM", "batch": PB, "frame_hw": [H, W],
+                   "pool_frames": pool, "eager_frames_per_sec": round(PB * args.steps / dt_eager, 1),
+                   "host_frames_streamed_frames_per_sec": round(nh / dt_host, 1),
+                   "host_frames_note": "Model.predict over %d host frames: pageable -> pinned ring -> HBM on a copy "
+                                       "stream, overlapped with the forward passes (PCIe-inclusive; not `value`)" % nh},
+        "roofline": {"kernel": "fp32 MFMA GEMM family, forward form (pointwise / residual / Dense + conv3x3_fwd_kernel)",
+                     "bound": "mfma", "achieved": round(gemm_tflops, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                     "frac": round(gemm_tflops / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                     "launches_per_step": g_n / n_prof, "ms_per_step": round(g_ms / n_prof, 3), "measured": note},
+        "roofline_secondary": {"kernel": "dw3x3_tile_fwd_kernel (34 depthwise layers, forward)", "bound": "hbm",
+                               "achieved": round(dw_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                               "frac": round(dw_gbs / HBM_PEAK_GBS, 4), "traffic": None,
+                               "launches_per_step": d_n / n_prof, "ms_per_step": round(d_ms / n_prof, 3), "measured": note},
+    }), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--pool", type=int, default=256, help="synthetic frames resident per GPU")
+    ap.add_argument("--pool", type=int, default=4096,
+                    help="synthetic frames resident per GPU (SURVEY 8d: >= 4,096; 3.2 GB of fp32 frames, far beyond "
+                         "the 256 MiB Infinity Cache)")
+    ap.add_argument("--sustained-seconds", type=float, default=6.0,
+                    help="after the timed region keep stepping for this long and report the rate separately "
+                         "(clocks under sustained load); 0 = skip")
     ap.add_argument("--cpu-baseline-steps", type=int, default=2)
     ap.add_argument("--cpu-baseline-batch", type=int, default=8)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -164,25 +271,31 @@ def main():
     from spnet_amd.engine import Engine, KernelTimer
     from spnet_amd import _lib as L
 
+    if args.mode == "predict" and (args.height, args.width) == (H, W) and args.batch in (BATCH, 128):
+        return predict_bench(args)
     if (args.height, args.width, args.batch, args.mode) != (H, W, BATCH, "train"):
         return secondary(args)
-    rank, local_rank, world = parallel.init_distributed()
+    # ---- synthetic data first: the generator forks worker processes, which must happen before this process
+    # initialises the GPU or joins the process group (rank-specific frames: weak scaling)
+    rank, local_rank, world = parallel.env_world()
     if world != args.gpus:
         raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, world))
-    dev = torch.device("cuda", local_rank % torch.cuda.device_count())   # (>1 rank per GPU only in gloo rehearsals)
-    torch.cuda.set_device(dev)
-
-    # ---- synthetic data, resident in HBM before timing (rank-specific frames: weak scaling)
+    t_gen = time.perf_counter()
     X_u8, labels = F.generate(args.pool, seed=1 + rank, workers=max(2, min(16, (os.cpu_count() or 8) // world)))
     Y_host = labels_to_Y(labels)
+    t_gen = time.perf_counter() - t_gen
+    rank, local_rank, world = parallel.init_distributed()
+    dev = parallel.local_device()                  # (>1 rank per GPU only in gloo rehearsals)
+    torch.cuda.set_device(dev)
+    # ---- resident in HBM before timing
     X_pool = torch.from_numpy(F.to_network_input(X_u8)).to(dev)
     Y_pool = torch.from_numpy(Y_host).to(dev)
     np.random.seed(1 + rank)
 
-    eng = Engine(H, W, BATCH, device=str(dev), seed=0)
+    eng = Engine(H, W, BATCH, device=str(dev), seed=0, rank=rank)
     aug = DeviceAugmenter(X_pool)
     upload = L.AsyncUploader(dev)
-    reducer = parallel.GradReducer(eng.grad, eng.head_grad_range()) if world > 1 else None
+    reducer = eng.make_reducer() if world > 1 else None
     # 1-cycle table of the reference's own run configuration (lr_max 4e-5, 40k frames, 100 epochs)
     lrs = get_1cycle_schedule(lr_max=4e-5, n_data_points=40000, epochs=100, batch_size=BATCH * world)
     order = np.random.RandomState(7).permutation(args.pool)
@@ -215,6 +328,38 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     loss = float(out[5])
+
+    # Host cost of enqueueing ONE step into an idle GPU (the figure above is taken under queue back-pressure: the
+    # host runs ahead until the launch queue is full and then waits for the GPU, so it reads ~ the GPU step time).
+    t_idle = []
+    for _ in range(3):
+        fence()
+        t1 = time.perf_counter()
+        step()
+        t_idle.append(time.perf_counter() - t1)
+    fence()
+    t_host_idle = min(t_idle)
+
+    # Sustained leg: the same step for several seconds (reported separately; `value` stays the K timed steps).
+    sustained = None
+    if args.sustained_seconds > 0:
+        n_s = 0
+        fence()
+        t1 = time.perf_counter()
+        while True:
+            for _ in range(20):
+                step()
+            n_s += 20
+            if time.perf_counter() - t1 >= args.sustained_seconds:     # host time; the queue is at most ~4 steps deep
+                break
+        fence()
+        dts = time.perf_counter() - t1
+        if world > 1:
+            tt = torch.tensor([dts, float(n_s)], dtype=torch.float64, device=dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dts = float(tt[0].item())
+        sustained = {"seconds": round(dts, 2), "steps": n_s, "images_per_sec": round(BATCH * world * n_s / dts, 1),
+                     "ms_per_step": round(1e3 * dts / n_s, 3)}
 
     # Roofline leg: the same K steps replayed with every kernel on ONE stream (no weight-gradient overlap),
     # so that a kernel's HIP-event duration is its own and not that of two kernels sharing the chip.
@@ -249,14 +394,18 @@ def main():
                        "global_batch": BATCH * world, "frame_hw": [H, W], "pool_frames_per_gpu": args.pool,
                        "parallelism": "dp%d" % world, "final_loss": round(loss, 6),
                        "wgrad_overlap": not args.no_overlap,
-                       "host_enqueue_ms_per_step": round(1e3 * t_host / args.steps, 3)},
+                       "host_enqueue_ms_per_step_backpressured": round(1e3 * t_host / args.steps, 3),
+                       "host_enqueue_ms_per_step_gpu_idle": round(1e3 * t_host_idle, 3),
+                       "pool_generation_s": round(t_gen, 1)},
         }
+        if sustained is not None:
+            result["sustained"] = sustained
         if timer is not None:
             tot = timer.totals()
             fam = {}
             for k, (n, ms, work) in tot.items():
                 fam[k] = dict(launches_per_step=n / args.steps, ms_per_step=round(ms / args.steps, 3))
-            tr = measured_traffic()
+            tr, tr_note = measured_traffic()
             g_traffic = None
             if "gemm" in tr:    # PMC bytes of the family per step / this run's family launches per step
                 g_traffic = (tr["gemm"]["hbm_read_bytes_per_step"] + tr["gemm"]["hbm_write_bytes_per_step"]) / \
@@ -289,6 +438,7 @@ def main():
             note = ("HIP events around every launch of the family during %d extra steps replayed on one stream "
                     "(weight-gradient overlap off) right after the timed region" % args.steps)
             roof_gemm["measured"] = roof_dw["measured"] = note
+            roof_gemm["traffic_source"] = roof_dw["traffic_source"] = tr_note
             result["roofline"] = roof_gemm if g_ms >= d_ms else roof_dw
             result["roofline_secondary"] = roof_dw if g_ms >= d_ms else roof_gemm
             result["kernel_families"] = fam

@@ -46,6 +46,15 @@ int spnet_gemm_f32_batched(const float* A0, const float* B0, float* C0, const lo
                            int a_major, int lda, int b_major, int ldb, int ldc, int M, int N, int K, int tile,
                            void* stream);
 
+/* dX[M,N] = dY[M,K] B[K,N] where dY = a[k]*g + b[k]*yp + c[k] is the output of a BatchNormalization backward
+ * (keras BatchNormalization behind every SeparableConv2D / Conv2D of Xception), blended from the incoming gradient
+ * g and the saved pre-normalisation tensor yp while the A tile is staged: dY never makes a pass of its own.
+ * coef = [a | b | c], cld floats each (from spnet_bn_bwd_coeffs*; zero beyond channel K-1; cld % 32 == 0,
+ * cld >= K rounded up to 32).  B is W^T in the output-major form (spnet_transpose_batched).  dy_out (or NULL)
+ * receives dY once, for the layer's weight-gradient GEMM. */
+int spnet_gemm_f32_bnblend(const float* g, const float* yp, const float* coef, int cld, int lda, const float* B,
+                           int ldb, float* C, int ldc, int M, int N, int K, int tile, float* dy_out, void* stream);
+
 /* 3x3 VALID stride-1 patch matrix and its adjoint (block1_conv2 of keras Xception). */
 int spnet_im2col3x3(const float* x, float* col, int B, int H, int W, int C, void* stream);
 int spnet_col2im3x3(const float* dcol, float* dx, int B, int H, int W, int C, void* stream);
@@ -59,6 +68,11 @@ int spnet_conv3x3_dgrad(const float* dy, const float* w, float* dx, int B, int H
 long spnet_conv3x3_wgrad_ws(int B, int H, int W, int cin, int cout);
 int spnet_conv3x3_wgrad(const float* x, const float* dy, float* dw, int B, int H, int W, int cin, int cout,
                         float* workspace, long ws_floats, void* stream);
+/* njobs matrix transposes in one launch: dst_j[c][r] = src_j[r][c]; jobs: DEVICE array of {src, dst, R, C}
+ * (four 64-bit words per job).  The engine keeps W^T of every pointwise kernel (refreshed once per optimizer
+ * step), so the data-gradient product dX = dY W^T of keras SeparableConv2D / Conv2D(1x1) runs in the
+ * forward operand form (call site spnet/models.py:357-359). */
+int spnet_transpose_batched(const void* jobs, int njobs, int max_rows, int max_cols, void* stream);
 /* out[M][ldc] = sum over nslab slabs of M*N floats, in slab order (the second stage of every K split). */
 int spnet_reduce_slabs(const float* ws, int nslab, int M, int N, float* out, int ldc, void* stream);
 /* Even-pixel gather / scatter-add: TF 'same' 1x1 stride-2 residual convs of Xception blocks 2,3,4,13. */
@@ -123,6 +137,14 @@ int spnet_bn_bwd_from_partials(const float* x, const float* dy, long M, int C, c
                                const float* beta, const float* save_mean, const float* save_invstd, int P,
                                const float* partial, float* dx, float* dgamma, float* dbeta, float* coeffs,
                                void* stream);
+
+/* Reduction half of the backward only (dgamma, dbeta, blend coefficients for spnet_gemm_f32_bnblend). */
+int spnet_bn_bwd_coeffs_from_partials(int P, const float* partial, long M, int C, const float* gamma,
+                                      const float* save_mean, const float* save_invstd, float* dgamma, float* dbeta,
+                                      float* coef, int cld, void* stream);
+int spnet_bn_bwd_coeffs(const float* x, const float* dy, long M, int C, const float* gamma, const float* beta,
+                        const float* save_mean, const float* save_invstd, float* dgamma, float* dbeta, float* coef,
+                        int cld, float* workspace, void* stream);
 
 /* ---- pooling --------------------------------------------------------------------------------- */
 /* MaxPooling2D(3, strides 2, 'same') + residual add (Xception blocks 2,3,4,13); idx4 packs the argmax

@@ -71,6 +71,71 @@ def maxpool3x3s2_same(x):
     return _nhwc(F.max_pool2d(xc, 3, 2))
 
 
+class Decisions:
+    """The DISCRETE decisions of one forward pass, in application order: sign masks of every LeakyReLU / ReLU input
+    and the arg-max tap (kh*3+kw) of every max-pool window.
+
+    A network with ReLUs and max-pools is piecewise linear in its activations: two correct fp32 evaluations that
+    round an input sitting within ~1e-6 of zero (or two window entries within ~1e-6 of each other) to different sides
+    take different linear pieces, and the GRADIENTS then differ by whole terms, not by rounding (measured: the fp32
+    CPU evaluation of this very oracle deviates from its fp64 evaluation by up to 20 % in single tensors at 384x512).
+    Decisions() records the pieces a forward pass took; Decisions(relu, pool) makes forward() take the given ones,
+    and notes for each site how far from a tie the overridden elements were (`flips`).  Parity tests evaluate the
+    fp64 oracle on the DEVICE's pieces: everything continuous must then agree to rounding, and every overridden
+    decision must have been a tie at fp32 resolution."""
+
+    def __init__(self, relu=None, pool=None):
+        self.force = relu is not None
+        self.relu = list(relu) if relu is not None else []
+        self.pool = list(pool) if pool is not None else []
+        self._ri = self._pi = 0
+        self.flips = []          # (site, n_overridden, largest |x| (or window gap) among them / largest |x| of the tensor)
+
+    def act(self, x, slope):
+        if not self.force:
+            self.relu.append((x > 0).detach())
+            return F.leaky_relu(x, slope) if slope else F.relu(x)
+        m = self.relu[self._ri].to(x.device)
+        self._ri += 1
+        diff = m != (x > 0)
+        n = int(diff.sum())
+        if n:
+            self.flips.append(("relu%d" % (self._ri - 1), n, float(x.detach()[diff].abs().max() / x.detach().abs().max())))
+        return torch.where(m, x, slope * x)
+
+    def pool_taps(self, cols):
+        """cols [B,C,9,OH,OW] window entries (-inf padding) -> taps [B,C,1,OH,OW] to gather."""
+        own = cols.detach().argmax(2, keepdim=True)
+        if not self.force:
+            self.pool.append(own)
+            return own
+        t = self.pool[self._pi].to(cols.device)
+        self._pi += 1
+        diff = t != own
+        n = int(diff.sum())
+        if n:
+            gap = (cols.detach().gather(2, own) - cols.detach().gather(2, t))[diff]
+            self.flips.append(("pool%d" % (self._pi - 1), n, float(gap.max() / cols.detach()[torch.isfinite(cols.detach())].abs().max())))
+        return t
+
+
+def _act(x, slope, decisions):
+    if decisions is None:
+        return F.leaky_relu(x, slope) if slope else F.relu(x)
+    return decisions.act(x, slope)
+
+
+def maxpool3x3s2_same_decided(x, decisions):
+    """maxpool3x3s2_same with the window arg-max recorded in / taken from `decisions`."""
+    B, H, W, C = x.shape
+    oh, ow = -(-H // 2), -(-W // 2)
+    ph = max((oh - 1) * 2 + 3 - H, 0)
+    pw = max((ow - 1) * 2 + 3 - W, 0)
+    xc = F.pad(_nchw(x), (pw // 2, pw - pw // 2, ph // 2, ph - ph // 2), value=float("-inf"))
+    cols = F.unfold(xc, 3, stride=2).reshape(B, C, 9, oh, ow)
+    return _nhwc(cols.gather(2, decisions.pool_taps(cols)).squeeze(2))
+
+
 def avgpool2(x):
     return _nhwc(F.avg_pool2d(_nchw(x), 2))
 
@@ -195,16 +260,16 @@ def count_params(P):
 
 
 # ------------------------------------------------------------------ forward
-def stem(P, x, training, drop_mask=None, taps=None):
+def stem(P, x, training, drop_mask=None, taps=None, decisions=None):
     """spnet/models.py:321-340.  x [B,H,W,1] -> [B,H/2,W/2,3]."""
     def bn(name, t):
         return batchnorm(t, P[name + "/gamma"], P[name + "/beta"], P[name + "/moving_mean"],
                          P[name + "/moving_variance"], training)
     t = conv2d(x, P["conv2d_1/kernel"], 1, "same")
     t = avgpool2(t)
-    t = F.leaky_relu(bn("batch_normalization_1", t), 0.1)
+    t = _act(bn("batch_normalization_1", t), 0.1, decisions)
     t = conv2d(t, P["conv2d_2/kernel"], 1, "same")
-    t = F.leaky_relu(bn("batch_normalization_2", t), 0.1)
+    t = _act(bn("batch_normalization_2", t), 0.1, decisions)
     t = conv2d(t, P["conv2d_3/kernel"], 1, "same")
     t = bn("batch_normalization_3", t)
     t = t + avgpool2(x)                      # [.,.,.,1] broadcasts over the 3 channels
@@ -215,7 +280,7 @@ def stem(P, x, training, drop_mask=None, taps=None):
     return t
 
 
-def backbone(P, x, training, taps=None):
+def backbone(P, x, training, taps=None, decisions=None):
     res = None
     for lay in xception_layers():
         kind = lay[0]
@@ -227,7 +292,7 @@ def backbone(P, x, training, taps=None):
             if taps is not None:
                 taps[n] = x
         elif kind == "relu":
-            x = F.relu(x)
+            x = _act(x, 0.0, decisions)
         elif kind == "res_conv":
             _, cn, bnn, cin, cout = lay
             r = conv2d(x, P[cn + "/kernel"], 2, "same")
@@ -238,7 +303,7 @@ def backbone(P, x, training, taps=None):
             n = lay[1]
             x = pwconv(dwconv3x3(x, P[n + "/depthwise_kernel"]), P[n + "/pointwise_kernel"])
         elif kind == "pool":
-            x = maxpool3x3s2_same(x)
+            x = maxpool3x3s2_same(x) if decisions is None else maxpool3x3s2_same_decided(x, decisions)
         elif kind == "add_res":
             x = x + res
     if taps is not None:
@@ -246,10 +311,10 @@ def backbone(P, x, training, taps=None):
     return x
 
 
-def forward(P, X, training=False, drop_mask=None, taps=None):
-    """X [B,H,W,1] -> [B,n_out] in normalised units (linear Dense output)."""
-    x = stem(P, X, training, drop_mask, taps)
-    x = backbone(P, x, training, taps)
+def forward(P, X, training=False, drop_mask=None, taps=None, decisions=None):
+    """X [B,H,W,1] -> [B,n_out] in normalised units (linear Dense output).  decisions: see Decisions."""
+    x = stem(P, X, training, drop_mask, taps, decisions)
+    x = backbone(P, x, training, taps, decisions)
     flat = x.reshape(x.shape[0], -1)          # NHWC flatten order (Keras Flatten on channels_last)
     return flat @ P["FinalOutput/kernel"] + P["FinalOutput/bias"]
 
@@ -288,13 +353,13 @@ class Trainer:
         self.m = {k: torch.zeros_like(P[k]) for k in self.names}
         self.v = {k: torch.zeros_like(P[k]) for k in self.names}
 
-    def grads(self, X, Y, drop_mask=None, include_l2=True):
+    def grads(self, X, Y, drop_mask=None, include_l2=True, decisions=None):
         """Returns (data_loss, total_loss_with_l2, {name: grad}, y_pred) and updates BN moving stats.
         include_l2=False differentiates the data term only (the product folds the l2 gradient into
         its optimizer kernel)."""
         leaves = {k: self.P[k].detach().clone().requires_grad_(True) for k in self.names}
         Pg = OrderedDict((k, leaves.get(k, self.P[k])) for k in self.P)
-        yp = forward(Pg, X, training=True, drop_mask=drop_mask)
+        yp = forward(Pg, X, training=True, drop_mask=drop_mask, decisions=decisions)
         data = custom_loss(Y, yp, self.loss_type)
         total = data + l2_penalty(Pg)
         gs = torch.autograd.grad(total if include_l2 else data, [leaves[k] for k in self.names])

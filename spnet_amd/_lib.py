@@ -33,6 +33,7 @@ _SIGS = {
     "spnet_conv3x3_wgrad_ws": (c_long, [c_int, c_int, c_int, c_int, c_int]),
     "spnet_conv3x3_wgrad": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, P, c_long, P]),
     "spnet_reduce_slabs": (c_int, [P, c_int, c_int, c_int, P, c_int, P]),
+    "spnet_transpose_batched": (c_int, [P, c_int, c_int, c_int, P]),
     "spnet_gather_s2": (c_int, [P, P, c_int, c_int, c_int, c_int, P]),
     "spnet_scatter_add_s2": (c_int, [P, P, c_int, c_int, c_int, c_int, P]),
     "spnet_dwconv3x3_fwd": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, P]),
@@ -50,6 +51,9 @@ _SIGS = {
     "spnet_bn_apply": (c_int, [P, c_long, c_int, P, c_int, P, c_int, P, P]),
     "spnet_bn_bwd_from_partials": (c_int, [P, P, c_long, c_int, P, P, P, P, c_int, P, P, P, P, P, P]),
     "spnet_gemm_f32_colstats": (c_int, [P, c_int, c_int, P, c_int, c_int, P, c_int, c_int, c_int, c_int, c_int, P, P, P]),
+    "spnet_gemm_f32_bnblend": (c_int, [P, P, P, c_int, c_int, P, c_int, P, c_int, c_int, c_int, c_int, c_int, P, P]),
+    "spnet_bn_bwd_coeffs_from_partials": (c_int, [c_int, P, c_long, c_int, P, P, P, P, P, P, c_int, P]),
+    "spnet_bn_bwd_coeffs": (c_int, [P, P, c_long, c_int, P, P, P, P, P, P, P, c_int, P, P]),
     "spnet_gemm_f32_batched": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P]),
     "spnet_bn_ws": (c_long, [c_long, c_int]),
     "spnet_bn_fwd_train": (c_int, [P, c_long, c_int, P, P, P, P, P, P, P, c_int, P, c_int, P, c_float, c_float, P, P]),

@@ -90,8 +90,10 @@ class DeviceAugmenter:
         self.n_salt, self.n_pepper = saltpepper_counts(self.shape)
         self._upload = None
 
-    def draw(self, indices):
-        """Host-side parameter draw for the given frame indices, reference RNG order per frame."""
+    def draw(self, indices, seeds=None):
+        """Host-side parameter draw for the given frame indices, reference RNG order per frame.  seeds (optional,
+        one per frame): re-seed numpy's and python's global RNGs before each frame's draws (data parallel: a
+        sample's augmentation then depends on its own seed only, not on what was drawn before it)."""
         B = len(indices)
         npts = self.n_salt + self.n_pepper
         rects = np.zeros((B, MAX_RECTS, 4), np.int32)
@@ -100,6 +102,9 @@ class DeviceAugmenter:
         coords = np.zeros((B, 2, npts), np.int32)
         flag = np.zeros(B, np.int32)
         for j, i in enumerate(indices):
+            if seeds is not None:
+                np.random.seed(int(seeds[j]))
+                random.seed(int(seeds[j]))
             lo, hi = self.mm_host[i]
             rs = draw_cutout(self.shape, lo, hi)
             nrect[j] = len(rs)

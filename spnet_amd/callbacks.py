@@ -91,15 +91,18 @@ class AugmentOnTheFly(Callback):
     tensor) or already a device tensor.  The augmented set is a second device tensor that the model's
     fit() reads batches from (`model.set_train_frames`)."""
 
-    def __init__(self, X, Y, orig_img_shape=(384, 512), aug_every=1, chunk=256):
+    def __init__(self, X, Y, orig_img_shape=(384, 512), aug_every=1, chunk=256, seed=1):
         super().__init__()
         import torch
+        from . import parallel
         from .augmentation import DeviceAugmenter
         self.X, self.Y = X, Y
         self.aug_every = aug_every
         self.orig_img_shape = orig_img_shape
         self.chunk = chunk
-        dev = torch.device("cuda", torch.cuda.current_device())
+        self.seed = seed
+        parallel.init_distributed()          # this rank's GPU (no-op if the model already did it)
+        dev = parallel.local_device()
         self.X_orig = X if isinstance(X, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(X)).to(dev)
         self.X_aug = torch.empty_like(self.X_orig)
         self.augmenter = DeviceAugmenter(self.X_orig)
@@ -112,6 +115,9 @@ class AugmentOnTheFly(Callback):
     def on_epoch_begin(self, epoch, logs=None):
         if 0 != epoch % self.aug_every:
             return
+        shard = getattr(self.model, "epoch_indices", None) if getattr(self.model, "world", 1) > 1 else None
+        if shard is not None:
+            return self._augment_shard(np.asarray(shard), getattr(self.model, "_epochs_seen", epoch))
         n = self.X_orig.shape[0]
         for lo in range(0, n, self.chunk):
             hi = min(n, lo + self.chunk)
@@ -119,6 +125,22 @@ class AugmentOnTheFly(Callback):
                 print("   Augmenting on the fly: ", hi, "/", n, "\r", sep="", end="")
             self.augmenter.augment(list(range(lo, hi)), self.X_aug[lo:hi])
         print("")
+
+
+    def _augment_shard(self, shard, epoch):
+        """Data parallel: only the samples this rank trains on in this epoch are augmented, each from its own RNG
+        stream seeded by (seed, epoch, sample index) -- the augmented frame of a sample does not depend on the world
+        size or on the rank that draws it."""
+        import torch
+        from . import parallel
+        tmp = None
+        for lo in range(0, len(shard), self.chunk):
+            idx = shard[lo:lo + self.chunk]
+            if tmp is None or tmp.shape[0] != len(idx):
+                tmp = torch.empty((len(idx),) + tuple(self.X_aug.shape[1:]), device=self.X_aug.device)
+            seeds = [parallel.sample_seed(self.seed, epoch, i) for i in idx]
+            self.augmenter.apply(self.augmenter.draw(list(idx), seeds=seeds), tmp)
+            self.X_aug.index_copy_(0, torch.as_tensor(idx, dtype=torch.int64, device=self.X_aug.device), tmp)
 
 
 # ----------------------------------------------------------------------------- checkpoints

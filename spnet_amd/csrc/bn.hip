@@ -249,19 +249,30 @@ __global__ __launch_bounds__(256) void bn_infer_coeffs_kernel(
 
 // Backward: partial [P][2][C] -> dgamma, dbeta and the three per-channel coefficients of
 //   dx = k1 * g + k2 * xhat + k3,  g = dy * act'(.)
+// BLEND: the coefficients are written in the form the GEMM operand blend consumes (TileStage XF),
+//   dx = k1 * g + k2 * x + k3  on the RAW pre-normalisation x  (k2' = k2*invstd, k3' = k3 - k2*invstd*mean),
+// as three arrays `cld` floats apart; otherwise dx = k1 * g + k2 * xhat + k3 (bn_bwd_apply kernels).
+template <int BLEND>
 __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(
     const float* __restrict__ partial, int P, int C, long M, const float* __restrict__ gamma,
-    const float* __restrict__ invstd, float* __restrict__ dgamma, float* __restrict__ dbeta,
-    float* __restrict__ k1, float* __restrict__ k2, float* __restrict__ k3) {
+    const float* __restrict__ invstd, const float* __restrict__ mean, float* __restrict__ dgamma,
+    float* __restrict__ dbeta, float* __restrict__ k1, float* __restrict__ k2, float* __restrict__ k3) {
   double sg, sgx;
   const int c = combine_partials(partial, P, C, &sg, &sgx);
   if (c < 0) return;
   dbeta[c] = (float)sg;
   dgamma[c] = (float)sgx;
-  const double a = (double)gamma[c] * (double)invstd[c];
+  const double is = (double)invstd[c];
+  const double a = (double)gamma[c] * is;
+  const double b = -a * sgx / (double)M, d = -a * sg / (double)M;
   k1[c] = (float)a;
-  k2[c] = (float)(-a * sgx / (double)M);
-  k3[c] = (float)(-a * sg / (double)M);
+  if (BLEND) {
+    k2[c] = (float)(b * is);
+    k3[c] = (float)(d - b * is * (double)mean[c]);
+  } else {
+    k2[c] = (float)b;
+    k3[c] = (float)d;
+  }
 }
 
 // ---------------------------------------------------------------- apply kernels
@@ -466,8 +477,8 @@ extern "C" int spnet_bn_bwd(const float* x, const float* dy, long M, int C, cons
   if ((C & 3) && C > 4) return (int)hipErrorInvalidValue;
   const int parts = bn_parts(M, C);
   launch_partial<1>(x, dy, M, C, save_mean, save_invstd, gamma, beta, act, workspace, parts, st);
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + BN_FIN_CH - 1) / BN_FIN_CH), dim3(256), 0, st, workspace, parts,
-                     C, M, gamma, save_invstd, dgamma, dbeta, coeffs, coeffs + C, coeffs + 2 * C);
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel<0>, dim3((C + BN_FIN_CH - 1) / BN_FIN_CH), dim3(256), 0, st, workspace, parts,
+                     C, M, gamma, save_invstd, save_mean, dgamma, dbeta, coeffs, coeffs + C, coeffs + 2 * C);
   if (C & 3) {
     const long n = M * C;
     hipLaunchKernelGGL(bn_bwd_apply_scalar_kernel, dim3(spnet_ew_grid(n, 256)), dim3(256), 0, st, x,
@@ -522,10 +533,35 @@ extern "C" int spnet_bn_bwd_from_partials(const float* x, const float* dy, long 
                                           float* dgamma, float* dbeta, float* coeffs, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   if (C & 3) return (int)hipErrorInvalidValue;
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + BN_FIN_CH - 1) / BN_FIN_CH), dim3(256), 0, st, partial, P,
-                     C, M, gamma, save_invstd, dgamma, dbeta, coeffs, coeffs + C, coeffs + 2 * C);
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel<0>, dim3((C + BN_FIN_CH - 1) / BN_FIN_CH), dim3(256), 0, st, partial, P,
+                     C, M, gamma, save_invstd, save_mean, dgamma, dbeta, coeffs, coeffs + C, coeffs + 2 * C);
   const long n4 = M * (C / 4);
   hipLaunchKernelGGL(bn_bwd_apply_vec_kernel, dim3(spnet_ew_grid(n4, 256)), dim3(256), 0, st, x, dy, M, C,
                      save_mean, save_invstd, gamma, beta, 0, coeffs, coeffs + C, coeffs + 2 * C, dx);
+  SPNET_RETURN_LAUNCH_STATUS();
+}
+
+// The reduction half of the backward only: dgamma, dbeta and the blend coefficients [k1 | k2' | k3'] (cld floats
+// apart, the caller keeps the tail beyond C zero) with which a GEMM builds dx = k1*g + k2'*x + k3' while it stages
+// its operand (spnet_gemm_f32_bnblend) -- no pass over the activations here.  Sums from partial[P][2][C] ...
+extern "C" int spnet_bn_bwd_coeffs_from_partials(int P, const float* partial, long M, int C, const float* gamma,
+                                                 const float* save_mean, const float* save_invstd, float* dgamma,
+                                                 float* dbeta, float* coef, int cld, void* stream) {
+  if (cld < C || !coef) return (int)hipErrorInvalidValue;
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel<1>, dim3((C + BN_FIN_CH - 1) / BN_FIN_CH), dim3(256), 0, (hipStream_t)stream,
+                     partial, P, C, M, gamma, save_invstd, save_mean, dgamma, dbeta, coef, coef + cld, coef + 2 * cld);
+  SPNET_RETURN_LAUNCH_STATUS();
+}
+
+// ... or from an own reduction pass over (x, dy) (no activation behind this BatchNorm).  workspace: spnet_bn_ws(M,C).
+extern "C" int spnet_bn_bwd_coeffs(const float* x, const float* dy, long M, int C, const float* gamma,
+                                   const float* beta, const float* save_mean, const float* save_invstd,
+                                   float* dgamma, float* dbeta, float* coef, int cld, float* workspace, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  if ((C & 3) || cld < C || !coef) return (int)hipErrorInvalidValue;
+  const int parts = bn_parts(M, C);
+  launch_partial<1>(x, dy, M, C, save_mean, save_invstd, gamma, beta, 0, workspace, parts, st);
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel<1>, dim3((C + BN_FIN_CH - 1) / BN_FIN_CH), dim3(256), 0, st, workspace, parts,
+                     C, M, gamma, save_invstd, save_mean, dgamma, dbeta, coef, coef + cld, coef + 2 * cld);
   SPNET_RETURN_LAUNCH_STATUS();
 }

@@ -8,6 +8,7 @@
 //   bwd_data   dx = dw3x3(dy, flip(w)) * (x > 0 if relu_in) (+ add)
 //   bwd_weight dw[tap][c] = sum_{b,h,w} relu?(x)[b,h+kh-1,w+kw-1,c] * dy[b,h,w,c]   (two-stage, deterministic)
 #include "common.h"
+#include <stdlib.h>
 
 #define DW_STRIP 4
 
@@ -585,10 +586,26 @@ extern "C" int spnet_reduce_rows(const float* in, int P, int L, float* out, void
 struct DwGeom { int cfg, th, tw, cc4, tiles_h, tiles_w, cchunks; long nblk; size_t lds_fwd, lds_bwd; };
 // cfg 1: 6x8 pixel tile x 16 channel quads (exit flow, 6x8 planes); cfg 0: 12x16 tile x 8 quads;
 // cfg 2 (forward only): 24x16 tile x 8 quads for the large planes (halo read overhead 1.22 instead of 1.31)
+// cfg 3: 6x16 tile x 8 quads for planes so small that 12-row tiles give the chip less than ~4 workgroups per CU (the
+// middle flow's 12x16 planes: 736 workgroups that all load, then all compute, then all store -- half-height tiles
+// double the workgroups, shorten each one's serial load/compute/store chain and let the phases of different
+// workgroups overlap)
+static int dw_small_tiles() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("SPNET_DW_SMALL");
+    v = (e && e[0] == '0') ? 0 : 1;
+  }
+  return v;
+}
 static DwGeom dw_geom(int B, int H, int W, int C, bool fwd) {
   DwGeom g;
   g.cfg = (H <= 6 && W <= 8) ? 1 : 0;   // (a 24x16 forward tile was tried: 60 KB of LDS halves residency and loses)
-  g.th = g.cfg == 1 ? 6 : (g.cfg == 2 ? 24 : 12);
+  if (g.cfg == 0 && dw_small_tiles()) {
+    const long nblk12 = (long)B * ((H + 11) / 12) * ((W + 15) / 16) * ((C / 4 + 7) / 8);
+    if (nblk12 < 4 * 256 && H > 6) g.cfg = 3;
+  }
+  g.th = (g.cfg == 1 || g.cfg == 3) ? 6 : (g.cfg == 2 ? 24 : 12);
   g.tw = g.cfg == 1 ? 8 : 16;
   g.cc4 = g.cfg == 1 ? 16 : 8;
   g.tiles_h = (H + g.th - 1) / g.th;
@@ -611,6 +628,7 @@ extern "C" int spnet_dwconv3x3_tiled_fwd(const float* x, const float* w, float* 
                      in_shift)
   if (g.cfg == 1) DW_FWD(16, 8, 6);
   else if (g.cfg == 2) DW_FWD(8, 16, 24);
+  else if (g.cfg == 3) DW_FWD(8, 16, 6);
   else DW_FWD(8, 16, 12);
 #undef DW_FWD
   SPNET_RETURN_LAUNCH_STATUS();
@@ -645,6 +663,10 @@ extern "C" int spnet_dwconv3x3_tiled_bwd(const float* dy, const float* x_fwd, co
   const DwGeom g = dw_geom(B, H, W, C, false);
   if (g.cfg == 1)
     hipLaunchKernelGGL((dw3x3_tile_bwd_kernel<16, 8, 6>), dim3((unsigned)g.nblk), dim3(256), g.lds_bwd,
+                       (hipStream_t)stream, dy, x_fwd, w, dx, workspace, add, H, W, C, relu_in, g.tiles_h,
+                       g.tiles_w, g.cchunks, in_scale, in_shift, bn_mean, bn_invstd, bn_partial, bn_x);
+  else if (g.cfg == 3)
+    hipLaunchKernelGGL((dw3x3_tile_bwd_kernel<8, 16, 6>), dim3((unsigned)g.nblk), dim3(256), g.lds_bwd,
                        (hipStream_t)stream, dy, x_fwd, w, dx, workspace, add, H, W, C, relu_in, g.tiles_h,
                        g.tiles_w, g.cchunks, in_scale, in_shift, bn_mean, bn_invstd, bn_partial, bn_x);
   else

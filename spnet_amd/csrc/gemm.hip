@@ -22,23 +22,36 @@
 // (v_mfma_f32_16x16x4_f32: D col = l&15, row = 4*(l>>4)+reg).  Tile t+1 travels global -> registers while
 // tile t is multiplied, and is written to the idle LDS buffer in the MIDDLE of the MFMA stream (nobody
 // reads that buffer during this iteration), so one barrier per K tile suffices.
-template <int BM, int BN, int BK, int WM, int WN, int AMAJ, int BMAJ>
-__global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const float* __restrict__ A_, int lda,
+// AX = 1: the A operand is the blend a[k]*A_ + b[k]*X2_ + c[k] of two tensors (TileStage XF): the BatchNorm-backward
+// output dy built on the fly from the incoming gradient g (= A_) and the saved pre-normalisation tensor yp (= X2_),
+// coef = [a|b|c] with cld floats each.  dy_out (or NULL): the blended operand is also written to memory once (the
+// weight-gradient GEMM of the same layer reads it): K tile t of a row tile is written by the workgroup of column
+// tile t % tiles_n, so the extra stores are spread evenly over the workgroups that stage that row tile.
+// (blended kernels of the small tiles are held to 3 workgroups per CU like their plain counterparts: the middle
+// flow's 768-workgroup launches are exactly one resident wave of 3 per CU)
+template <int BM, int BN, int BK, int WM, int WN, int AMAJ, int BMAJ, int AX = 0>
+__global__ __launch_bounds__(256, (AX && BM * BN <= 96 * 64) ? 3 : 2) void gemm_f32_kernel(const float* __restrict__ A_, int lda,
                                                        const float* __restrict__ B_, int ldb,
                                                        float* __restrict__ C_, int ldc, int M, int N,
                                                        int K, int k_chunk, long slab_stride,
                                                        int tiles_m, int tiles_n, int nsplit,
                                                        const float* __restrict__ bias,
                                                        float* __restrict__ colstats,
-                                                       const long long* __restrict__ batch) {
+                                                       const long long* __restrict__ batch,
+                                                       const float* __restrict__ X2,
+                                                       const float* __restrict__ coef, int cld,
+                                                       float* __restrict__ dy_out) {
   static_assert(WM * WN == 4, "4 waves per workgroup");
+  static_assert(!AX || AMAJ == SP_K_MAJOR, "blended A operands are K-major");
   constexpr int TM = BM / WM / 16, TN = BN / WN / 16;
   static_assert(TM >= 1 && TN >= 1 && (BM % (WM * 16)) == 0 && (BN % (WN * 16)) == 0, "wave tile");
-  typedef TileStage<BM, BK, AMAJ, TM> SA;
+  typedef TileStage<BM, BK, AMAJ, TM, 0, AX> SA;
   typedef TileStage<BN, BK, BMAJ, TN, (BMAJ == SP_K_MAJOR)> SB;
   constexpr int STAGE = SA::SIZE + SB::SIZE;
   constexpr int NCH = BK / 16;
-  __shared__ __attribute__((aligned(16))) float smem[2 * STAGE];
+  // (+ a two-slot ring of blend coefficients: [a | b | c] x BK floats per K tile)
+  constexpr int CFS = 3 * BK;
+  __shared__ __attribute__((aligned(16))) float smem[2 * STAGE + (AX ? 2 * CFS : 0)];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -86,12 +99,51 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const float* __restric
 #pragma unroll
   for (int i = 0; i < SB::NV; ++i) sb[1].off[i] = sb[0].off[i];
 
+  // Blended A operand: tile t+1 waits in its register stage as TWO raw tensors (v = g, w = yp); it is blended -- and,
+  // by the column tile whose turn it is, written out as dy -- at the START of step t, before tile t+2's fetch
+  // reuses the one shared w set.  The blend coefficients of a K tile (3 x BK floats) travel like the tile itself:
+  // fetched by 3*BK/4 threads two tiles ahead, parked in a two-slot LDS ring in the middle of the step, read back
+  // (three broadcast ds_read_b128 per thread) one barrier later -- a global load right in front of the blend
+  // would put an L2 round trip on every wave's critical path once per K tile.
+  float4 wsh[AX ? SA::NV : 1];
+  float4 cfreg = make_float4(0.f, 0.f, 0.f, 0.f);
+  constexpr int CFT = 3 * BK / 4;                      // coefficient float4 per K tile
+  float* cfs = smem + 2 * STAGE;
+  auto cf_fetch = [&](int k0) {                        // this thread's share of tile k0's coefficients
+    if constexpr (AX)
+      if (tid < CFT) cfreg = *reinterpret_cast<const float4*>(coef + (tid / (BK / 4)) * cld + k0 + (tid % (BK / 4)) * 4);
+  };
+  auto cf_park = [&](int slot) {
+    if constexpr (AX)
+      if (tid < CFT) *reinterpret_cast<float4*>(cfs + slot * CFS + tid * 4) = cfreg;
+  };
+  auto fetch = [&](auto& stA, auto& stB, int k0, auto& wreg) {      // any tile: predicated
+    if constexpr (AX) stA.load2(A, X2, lda, m0, M, k0, kend, tid, wreg);
+    else stA.load(A, lda, m0, M, k0, kend, tid);
+    stB.load(B, ldb, n0, N, k0, kend, tid);
+  };
+  auto blend = [&](auto& stA, int k0, auto& wreg, const float4 a, const float4 b, const float4 c) {
+    if constexpr (AX) {
+      stA.xform(a, b, c, wreg);
+      if (dy_out && ((k0 - kbeg) / BK) % tiles_n == tn) stA.store_global(dy_out, lda, m0, M, k0, kend, tid);
+    }
+  };
   if (nt > 0) {
-    sa[0].load(A, lda, m0, M, kbeg, kend, tid);
-    sb[0].load(B, ldb, n0, N, kbeg, kend, tid);
-    if (nt > 1) {
-      sa[1].load(A, lda, m0, M, kbeg + BK, kend, tid);
-      sb[1].load(B, ldb, n0, N, kbeg + BK, kend, tid);
+    if constexpr (AX) {
+      float4 w0[SA::NV];
+      const int kq4 = (tid % (BK / 4)) * 4;
+      fetch(sa[0], sb[0], kbeg, w0);
+      if (nt > 1) {
+        fetch(sa[1], sb[1], kbeg + BK, wsh);
+        cf_fetch(kbeg + BK);
+      }
+      blend(sa[0], kbeg, w0, *reinterpret_cast<const float4*>(coef + kbeg + kq4),
+            *reinterpret_cast<const float4*>(coef + cld + kbeg + kq4),
+            *reinterpret_cast<const float4*>(coef + 2 * cld + kbeg + kq4));
+      if (nt > 1) cf_park(1);
+    } else {
+      fetch(sa[0], sb[0], kbeg, wsh);
+      if (nt > 1) fetch(sa[1], sb[1], kbeg + BK, wsh);
     }
     sa[0].store(smem, tid);
     sb[0].store(smem + SA::SIZE, tid);
@@ -101,28 +153,40 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const float* __restric
   // PAR = t & 1: tile t sits in LDS buffer PAR, tile t+1 in register stage 1-PAR, stage PAR is free.
   // FULL: tile t+2 exists and lies completely below kend -> its fetch is branch-free, the whole step is one
   // basic block and the compiler interleaves loads, LDS writes and MFMAs.
-  const float* Ak = A + (AMAJ == SP_K_MAJOR ? (long)kbeg : (long)kbeg * lda) + 2 * SA::kstep(lda);
-  const float* Bk = B + (BMAJ == SP_K_MAJOR ? (long)kbeg : (long)kbeg * ldb) + 2 * SB::kstep(ldb);
+  const long aoff = (AMAJ == SP_K_MAJOR ? (long)kbeg : (long)kbeg * lda) + 2 * SA::kstep(lda);
+  const long boff = (BMAJ == SP_K_MAJOR ? (long)kbeg : (long)kbeg * ldb) + 2 * SB::kstep(ldb);
+  const float* Ak = A + aoff;
+  const float* Bk = B + boff;
+  const float* Xk = AX ? X2 + aoff : nullptr;      // second tensor of the blended operand
   auto step = [&](auto par, auto full, int t) {
     constexpr int PAR = decltype(par)::value;
     constexpr bool FULL = decltype(full)::value;
     const float* cur = smem + PAR * STAGE;
     float* nxt = smem + (1 - PAR) * STAGE;
     const bool more = FULL || (t + 1 < nt);
+    if constexpr (AX) {
+      if (more) {
+        const float4* cs = reinterpret_cast<const float4*>(cfs + (1 - PAR) * CFS) + tid % (BK / 4);
+        blend(sa[1 - PAR], kbeg + (t + 1) * BK, wsh, cs[0], cs[BK / 4], cs[2 * (BK / 4)]);
+      }
+      if (FULL || t + 2 < nt) cf_fetch(kbeg + (t + 2) * BK);
+    }
     if (FULL) {
-      sa[PAR].load_full(Ak);
+      if constexpr (AX) sa[PAR].load_full2(Ak, Xk, wsh);
+      else sa[PAR].load_full(Ak);
       sb[PAR].load_full(Bk);
       Ak += SA::kstep(lda);
       Bk += SB::kstep(ldb);
+      if constexpr (AX) Xk += SA::kstep(lda);
     } else if (t + 2 < nt) {
-      sa[PAR].load(A, lda, m0, M, kbeg + (t + 2) * BK, kend, tid);
-      sb[PAR].load(B, ldb, n0, N, kbeg + (t + 2) * BK, kend, tid);
+      fetch(sa[PAR], sb[PAR], kbeg + (t + 2) * BK, wsh);
     }
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
       if (c == NCH / 2 && more) {
         sa[1 - PAR].store(nxt, tid);
         sb[1 - PAR].store(nxt + SA::SIZE, tid);
+        if (FULL || t + 2 < nt) cf_park(PAR);          // coefficients of tile t+2 (slot parity of t+2 = PAR)
       }
       float a[TM][4], b[TN][4];
       SA::frags(cur, wm * (TM * 16), lane, c, a);
@@ -216,22 +280,25 @@ extern "C" int spnet_reduce_slabs(const float* ws, int nslab, int M, int N, floa
 #define SP_BK 32
 #endif
 
+// xf: 0 = plain operands, 1 = blended A (forward form only)
 template <int BM, int BN, int WM, int WN>
 static int launch_tile(const float* A, int amaj, int lda, const float* B, int bmaj, int ldb, float* C,
                        int ldc, int M, int N, int K, int nsplit, int k_chunk, long slab_stride,
-                       const float* bias, float* colstats, const long long* batch, hipStream_t st) {
+                       const float* bias, float* colstats, const long long* batch, hipStream_t st,
+                       int xf = 0, const float* X2 = nullptr, const float* coef = nullptr, int cld = 0,
+                       float* dy_out = nullptr) {
   const int tm = spnet_cdiv(M, BM), tn = spnet_cdiv(N, BN);
   dim3 grid(tm * tn * nsplit), block(256);
-#define SP_ARGS A, lda, B, ldb, C, ldc, M, N, K, k_chunk, slab_stride, tm, tn, nsplit, bias, colstats, batch
-#define SP_LAUNCH(KERNEL, BKV, AM, BMJ) \
-  hipLaunchKernelGGL((KERNEL<BM, BN, BKV, WM, WN, AM, BMJ>), grid, block, 0, st, SP_ARGS)
-#define SP_FORMS(KERNEL, BKV)                                                                             \
-  if (amaj == SP_K_MAJOR && bmaj == SP_OUT_MAJOR) SP_LAUNCH(KERNEL, BKV, SP_K_MAJOR, SP_OUT_MAJOR);       \
-  else if (amaj == SP_K_MAJOR && bmaj == SP_K_MAJOR) SP_LAUNCH(KERNEL, BKV, SP_K_MAJOR, SP_K_MAJOR);      \
-  else if (amaj == SP_OUT_MAJOR && bmaj == SP_OUT_MAJOR) SP_LAUNCH(KERNEL, BKV, SP_OUT_MAJOR, SP_OUT_MAJOR); \
-  else return (int)hipErrorInvalidValue
-  SP_FORMS(gemm_f32_kernel, SP_BK);
-#undef SP_FORMS
+#define SP_ARGS A, lda, B, ldb, C, ldc, M, N, K, k_chunk, slab_stride, tm, tn, nsplit, bias, colstats, batch, X2, coef, cld, dy_out
+#define SP_LAUNCH(BKV, AM, BMJ, AXV) \
+  hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, BKV, WM, WN, AM, BMJ, AXV>), grid, block, 0, st, SP_ARGS)
+  if (xf == 1) {
+    if (amaj == SP_K_MAJOR && bmaj == SP_OUT_MAJOR) SP_LAUNCH(SP_BK, SP_K_MAJOR, SP_OUT_MAJOR, 1);
+    else return (int)hipErrorInvalidValue;
+  } else if (amaj == SP_K_MAJOR && bmaj == SP_OUT_MAJOR) SP_LAUNCH(SP_BK, SP_K_MAJOR, SP_OUT_MAJOR, 0);
+  else if (amaj == SP_K_MAJOR && bmaj == SP_K_MAJOR) SP_LAUNCH(SP_BK, SP_K_MAJOR, SP_K_MAJOR, 0);
+  else if (amaj == SP_OUT_MAJOR && bmaj == SP_OUT_MAJOR) SP_LAUNCH(SP_BK, SP_OUT_MAJOR, SP_OUT_MAJOR, 0);
+  else return (int)hipErrorInvalidValue;
 #undef SP_LAUNCH
 #undef SP_ARGS
   return 0;
@@ -295,7 +362,8 @@ static int pick_tile(int form, int M, int N, int K, int split_k, bool have_ws, l
 static int gemm_impl(const float* A, int a_major, int lda, const float* B, int b_major, int ldb, float* C,
                      int ldc, int M, int N, int K, int split_k, float* workspace, long ws_floats,
                      const float* bias, int tile, float* colstats, int* stat_rows, void* stream,
-                     const long long* batch = nullptr, int nbatch = 0) {
+                     const long long* batch = nullptr, int nbatch = 0, int xf = 0, const float* X2 = nullptr,
+                     const float* coef = nullptr, int cld = 0, float* dy_out = nullptr) {
   hipStream_t st = (hipStream_t)stream;
   if (batch) {                       // nbatch whole problems side by side: no K split, no workspace
     if (nbatch < 1 || bias || colstats) return (int)hipErrorInvalidValue;
@@ -309,9 +377,17 @@ static int gemm_impl(const float* A, int a_major, int lda, const float* B, int b
   if ((a_major == SP_K_MAJOR || b_major == SP_K_MAJOR) && (K & 3)) return (int)hipErrorInvalidValue;
   if (a_major == SP_OUT_MAJOR && (M & 3)) return (int)hipErrorInvalidValue;
   if (((uintptr_t)A | (uintptr_t)B | (uintptr_t)C) & 15) return (int)hipErrorInvalidValue;
+  if (xf) {   // blended A operand: second tensor + [a|b|c] coefficients, zero-padded to whole K tiles; no K split
+    if (xf != 1 || batch || !X2 || !coef || (((uintptr_t)X2 | (uintptr_t)coef | (uintptr_t)dy_out) & 15) || (cld & 3))
+      return (int)hipErrorInvalidValue;
+    if (cld < spnet_cdiv(K, SP_BK) * SP_BK) return (int)hipErrorInvalidValue;
+    split_k = 1;
+  }
+  const bool auto_tile = (tile <= 0 || tile > SP_NTILES);
   const int form = (a_major == SP_OUT_MAJOR) ? 2 : (b_major == SP_K_MAJOR ? 1 : 0);
   if (tile <= 0 || tile > SP_NTILES)
     tile = pick_tile(form, M, N, K, split_k, workspace != nullptr, ws_floats, batch ? nbatch : 1);
+  if (xf && auto_tile && tile == 1) tile = 8;     // the blended 128x128 kernel does not fit the register file
   int bm, bn;
   tile_dims(tile, &bm, &bn);
   const long tiles = (long)spnet_cdiv(M, bm) * spnet_cdiv(N, bn);
@@ -337,14 +413,14 @@ static int gemm_impl(const float* A, int a_major, int lda, const float* B, int b
   if (batch) nsplit = nbatch;        // the kernel's slice index selects the problem
   int rc;
   switch (tile) {
-    case 1: rc = launch_tile<128, 128, 2, 2>(A, a_major, lda, B, b_major, ldb, out, out_ld, M, N, K, nsplit, k_chunk, slab, kbias, colstats, batch, st); break;
-    case 2: rc = launch_tile<128, 64, 2, 2>(A, a_major, lda, B, b_major, ldb, out, out_ld, M, N, K, nsplit, k_chunk, slab, kbias, colstats, batch, st); break;
-    case 3: rc = launch_tile<64, 64, 2, 2>(A, a_major, lda, B, b_major, ldb, out, out_ld, M, N, K, nsplit, k_chunk, slab, kbias, colstats, batch, st); break;
-    case 5: rc = launch_tile<96, 96, 2, 2>(A, a_major, lda, B, b_major, ldb, out, out_ld, M, N, K, nsplit, k_chunk, slab, kbias, colstats, batch, st); break;
-    case 6: rc = launch_tile<96, 64, 2, 2>(A, a_major, lda, B, b_major, ldb, out, out_ld, M, N, K, nsplit, k_chunk, slab, kbias, colstats, batch, st); break;
-    case 7: rc = launch_tile<64, 128, 2, 2>(A, a_major, lda, B, b_major, ldb, out, out_ld, M, N, K, nsplit, k_chunk, slab, kbias, colstats, batch, st); break;
-    case 8: rc = launch_tile<128, 96, 2, 2>(A, a_major, lda, B, b_major, ldb, out, out_ld, M, N, K, nsplit, k_chunk, slab, kbias, colstats, batch, st); break;
-    default: rc = launch_tile<32, 128, 1, 4>(A, a_major, lda, B, b_major, ldb, out, out_ld, M, N, K, nsplit, k_chunk, slab, kbias, colstats, batch, st); break;
+    case 1: rc = launch_tile<128, 128, 2, 2>(A, a_major, lda, B, b_major, ldb, out, out_ld, M, N, K, nsplit, k_chunk, slab, kbias, colstats, batch, st, xf, X2, coef, cld, dy_out); break;
+    case 2: rc = launch_tile<128, 64, 2, 2>(A, a_major, lda, B, b_major, ldb, out, out_ld, M, N, K, nsplit, k_chunk, slab, kbias, colstats, batch, st, xf, X2, coef, cld, dy_out); break;
+    case 3: rc = launch_tile<64, 64, 2, 2>(A, a_major, lda, B, b_major, ldb, out, out_ld, M, N, K, nsplit, k_chunk, slab, kbias, colstats, batch, st, xf, X2, coef, cld, dy_out); break;
+    case 5: rc = launch_tile<96, 96, 2, 2>(A, a_major, lda, B, b_major, ldb, out, out_ld, M, N, K, nsplit, k_chunk, slab, kbias, colstats, batch, st, xf, X2, coef, cld, dy_out); break;
+    case 6: rc = launch_tile<96, 64, 2, 2>(A, a_major, lda, B, b_major, ldb, out, out_ld, M, N, K, nsplit, k_chunk, slab, kbias, colstats, batch, st, xf, X2, coef, cld, dy_out); break;
+    case 7: rc = launch_tile<64, 128, 2, 2>(A, a_major, lda, B, b_major, ldb, out, out_ld, M, N, K, nsplit, k_chunk, slab, kbias, colstats, batch, st, xf, X2, coef, cld, dy_out); break;
+    case 8: rc = launch_tile<128, 96, 2, 2>(A, a_major, lda, B, b_major, ldb, out, out_ld, M, N, K, nsplit, k_chunk, slab, kbias, colstats, batch, st, xf, X2, coef, cld, dy_out); break;
+    default: rc = launch_tile<32, 128, 1, 4>(A, a_major, lda, B, b_major, ldb, out, out_ld, M, N, K, nsplit, k_chunk, slab, kbias, colstats, batch, st, xf, X2, coef, cld, dy_out); break;
   }
   if (rc) return rc;
   if (nsplit > 1 && !batch) {
@@ -372,6 +448,17 @@ extern "C" int spnet_gemm_f32_batched(const float* A0, const float* B0, float* C
   if (!offsets || !A0 || !B0 || !C0) return (int)hipErrorInvalidValue;
   return gemm_impl(A0, a_major, lda, B0, b_major, ldb, C0, ldc, M, N, K, 1, nullptr, 0, nullptr, tile, nullptr, nullptr,
                    stream, offsets, nbatch);
+}
+
+// dX[M,N] = dY[M,K] B[K,N] where dY is the BatchNorm-backward output dy = a[k]*g + b[k]*yp + c[k], blended from the
+// incoming gradient g and the saved pre-normalisation tensor yp while the A tile is staged (forward operand form:
+// B = W^T kept by the engine).  coef = [a | b | c], cld floats each (zero beyond channel K-1, cld a multiple of 32
+// covering K).  dy_out (or NULL) receives dy itself, once, for the weight-gradient GEMM of the layer.
+extern "C" int spnet_gemm_f32_bnblend(const float* g, const float* yp, const float* coef, int cld, int lda,
+                                      const float* B, int ldb, float* C, int ldc, int M, int N, int K, int tile,
+                                      float* dy_out, void* stream) {
+  return gemm_impl(g, SP_K_MAJOR, lda, B, SP_OUT_MAJOR, ldb, C, ldc, M, N, K, 1, nullptr, 0, nullptr, tile, nullptr,
+                   nullptr, stream, nullptr, 0, 1, yp, coef, cld, dy_out);
 }
 
 // Forward-form GEMM that also emits BatchNorm column statistics of C: colstats[rows][2][N] holds per
@@ -480,6 +567,38 @@ __global__ __launch_bounds__(256) void scatter_add_s2_kernel(const float* __rest
     v.x += g.x; v.y += g.y; v.z += g.z; v.w += g.w;
     *d = v;
   }
+}
+
+// Transposes of many small matrices in one launch: job j writes dst_j[c][r] = src_j[r][c] for an R_j x C_j
+// row-major matrix.  jobs (device memory) = njobs x {src pointer, dst pointer, R, C} as four 64-bit words.
+// 32x32 tiles through a padded LDS tile: both the global read and the global write are 128-byte row segments.
+__global__ __launch_bounds__(256) void transpose_batched_kernel(const long long* __restrict__ jobs) {
+  __shared__ float t[32][33];
+  const long long* jb = jobs + 4 * blockIdx.z;
+  const float* __restrict__ src = reinterpret_cast<const float*>(jb[0]);
+  float* __restrict__ dst = reinterpret_cast<float*>(jb[1]);
+  const int R = (int)jb[2], C = (int)jb[3];
+  const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
+  if (r0 >= R || c0 >= C) return;                    // whole workgroup leaves together
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int r = r0 + ty + 8 * i, c = c0 + tx;
+    t[ty + 8 * i][tx] = (r < R && c < C) ? src[(long)r * C + c] : 0.f;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int c = c0 + ty + 8 * i, r = r0 + tx;
+    if (c < C && r < R) dst[(long)c * R + r] = t[tx][ty + 8 * i];
+  }
+}
+
+extern "C" int spnet_transpose_batched(const void* jobs, int njobs, int max_rows, int max_cols, void* stream) {
+  if (!jobs || njobs < 1 || max_rows < 1 || max_cols < 1) return (int)hipErrorInvalidValue;
+  hipLaunchKernelGGL(transpose_batched_kernel, dim3((max_cols + 31) / 32, (max_rows + 31) / 32, njobs), dim3(256), 0,
+                     (hipStream_t)stream, reinterpret_cast<const long long*>(jobs));
+  SPNET_RETURN_LAUNCH_STATUS();
 }
 
 extern "C" int spnet_im2col3x3(const float* x, float* col, int B, int H, int W, int C, void* stream) {

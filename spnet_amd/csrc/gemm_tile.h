@@ -28,7 +28,13 @@ enum { SP_K_MAJOR = 0, SP_OUT_MAJOR = 1 };
 //               position p of MFMA tile t stands for output index T*p + t: a lane then holds T CONSECUTIVE
 //               output columns (dgrad, where B = W^T is K-major) and the epilogue stores them as one vector.
 //               The fetch pattern (and its bank behaviour) is unchanged; only the staging store permutes.
-template <int BR, int BK, int MAJ, int T, int PERM = 0>
+//   XF = 1:   the operand is not a tensor in memory but a per-channel affine blend of TWO tensors of one layout,
+//               op = a[ch]*P + b[ch]*Q + c[ch]  (ch = the operand's channel index: k for a K-major A, the column for an
+//               out-major B).  Both tensors are fetched with the same offsets and blended in registers just before the
+//               staging store, so the blended tensor is never written to memory: this is how the BatchNorm backward
+//               dy = k1*g + k2*xhat(yp) + k3 reaches the data-gradient and weight-gradient GEMMs (coef = [a|b|c], each
+//               cld floats, zero beyond the last channel).
+template <int BR, int BK, int MAJ, int T, int PERM = 0, int XF = 0>
 struct TileStage {
   static constexpr int TOTAL = BR * BK / 4;            // float4 per tile
   static constexpr int NV = (TOTAL + 255) / 256;       // float4 per thread
@@ -62,6 +68,42 @@ struct TileStage {
     static_assert(TOTAL % 256 == 0, "whole float4 slots per thread");
 #pragma unroll
     for (int i = 0; i < NV; ++i) v[i] = *reinterpret_cast<const float4*>(Pk + off[i]);
+  }
+  // (the second tensor of a blended operand lives in a caller-owned register set w: ONE set serves both register
+  // stages, because a stage is blended -- and its w values die -- before the next fetch is issued)
+  __device__ __forceinline__ void load_full2(const float* __restrict__ Pk, const float* __restrict__ Qk,
+                                             float4 (&w)[NV]) {
+    static_assert(TOTAL % 256 == 0, "whole float4 slots per thread");
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      v[i] = *reinterpret_cast<const float4*>(Pk + off[i]);
+      w[i] = *reinterpret_cast<const float4*>(Qk + off[i]);
+    }
+  }
+  // v <- a*v + b*w + c with the per-channel coefficients of this thread's slots (K-major operands: every slot of a
+  // thread covers the same four reduction steps kq*4..kq*4+3 of the tile, so ONE coefficient triple serves them all).
+  __device__ __forceinline__ void xform(const float4 a, const float4 b, const float4 c, const float4 (&w)[NV]) {
+    static_assert(MAJ == SP_K_MAJOR && 256 % (BK / 4) == 0, "K-major operands only");
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      v[i].x = fmaf(a.x, v[i].x, fmaf(b.x, w[i].x, c.x));
+      v[i].y = fmaf(a.y, v[i].y, fmaf(b.y, w[i].y, c.y));
+      v[i].z = fmaf(a.z, v[i].z, fmaf(b.z, w[i].z, c.z));
+      v[i].w = fmaf(a.w, v[i].w, fmaf(b.w, w[i].w, c.w));
+    }
+  }
+  // The (blended) tile as it stands in v[] -> out[row*ld + k] (K-major operands): only real rows / reduction steps.
+  __device__ __forceinline__ void store_global(float* __restrict__ out, int ld, int r0, int R, int k0, int kend,
+                                               int tid) const {
+    static_assert(MAJ == SP_K_MAJOR, "K-major operands only");
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int f = tid + i * 256;
+      const int r = f / (BK / 4), kq = f % (BK / 4);
+      // off[i] already is (row clamped into range)*ld + kq*4: a clamped (duplicate) row is simply not written
+      if (((TOTAL % 256 == 0) || f < TOTAL) && r0 + r < R && k0 + kq * 4 < kend)
+        *reinterpret_cast<float4*>(out + off[i] + k0) = v[i];
+    }
   }
   // Gathered tile: slot i comes from base[offs[i] + shift], or is zero (and reads base[0]) when bit i of
   // `okmask` is clear.  (Kept as member functions with #pragma unroll: stage slots indexed from a loop that is
@@ -97,6 +139,34 @@ struct TileStage {
         }
       }
       v[i] = val;
+    }
+  }
+
+  // Any K tile of a blended operand (both tensors, same predicates).
+  __device__ __forceinline__ void load2(const float* __restrict__ P, const float* __restrict__ Q, int ld, int r0,
+                                        int R, int k0, int kend, int tid, float4 (&w)[NV]) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int f = tid + i * 256;
+      float4 val = make_float4(0.f, 0.f, 0.f, 0.f), val2 = val;
+      if ((TOTAL % 256 == 0) || f < TOTAL) {
+        long o = -1;
+        if (MAJ == SP_OUT_MAJOR) {
+          const int k = f / (BR / 4), r4 = f % (BR / 4);
+          const int gk = k0 + k, gr = r0 + r4 * 4;
+          if (gk < kend && gr < R) o = (long)gk * ld + gr;
+        } else {
+          const int r = f / (BK / 4), kq = f % (BK / 4);
+          const int gr = r0 + r, gk = k0 + kq * 4;
+          if (gr < R && gk < kend) o = (long)gr * ld + gk;
+        }
+        if (o >= 0) {
+          val = *reinterpret_cast<const float4*>(P + o);
+          val2 = *reinterpret_cast<const float4*>(Q + o);
+        }
+      }
+      v[i] = val;
+      w[i] = val2;
     }
   }
 

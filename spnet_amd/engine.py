@@ -149,7 +149,8 @@ def _glorot_fans(name, shape):
 
 class Engine:
     def __init__(self, H, W, batch, n_out=576, device="cuda:0", loss_type="same", seed=0,
-                 train=True, adam_eps=1e-7, share_from=None):
+                 train=True, adam_eps=1e-7, share_from=None, rank=0):
+        """rank: data-parallel rank, mixed into the initial dropout seed so that replicas draw different masks."""
         if not torch.cuda.is_available():
             raise RuntimeError("spnet_amd.Engine needs a HIP device (no CPU fallback)")
         self.H, self.W, self.B, self.n_out = int(H), int(W), int(batch), int(n_out)
@@ -157,7 +158,10 @@ class Engine:
         self.loss_type = loss_type
         self.train_capable = bool(train)
         self.adam_eps = adam_eps
-        self.t = 0                      # optimizer iterations done
+        # Optimizer iteration count and dropout seed live beside theta/m/v: every plan over one weight set
+        # (other batch sizes, the inference plans) advances the SAME counters, so a second fit() with another
+        # batch size continues Adam's bias correction and the dropout seed sequence instead of restarting them.
+        self._opt = share_from._opt if share_from is not None else {"t": 0, "drop_seed": 12345 + 7919 * int(rank)}
         self.prof = None                # KernelTimer or None
         self.deferred_wgrads = []       # (x, dy, gw, cin, cout, M) of layers whose dW waits for the batched launch
         self.dw_reduce_jobs = []        # (partials, grad, rows, 9*C) of every depthwise layer
@@ -171,16 +175,22 @@ class Engine:
         # 13.4 ms for the eager launches (single stream: 13.5 either way) -- the host enqueues a step in
         # 4.3 ms and runs ahead of the GPU, so launch overhead is not what limits the step.
         self.use_graph = False
-        self.drop_seed = 12345
         torch.cuda.set_device(self.dev)
         # Inference coefficients (scale|shift from the moving statistics, one tiny kernel per BatchNorm) are
         # recomputed only when the weights or statistics changed since this plan last did: [version] is shared
         # by all plans over one weight set and bumped by every training forward / optimizer step / load.
         self._wver = share_from._wver if share_from is not None else [0]
+        # W^T of every pointwise kernel (name -> tensor), shared by all plans; [_tver] counts changes of theta,
+        # [_wT_ver] is the value of _tver the transposes were last refreshed at.
+        self._wT = share_from._wT if share_from is not None else {}
+        self._tver = share_from._tver if share_from is not None else [0]
+        self._wT_ver = share_from._wT_ver if share_from is not None else [-1]
+        self._wT_jobs = None
+        self._igraph = None             # captured inference forward (predict_step)
         self._coeff_ver = -1
         self._infer_fresh = True
         if share_from is not None:      # second plan (other batch size / inference) over the SAME weights
-            for a in ("p_off", "s_off", "l2_n", "n_theta", "theta", "stats", "spec_order"):
+            for a in ("p_off", "s_off", "l2_n", "rest_lo", "n_theta", "theta", "stats", "spec_order"):
                 setattr(self, a, getattr(share_from, a))
             if self.train_capable:
                 for a in ("grad", "m", "v"):
@@ -190,10 +200,35 @@ class Engine:
         self.update_mask = None         # optional flat 0/1 tensor: frozen parameters are skipped by Adam
         self._build_graph()
 
+    @property
+    def t(self):
+        """optimizer iterations done (shared by all plans over this weight set)"""
+        return self._opt["t"]
+
+    @t.setter
+    def t(self, v):
+        self._opt["t"] = int(v)
+
+    @property
+    def drop_seed(self):
+        return self._opt["drop_seed"]
+
+    @drop_seed.setter
+    def drop_seed(self, v):
+        self._opt["drop_seed"] = int(v) & 0xFFFFFFFF
+
     # ------------------------------------------------------------------ parameters
     def _build_params(self, seed):
         specs = param_specs(self.H, self.W, self.n_out)
-        order = [s for s in specs if s[2] and s[3]] + [s for s in specs if s[2] and not s[3]]
+        # Flat layout: [l2-regularised kernels, the Dense head's first] [all depthwise kernels] [everything else in
+        # forward order].  The l2 set is a prefix (weight decay inside the fused optimizer); the head kernel (73 % of
+        # the bytes, produced first in backward) is one contiguous range at offset 0; the depthwise gradients, which
+        # one batched reduction finishes at the very END of backward, sit together in front of the forward-ordered
+        # rest, so that suffixes of the buffer are complete -- and can be all-reduced -- as backward walks up the net.
+        tr = [s for s in specs if s[2]]
+        l2 = sorted((s for s in tr if s[3]), key=lambda s: s[0] != "FinalOutput/kernel")
+        dwk = [s for s in tr if not s[3] and s[0].endswith("depthwise_kernel")]
+        order = l2 + dwk + [s for s in tr if not s[3] and not s[0].endswith("depthwise_kernel")]
         off = 0
         self.p_off = OrderedDict()
         for name, shape, _, l2 in order:
@@ -202,6 +237,8 @@ class Engine:
             off += (n + ALIGN - 1) // ALIGN * ALIGN
             if l2:
                 self.l2_n = off          # prefix (incl. alignment padding, which stays zero)
+            if name.endswith("depthwise_kernel"):
+                self.rest_lo = off       # first offset behind the depthwise kernels
         self.n_theta = off
         s_off = 0
         self.s_off = OrderedDict()
@@ -221,6 +258,7 @@ class Engine:
     def init_weights(self, seed=0):
         """Keras defaults: glorot_uniform kernels, zeros bias/beta, ones gamma, moving stats 0/1."""
         self._wver[0] += 1
+        self._tver[0] += 1
         g = torch.Generator().manual_seed(seed)
         host = torch.zeros(self.n_theta, dtype=torch.float32)
         for name, (off, n, shape) in self.p_off.items():
@@ -267,6 +305,7 @@ class Engine:
 
     def load_state_dict(self, sd):
         self._wver[0] += 1
+        self._tver[0] += 1
         for name in self.spec_order:
             t = torch.as_tensor(np.asarray(sd[name]), dtype=torch.float32).reshape(-1)
             if name in self.p_off:
@@ -347,7 +386,7 @@ class Engine:
             self.sq_scratch = self.new(2048)
             # per-step scalars the kernels read from device memory: [lr_t (f32), dropout seed (u32)]
             self.step_params = torch.zeros(4, device=self.dev, dtype=torch.int32)
-            self._step_host = torch.zeros(4, dtype=torch.int32).pin_memory()
+            self._step_upload = L.AsyncUploader(self.dev, depth=8)
             self.lr_ptr = self.step_params.data_ptr()
             self.seed_ptr = self.step_params.data_ptr() + 4
             self._graph = None
@@ -371,11 +410,35 @@ class Engine:
             self._coeff_ver = self._wver[0]
         return self.out
 
+    def predict_step(self, use_graph=None):
+        """Inference forward of self.x_in -> self.out as ONE hipGraph replay (BASELINE configs[4]: predict_spnet.py's
+        model.predict loop).  The plan is static, so the ~110 launches of a forward are captured once per plan; the
+        BatchNorm inference coefficients are refreshed by an eager forward whenever the weights or moving statistics
+        changed since this plan last ran (the graph itself holds no weight-dependent host decisions).
+        SPNET_PREDICT_GRAPH=0 keeps the eager launches."""
+        if use_graph is None:
+            use_graph = os.environ.get("SPNET_PREDICT_GRAPH", "1") != "0"
+        if not use_graph or self.prof is not None:
+            return self.forward(None, training=False)
+        if self._coeff_ver != self._wver[0] or self._igraph is None:
+            out = self.forward(None, training=False)          # eager: also recomputes scale|shift of every BatchNorm
+            if self._igraph is None:
+                torch.cuda.synchronize()
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    self.forward(None, training=False)
+                self._igraph = g
+            return out
+        self._igraph.replay()
+        return self.out
+
     def backward(self, on_node_done=None):
         """Back-propagates self.dout (filled by loss()) into self.grad.  on_node_done(node) is called
         after each node's launches are enqueued (used to start the gradient all-reduce early)."""
         g = self.dout
         self.deferred_wgrads = []
+        if self._wT_ver[0] != self._tver[0]:    # weights were loaded / re-initialised since the last optimizer step
+            self.refresh_transposes()
         for node in reversed(self.nodes):
             g = node.bwd(g)
             if node is self._first_middle:      # (flushing in 2 or 4 smaller batches measured no faster)
@@ -386,6 +449,33 @@ class Engine:
         self.reduce_depthwise_wgrads()
         if self.wgrad_stream is not None:      # every weight gradient must have landed before the optimizer
             torch.cuda.current_stream().wait_stream(self.wgrad_stream)
+
+    def transposed(self, wname):
+        """W^T buffer ([cout][cin]) of a pointwise kernel; kept current by refresh_transposes()."""
+        if wname not in self._wT:
+            off, n, shape = self.p_off[wname]
+            self._wT[wname] = self.new(n)
+            self._wT_ver[0] = -1
+        return self._wT[wname]
+
+    def refresh_transposes(self):
+        """One batched launch: W^T of every pointwise kernel whose layer back-propagates a data gradient, so
+        that dX = dY W^T reads its B operand in the forward (output-major) form.  ~160 MB of traffic per step
+        against 36 data-gradient GEMMs that each run 10 % faster."""
+        if not self._wT:
+            self._wT_ver[0] = self._tver[0]
+            return
+        if self._wT_jobs is None or self._wT_jobs[1] != len(self._wT):
+            flat, mr, mc = [], 1, 1
+            for name, dst in self._wT.items():
+                off, n, shape = self.p_off[name]
+                R, C = int(shape[-2]), int(shape[-1])          # [cin][cout] (1x1 HWIO kernels: trailing two dims)
+                flat += [self.theta.data_ptr() + 4 * off, dst.data_ptr(), R, C]
+                mr, mc = max(mr, R), max(mc, C)
+            self._wT_jobs = (torch.tensor(flat, dtype=torch.int64, device=self.dev), len(self._wT), mr, mc)
+        table, nj, mr, mc = self._wT_jobs
+        L.spnet_transpose_batched(table.data_ptr(), nj, mr, mc, _stream())
+        self._wT_ver[0] = self._tver[0]
 
     def reduce_depthwise_wgrads(self):
         """Fold the partial sums every fused depthwise backward left behind into the 34 depthwise weight
@@ -460,16 +550,22 @@ class Engine:
         self.drop_seed = (self.drop_seed * 1664525 + 1013904223) & 0xFFFFFFFF
         b1, b2 = 0.9, 0.999
         lr_t = lr * math.sqrt(1.0 - b2 ** self.t) / (1.0 - b1 ** self.t)
-        h = self._step_host
-        h[0] = int(np.float32(lr_t).view(np.int32))
-        h[1] = int(np.uint32(self.drop_seed).view(np.int32))
-        self.step_params.copy_(h, non_blocking=True)
+        self._publish_step_params(lr_t)
+
+    def _publish_step_params(self, lr_t=None):
+        """[lr_t, dropout seed] -> device.  The host runs several steps ahead of the GPU, so the two words travel
+        through a ring of pinned staging slots (one slot per step in flight, reused only after its own DMA has
+        completed) and are copied into step_params IN STREAM ORDER: a step's kernels can never see the values of
+        a later step, which a single pinned buffer overwritten every step would allow."""
+        if lr_t is not None:
+            self._lr_bits = int(np.float32(lr_t).view(np.int32))
+        h = np.array([getattr(self, "_lr_bits", 0), int(np.uint32(self.drop_seed).view(np.int32)), 0, 0], np.int32)
+        self.step_params.copy_(self._step_upload("step", h), non_blocking=True)
 
     def set_drop_seed(self, seed):
         """Seed used by the next forward(training=True) called outside train_step (tests, smoke)."""
         self.drop_seed = int(seed) & 0xFFFFFFFF
-        self._step_host[1] = int(np.uint32(self.drop_seed).view(np.int32))
-        self.step_params[1:2].copy_(self._step_host[1:2])
+        self._publish_step_params()
 
     def adam_step(self, lr=None, grad_scale=1.0):
         """Fused Keras-Adam + l2 over the flat buffers.  lr=None: the step size already sits in device
@@ -481,6 +577,8 @@ class Engine:
         L.spnet_adam_step(L.ptr(self.theta), L.ptr(self.grad), L.ptr(self.m), L.ptr(self.v), self.n_theta,
                           self.l2_n, 0.0, b1, b2, self.adam_eps, L2_COEF, grad_scale, L.ptr(self.update_mask),
                           L.ptr(self.sq_scratch), self.loss_out[6:].data_ptr(), self.lr_ptr, _stream())
+        self._tver[0] += 1
+        self.refresh_transposes()
 
     def train_step(self, X, Y, lr, reducer=None):
         """augmented batch X -> forward -> custom_loss -> backward -> (all-reduce) -> Adam(+l2).
@@ -515,10 +613,56 @@ class Engine:
             self.backward()
             scale = 1.0 if scale is None else scale
         else:
-            head = self.nodes[-1]
-            self.backward(on_node_done=lambda n: reducer.launch_head() if n is head else None)
+            reducer.side_stream = self.wgrad_stream
+            self.backward(on_node_done=reducer.on_node_done)
             scale = reducer.finish()
         self.adam_step(None, scale)
+
+    def grad_buckets(self, bucket_bytes=32 << 20):
+        """Plan of the gradient all-reduce (~32 MB buckets in reverse layer order).
+
+        Returns (buckets, tail): buckets = [(lo, hi, trigger_node)] in launch order -- float ranges of the flat
+        gradient that are COMPLETE once `trigger_node` has been back-propagated -- and tail = [(lo, hi)], what is
+        only complete when backward ends.  The Dense-head kernel (produced first, 73 % of the bytes) goes first, cut
+        into bucket-sized pieces; then suffixes of the forward-ordered region, cut at node boundaries.  The
+        middle-flow pointwise gradients are produced by ONE deferred batched launch once block 5 is done
+        (flush_deferred_wgrads), so every bucket inside the middle flow is triggered by that block.  The tail holds
+        the small l2 kernels, all depthwise kernels (their batched reduction is the last launch of backward) and
+        whatever forward-ordered parameters precede the first bucket cut."""
+        per = max(int(bucket_bytes) // 4, ALIGN)
+        head = self.nodes[-1]
+        hlo, hhi = self.head_grad_range()
+        buckets = [(lo, min(lo + per, hhi), head) for lo in range(hlo, hhi, per)]
+        first = {}                                   # node -> lowest offset of its parameters in the rest region
+        for node in self.nodes:
+            offs = [off for name, (off, n, _) in self.p_off.items()
+                    if off >= self.rest_lo and name.split("/")[0] in getattr(node, "pnames", ())]
+            if offs:
+                first[node] = min(offs)
+        cur_hi = self.n_theta
+        owners = [n for n in self.nodes if n in first]
+        is_mid = lambda n: isinstance(n, MiddleBlock) and self.defer_mid_wgrad
+        for i in range(len(owners) - 1, -1, -1):
+            node = owners[i]
+            if first[node] >= cur_hi:
+                continue
+            # cut here when the bucket is full, and on both edges of the middle flow (what lies behind it is complete
+            # long before the deferred launch; what lies in front of it is not touched by it)
+            edge = i > 0 and is_mid(owners[i - 1]) != is_mid(node)
+            if (cur_hi - first[node]) >= per or edge:
+                buckets.append((first[node], cur_hi, self._first_middle if is_mid(node) else node))
+                cur_hi = first[node]
+        tail = [(hhi, cur_hi)] if cur_hi > hhi else []
+        if hlo > 0:
+            tail.insert(0, (0, hlo))
+        return buckets, tail
+
+    def make_reducer(self, group=None, force=False, bucket_bytes=32 << 20):
+        """parallel.GradReducer over this plan's gradient buckets (force=True: run the collectives even with one
+        rank, which exercises RCCL's stream hand-off on a single GPU)."""
+        from . import parallel
+        buckets, tail = self.grad_buckets(bucket_bytes)
+        return parallel.GradReducer(self.grad, buckets, tail=tail, group=group, force=force)
 
     def head_grad_range(self):
         """[lo,hi) of FinalOutput/kernel inside the flat gradient: produced first in backward and 73 %
@@ -575,6 +719,7 @@ class SmallConv(Node):
         self.OW = W if same else (W - 3) // stride + 1
         self.y = eng.new(B, self.OH, self.OW, cout)
         self.w = eng.P(name + "/kernel")
+        self.pnames = [name]
         self.need_dx = need_dx
         if eng.train_capable:
             self.gw = eng.G(name + "/kernel")
@@ -627,6 +772,7 @@ class BatchNorm(Node):
     def __init__(self, eng, x, C, name, act, residual=None, res_bcast=False, bwd_inplace=True):
         self.e, self.x, self.C, self.act = eng, x, C, act
         self.M = x.numel() // C
+        self.pnames = [name]
         self.gamma, self.beta = eng.P(name + "/gamma"), eng.P(name + "/beta")
         self.mm, self.mv = eng.S(name + "/moving_mean"), eng.S(name + "/moving_variance")
         self.residual, self.res_bcast = residual, res_bcast
@@ -683,6 +829,7 @@ class Pointwise:
         self.e, self.M, self.cin, self.cout = eng, M, cin, cout
         self.w = eng.P(wname)
         self.gw = eng.G(wname) if eng.train_capable else None
+        self.wT = eng.transposed(wname) if eng.train_capable else None     # [cout][cin], for the data gradient
         self.defer_wgrad = defer_wgrad      # dW is left to Engine.flush_deferred_wgrads() (one batched launch)
 
     def fwd(self, x, y):
@@ -709,8 +856,31 @@ class Pointwise:
             with torch.cuda.stream(side):
                 _gemm(x, OUT_MAJOR, self.cin, dy, OUT_MAJOR, self.cout, self.gw, self.cout, self.cin, self.cout,
                       self.M, e, region=WS_GEMM2)
-        if dx is not None:
-            _gemm(dy, K_MAJOR, self.cout, self.w, K_MAJOR, self.cout, dx, self.cin, self.M, self.cin, self.cout, e)
+        if dx is not None:      # dx[M,cin] = dy[M,cout] @ W^T[cout,cin]: the forward operand form on the transposed copy
+            _gemm(dy, K_MAJOR, self.cout, self.wT, OUT_MAJOR, self.cin, dx, self.cin, self.M, self.cin, self.cout, e)
+
+
+    def bwd_blend(self, x, g, yp, bn, dyb, dx):
+        """Backward through BatchNorm + this 1x1 conv in two GEMMs and no elementwise pass: the data-gradient GEMM
+        builds dy = BN'(g, yp) while staging its A operand (coefficients in bn.coef) and writes it to dyb once;
+        the weight-gradient GEMM (side stream / deferred batched launch) then reads dyb."""
+        e = self.e
+        prof = e.prof
+        t0 = prof.start() if prof is not None else None
+        L.spnet_gemm_f32_bnblend(L.ptr(g), L.ptr(yp), L.ptr(bn.coef), bn.cld, self.cout, L.ptr(self.wT), self.cin,
+                                 L.ptr(dx), self.cin, self.M, self.cin, self.cout, 0, L.ptr(dyb), _stream())
+        if prof is not None:
+            prof.stop("gemm", t0, 2.0 * self.M * self.cin * self.cout)
+        side = e.wgrad_stream
+        if self.defer_wgrad:
+            e.deferred_wgrads.append((x, dyb, self.gw, self.cin, self.cout, self.M))
+        elif side is None:
+            _gemm(x, OUT_MAJOR, self.cin, dyb, OUT_MAJOR, self.cout, self.gw, self.cout, self.cin, self.cout, self.M, e)
+        else:
+            side.wait_stream(torch.cuda.current_stream())      # dyb has just been produced on the main stream
+            with torch.cuda.stream(side):
+                _gemm(x, OUT_MAJOR, self.cin, dyb, OUT_MAJOR, self.cout, self.gw, self.cout, self.cin, self.cout,
+                      self.M, e, region=WS_GEMM2)
 
 
 class Conv3x3Gemm(Node):
@@ -724,6 +894,7 @@ class Conv3x3Gemm(Node):
         self.OH, self.OW = H - 2, W - 2
         self.y = eng.new(B, self.OH, self.OW, cout)
         self.w = eng.P(name + "/kernel")
+        self.pnames = [name]
         if eng.train_capable:
             self.gw = eng.G(name + "/kernel")
             self.dx = eng.new(*x.shape)
@@ -780,6 +951,25 @@ class BN:
         if eng.train_capable:
             self.ggamma, self.gbeta = eng.G(name + "/gamma"), eng.G(name + "/beta")
             self.save = eng.new(2 * C)           # [batch mean | invstd]
+            # backward as an operand blend: dx = k1*g + k2*x + k3 is built by the consuming GEMM while it stages its
+            # A tile (spnet_gemm_f32_bnblend); [k1 | k2 | k3], cld floats apart, zero beyond C (whole K tiles)
+            self.cld = (C + 63) // 64 * 64
+            self.coef = torch.zeros(3 * self.cld, device=eng.dev, dtype=torch.float32)
+
+    def coeffs_from_partials(self, rows):
+        """dgamma, dbeta and the blend coefficients from the (sum g, sum g*xhat) partial rows a consumer's fused
+        depthwise backward left in WS_BNP."""
+        e = self.e
+        L.spnet_bn_bwd_coeffs_from_partials(rows, e.ws_ptr(WS_BNP), self.M, self.C, L.ptr(self.gamma), self.mean_ptr,
+                                            self.invstd_ptr, L.ptr(self.ggamma), L.ptr(self.gbeta), L.ptr(self.coef),
+                                            self.cld, _stream())
+
+    def coeffs_full(self, x, g):
+        """The same from an own reduction pass over (x, g) (no activation behind this BatchNorm)."""
+        e = self.e
+        L.spnet_bn_bwd_coeffs(L.ptr(x), L.ptr(g), self.M, self.C, L.ptr(self.gamma), L.ptr(self.beta), self.mean_ptr,
+                              self.invstd_ptr, L.ptr(self.ggamma), L.ptr(self.gbeta), L.ptr(self.coef), self.cld,
+                              e.ws_ptr(WS_MISC), _stream())
 
     @property
     def scale_ptr(self):
@@ -876,7 +1066,11 @@ class SepConvBN:
             # that ALL units' reductions run as one launch at the end of backward, off the dependency chain.
             self.wpart = eng.new(L.spnet_dwconv3x3_tiled_bwd_ws(B, H, W, cin))
             eng.dw_reduce_jobs.append((self.wpart, self.gwd, self.rows_src, 9 * cin))
-            self.dbn = None if bwd_inplace else eng.new(B, H, W, cout)
+            # BatchNorm-backward output dy: written once by the blending data-gradient GEMM for the weight gradient
+            # (units with an activation behind their BN take the unfused path and use dbn / the incoming buffer)
+            self.blend = (act == ACT_NONE or mode != "apply") and os.environ.get("SPNET_BN_BLEND", "1") != "0"
+            self.dyb = eng.new(B, H, W, cout) if self.blend else None
+            self.dbn = None if (bwd_inplace or self.blend) else eng.new(B, H, W, cout)
         if src.bn is not None and hasattr(src, "owner"):
             src.owner.consumer_rows = self.rows_src
 
@@ -909,12 +1103,20 @@ class SepConvBN:
         """g: gradient wrt this unit's BN output (after `act` for mode 'apply').  Returns the gradient wrt
         the source as its consumers see it (wrt src's BN output when src is lazy), plus `add`."""
         e, sb = self.e, self.src.bn
-        out = g if self.bwd_inplace else self.dbn
-        if self.mode == "lazy" or (self.consumer_rows and self.act == ACT_NONE):
-            dy = self.bn.bwd_from_partials(self.yp, g, out, self.consumer_rows)
+        from_partials = self.mode == "lazy" or (self.consumer_rows and self.act == ACT_NONE)
+        if self.blend:
+            if from_partials:
+                self.bn.coeffs_from_partials(self.consumer_rows)
+            else:
+                self.bn.coeffs_full(self.yp, g)
+            self.pw.bwd_blend(self.z, g, self.yp, self.bn, self.dyb, self.dz)
         else:
-            dy = self.bn.bwd_full(self.yp, g, out, self.act if self.mode == "apply" else ACT_NONE)
-        self.pw.bwd(self.z, dy, self.dz)
+            out = g if self.bwd_inplace else self.dbn
+            if from_partials:
+                dy = self.bn.bwd_from_partials(self.yp, g, out, self.consumer_rows)
+            else:
+                dy = self.bn.bwd_full(self.yp, g, out, self.act if self.mode == "apply" else ACT_NONE)
+            self.pw.bwd(self.z, dy, self.dz)
         st = self.src.stats_bn if self.src.stats_bn is not None else sb     # whose backward sums to emit
         prof = e.prof
         if prof is not None:
@@ -936,6 +1138,7 @@ class MiddleBlock(Node):
         """prev: the middle block whose output is x -- its closing BatchNorm's backward sums then come out of
         this block's first depthwise backward (which reads yp of that BN beside x), saving a reduction pass."""
         self.x = x
+        self.pnames = [n for k in (1, 2, 3) for n in ("block%d_sepconv%d" % (b, k), "block%d_sepconv%d_bn" % (b, k))]
         src = Ref(x)
         if prev is not None and eng.train_capable:
             src = Ref(x, stats_bn=prev.u3.bn, stats_x=prev.u3.yp)
@@ -970,6 +1173,8 @@ class StridedBlock(Node):
 
     def __init__(self, eng, x, b, cin, c1, c2, first_relu, conv_name, bn_name):
         self.e, self.x, self.cin, self.c2 = eng, x, cin, c2
+        self.pnames = [conv_name, bn_name] + [n for k in (1, 2) for n in ("block%d_sepconv%d" % (b, k),
+                                                                           "block%d_sepconv%d_bn" % (b, k))]
         B, H, W, _ = x.shape
         self.H, self.W = H, W
         OH, OW = (H + 1) // 2, (W + 1) // 2
@@ -985,6 +1190,8 @@ class StridedBlock(Node):
         if eng.train_capable:
             self.idx = torch.empty(B * OH * OW * (c2 // 4), device=eng.dev, dtype=torch.int32)
             self.dxs = eng.new(B, OH, OW, cin)
+            self.blend = os.environ.get("SPNET_BN_BLEND", "1") != "0"
+            self.dyr = eng.new(B, OH, OW, c2) if self.blend else None
             self.dpool = eng.new(B, H, W, c2)
         else:
             self.idx = None
@@ -1016,8 +1223,12 @@ class StridedBlock(Node):
     def bwd(self, g):
         e = self.e
         L.spnet_maxpool3x3s2_bwd(L.ptr(g), L.ptr(self.idx), L.ptr(self.dpool), e.B, self.H, self.W, self.c2, _stream())
-        gr = self.bnr.bwd_full(self.yr, g, g, ACT_NONE)       # in place: g is dead after the pool backward
-        self.pwr.bwd(self.xs, gr, self.dxs)
+        if self.blend:
+            self.bnr.coeffs_full(self.yr, g)
+            self.pwr.bwd_blend(self.xs, g, self.yr, self.bnr, self.dyr, self.dxs)
+        else:
+            gr = self.bnr.bwd_full(self.yr, g, g, ACT_NONE)       # in place: g is dead after the pool backward
+            self.pwr.bwd(self.xs, gr, self.dxs)
         d = self.u2.bwd(self.dpool)
         dx = self.u1.bwd(d)
         L.spnet_scatter_add_s2(L.ptr(self.dxs), L.ptr(dx), e.B, self.H, self.W, self.cin, _stream())
@@ -1029,6 +1240,7 @@ class ExitBlock(Node):
     depthwise on load, the last one when the block output is materialised for the Dense head."""
 
     def __init__(self, eng, x, cin, c1, c2):
+        self.pnames = ["block14_sepconv1", "block14_sepconv1_bn", "block14_sepconv2", "block14_sepconv2_bn"]
         self.u1 = SepConvBN(eng, Ref(x), cin, c1, "block14_sepconv1", False, mode="lazy")
         self.u2 = SepConvBN(eng, self.u1.ref(), c1, c2, "block14_sepconv2", True, mode="apply", act=ACT_RELU)
         self.y = self.u2.y
@@ -1046,6 +1258,7 @@ class Dense(Node):
 
     def __init__(self, eng, x, n_out, name):
         self.e, self.x, self.n_out = eng, x, n_out
+        self.pnames = [name]
         self.K = x.numel() // eng.B
         self.w, self.b = eng.P(name + "/kernel"), eng.P(name + "/bias")
         self.y = eng.new(eng.B, n_out)

@@ -117,8 +117,12 @@ def generate(n, seed=0, workers=None):
     seeds = [seed * 1000003 + i for i in range(n)]
     workers = workers or min(os.cpu_count() or 1, 16)
     if workers > 1 and n >= 16:
-        with Pool(workers) as p:
+        p = Pool(workers)
+        try:
             res = p.map(gen_frame, seeds, chunksize=max(1, n // (workers * 4)))
+        finally:                     # let the workers exit normally (Pool.__exit__ would terminate() = SIGTERM them)
+            p.close()
+            p.join()
     else:
         res = [gen_frame(s) for s in seeds]
     X = np.stack([r[0] for r in res])

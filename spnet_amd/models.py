@@ -163,14 +163,23 @@ class Model:
 
     def __init__(self, input_shape, Y0size=576, freeze_fac=0.0, seed=None, device=None):
         torch = _require_gpu()
+        from . import parallel
         from .engine import Engine
+        # Select this rank's GPU (and join the torchrun process group) BEFORE anything is allocated: every plan,
+        # callback buffer and kernel launch of this process then lives on cuda:LOCAL_RANK.
+        self.rank, _, self.world = parallel.init_distributed()
         if cf.basemodel != 'Xception':
             raise NotImplementedError("this build implements the Xception backbone (cf.basemodel=%r)" % cf.basemodel)
         self.input_shape = tuple(int(v) for v in input_shape)
         H, W = self.input_shape[0], self.input_shape[1]
         self.H, self.W, self.Y0size = H, W, int(Y0size)
-        self.device = device or "cuda:%d" % torch.cuda.current_device()
+        self.device = device or str(parallel.local_device())
         self.seed = int(np.random.randint(0, 2 ** 31 - 1)) if seed is None else seed
+        if self.world > 1:                 # replicas must start from identical weights: rank 0's seed rules
+            import torch.distributed as dist
+            box = [self.seed]
+            dist.broadcast_object_list(box, src=0)
+            self.seed = int(box[0])
         self.optimizer = _Optimizer(1e-5)
         self.trainable = True
         self.stop_training = False
@@ -181,7 +190,9 @@ class Model:
         self._root = None
         self._train_frames = None          # (id of host array, device tensor) registered by AugmentOnTheFly
         self._uploaded = {}
-        self._reducer = None
+        self._rings = {}                   # predict(): pinned staging rings per (batch size, device)
+        self._epochs_seen = 0              # epochs trained so far (over all fit() calls): the shard permutation's index
+        self.epoch_indices = None          # data parallel: this rank's sample indices of the current epoch
         self._base = self._engine(1, train=False)      # owns the weights
         self._apply_freeze(freeze_fac)
 
@@ -196,7 +207,7 @@ class Model:
                 for a in ("grad", "m", "v"):       # optimizer state lives beside the weights it updates
                     setattr(root, a, torch.zeros(root.n_theta, device=root.dev, dtype=torch.float32))
             eng = self._Engine(self.H, self.W, batch, n_out=self.Y0size, device=self.device, loss_type=cf.loss_type,
-                               seed=self.seed, train=train, share_from=root)
+                               seed=self.seed, train=train, share_from=root, rank=self.rank)
             if root is None:
                 self._root = eng
             self._engines[key] = eng
@@ -256,16 +267,13 @@ class Model:
         from safetensors.torch import save_file
         meta = {"format": "spnet_amd-model-v1", "input_shape": json.dumps(self.input_shape), "Y0size": str(self.Y0size),
                 "basemodel": cf.basemodel, "model_type": cf.model_type, "loss_type": cf.loss_type,
-                "optimizer_iterations": str(self._root.t if hasattr(self._root, "t") else 0)}
+                "optimizer_iterations": str(self._root.t)}
         save_file({k: v.contiguous() for k, v in self._root.state_dict().items()}, path, metadata=meta)
 
     # -- data plumbing ----------------------------------------------------------------------------
     def set_train_frames(self, host_array, device_tensor):
         """AugmentOnTheFly registers the device tensor that shadows the host training array."""
         self._train_frames = (id(host_array), device_tensor)
-
-    def set_reducer(self, reducer_factory):
-        self._reducer = reducer_factory
 
     def _device_frames(self, X):
         torch = _torch()
@@ -284,21 +292,67 @@ class Model:
 
     # -- inference --------------------------------------------------------------------------------
     def predict(self, X, batch_size=32, verbose=0):
+        """model.predict(X, batch_size) (predict_spnet.py:85, evaluate_spnet.py:66): [N,576] float32.
+
+        One static launch plan per batch size, replayed as a hipGraph (Engine.predict_step).  Host frames are STREAMED:
+        batch k+1 travels host -> pinned ring -> HBM on a copy stream while batch k is being computed, so neither
+        the whole set nor a second copy of it has to fit anywhere and the PCIe transfer hides behind the forward
+        passes; device-resident frames are read in place."""
         torch = _torch()
-        Xd = self._device_frames(X)
-        N = Xd.shape[0]
-        bs = max(1, min(int(batch_size), N))
+        N = int(X.shape[0])
+        bs = max(1, min(int(batch_size), max(N, 1)))
         eng = self._engine(bs, train=False)
-        out = torch.empty(N, self.Y0size, device=Xd.device)
-        for lo in range(0, N, bs):
-            hi = min(N, lo + bs)
-            if hi - lo == bs:
-                eng.x_in.copy_(Xd[lo:hi].reshape(eng.x_in.shape))
+        dev = eng.dev
+        out = torch.empty(N, self.Y0size, device=dev)
+        if N == 0:
+            return out.cpu().numpy()
+        resident = X if isinstance(X, torch.Tensor) else None
+        if resident is None and self._train_frames is not None and self._train_frames[0] == id(X):
+            resident = self._train_frames[1]
+        if resident is not None and not resident.is_cuda:
+            resident = resident.to(dev)
+
+        def run(lo, hi, frames):
+            """frames: device tensor holding hi-lo frames"""
+            n = hi - lo
+            if n == bs:
+                eng.x_in.copy_(frames.reshape(eng.x_in.shape))
             else:                                   # ragged tail: pad with the last frame, drop the extras
-                eng.x_in[:hi - lo].copy_(Xd[lo:hi].reshape(hi - lo, self.H, self.W, 1))
-                eng.x_in[hi - lo:].copy_(Xd[hi - 1:hi].reshape(1, self.H, self.W, 1).expand(bs - (hi - lo), -1, -1, -1))
-            y = eng.forward(None, training=False)
-            out[lo:hi].copy_(y[:hi - lo])
+                eng.x_in[:n].copy_(frames.reshape(n, self.H, self.W, 1))
+                eng.x_in[n:].copy_(frames.reshape(n, self.H, self.W, 1)[n - 1:n].expand(bs - n, -1, -1, -1))
+            y = eng.predict_step()
+            out[lo:hi].copy_(y[:n])
+
+        if resident is not None:
+            for lo in range(0, N, bs):
+                hi = min(N, lo + bs)
+                run(lo, hi, resident[lo:hi])
+            return out.cpu().numpy()
+
+        # host frames: pinned ring + copy stream
+        Xh = np.ascontiguousarray(X, dtype=np.float32).reshape(N, self.H, self.W, 1)
+        depth = 3
+        key = (bs, str(dev))
+        ring = self._rings.get(key)
+        if ring is None:
+            ring = [(torch.empty((bs, self.H, self.W, 1), dtype=torch.float32).pin_memory(),
+                     torch.empty((bs, self.H, self.W, 1), dtype=torch.float32, device=dev),
+                     torch.cuda.Event(), torch.cuda.Event()) for _ in range(depth)]
+            self._rings[key] = ring
+            self._copy_stream = torch.cuda.Stream(device=dev)
+        main = torch.cuda.current_stream()
+        for k, lo in enumerate(range(0, N, bs)):
+            hi = min(N, lo + bs)
+            n = hi - lo
+            host, devbuf, landed, consumed = ring[k % depth]
+            consumed.synchronize()                   # the forward that read this slot `depth` batches ago is done
+            host[:n].copy_(torch.from_numpy(Xh[lo:hi]))
+            with torch.cuda.stream(self._copy_stream):
+                devbuf[:n].copy_(host[:n], non_blocking=True)
+                landed.record(self._copy_stream)
+            main.wait_event(landed)
+            run(lo, hi, devbuf[:n])
+            consumed.record(main)
         return out.cpu().numpy()
 
     def evaluate(self, X, Y, batch_size=32, verbose=0):
@@ -307,8 +361,10 @@ class Model:
     # -- training ---------------------------------------------------------------------------------
     def fit(self, X, Y, batch_size=32, epochs=1, shuffle=True, verbose=1, validation_data=None, callbacks=None,
             initial_epoch=0):
+        """Keras Model.fit.  Under torchrun (world > 1) `batch_size` is the PER-GPU batch: every rank trains on its
+        rank-strided slice of a shared-seed epoch permutation (parallel.shard_indices), gradients are all-reduced
+        bucket by bucket during backward, rank 0 alone prints, validates and feeds the logging callbacks."""
         torch = _torch()
-        import torch.distributed as dist
         from . import _lib as L
         from . import parallel
         callbacks = list(callbacks or [])
@@ -317,24 +373,32 @@ class Model:
         eng = self._engine(batch_size, train=True)
         eng.update_mask = self._mask
         upload = L.AsyncUploader(eng.dev)
-        world = dist.get_world_size() if dist.is_initialized() else 1
-        rank = dist.get_rank() if dist.is_initialized() else 0
-        reducer = parallel.GradReducer(eng.grad, eng.head_grad_range()) if world > 1 else None
+        world, rank = self.world, self.rank
+        reducer = eng.make_reducer() if world > 1 else None
         Yd = torch.from_numpy(np.ascontiguousarray(Y, dtype=np.float32)).to(eng.dev) if isinstance(Y, np.ndarray) else Y
         N = Yd.shape[0]
+        chatty = verbose and rank == 0
         for cb in callbacks:
             cb.on_train_begin({})
         history = {"loss": [], "val_loss": []}
         for epoch in range(initial_epoch, epochs):
             t_epoch = time.time()
+            if world > 1:
+                # sharded BEFORE the callbacks run, so that AugmentOnTheFly augments this rank's samples only
+                self.epoch_indices = parallel.shard_indices(N, self._epochs_seen, rank, world, seed=self.seed,
+                                                            batch_size=batch_size)
+                if not shuffle:
+                    self.epoch_indices = np.sort(self.epoch_indices)
             for cb in callbacks:
                 cb.on_epoch_begin(epoch, {})
             Xd = self._device_frames(X)
-            index = np.arange(N)
-            if shuffle:
-                np.random.shuffle(index)               # Keras shuffles with numpy's global RNG
             if world > 1:
-                index = index[rank::world][:N // world]
+                index = self.epoch_indices
+            else:
+                index = np.arange(N)
+                if shuffle:
+                    np.random.shuffle(index)           # Keras shuffles with numpy's global RNG
+            self._epochs_seen += 1
             nb = len(index) // batch_size
             loss_sum = torch.zeros(2, device=eng.dev, dtype=torch.float64)
             for b in range(nb):
@@ -345,16 +409,17 @@ class Model:
                 torch.index_select(Yd, 0, idx, out=eng.y_true)
                 out = eng.train_step(None, None, float(self.optimizer.lr), reducer=reducer)
                 loss_sum += out[5:7].double()
-                if verbose and (b % max(1, nb // 20) == 0 or b == nb - 1):
+                if chatty and (b % max(1, nb // 20) == 0 or b == nb - 1):
                     print("\rEpoch %d/%d  batch %d/%d" % (epoch + 1, epochs, b + 1, nb), end="", flush=True)
             ls = (loss_sum / max(nb, 1)).cpu().numpy()
-            logs = {"loss": float(ls[0] + ls[1])}             # Keras reports data loss + regularisation
-            if validation_data is not None:
+            data_loss = parallel.all_reduce_scalar_mean(float(ls[0]))    # mean over the replicas' shards
+            logs = {"loss": data_loss + float(ls[1])}         # Keras reports data loss + regularisation
+            if validation_data is not None and rank == 0:
                 Xv, Yv = validation_data[0], validation_data[1]
                 logs["val_loss"] = custom_loss(Yv, self.predict(Xv, batch_size=batch_size)) + float(ls[1])
             history["loss"].append(logs["loss"])
             history["val_loss"].append(logs.get("val_loss"))
-            if verbose:
+            if chatty:
                 n_img = nb * batch_size * world
                 print("\r%d/%d - %ds - loss: %.4e%s" % (n_img, n_img, time.time() - t_epoch, logs["loss"],
                                                           (" - val_loss: %.4e" % logs["val_loss"]) if "val_loss" in logs else ""))
@@ -406,6 +471,8 @@ def setup_model(X, Y0size=576, try_checkpoint=True, no_cp_fatal=False, weights_f
     Returns (model, serial_model) -- the same object twice: data parallelism here is one process per
     GPU (spnet_amd/parallel.py), not an in-graph wrapper."""
     print("Initializing blank model: Y0size =", Y0size)
+    if parallel:            # pick this rank's GPU and join the process group before anything is allocated
+        multi_gpu.make_parallel(None)
     if cf.model_type == 'simple':
         model = create_model_simple(X, Y0size=Y0size, freeze_fac=freeze_fac)
     else:
@@ -419,8 +486,6 @@ def setup_model(X, Y0size=576, try_checkpoint=True, no_cp_fatal=False, weights_f
         else:
             print('    No weights file detected, so starting from scratch.')
     model.optimizer = _Optimizer(lr=0.00001)
-    if parallel:
-        model = multi_gpu.make_parallel(model)
     print("Compiling the model")
     return model, model
 

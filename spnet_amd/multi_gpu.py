@@ -15,7 +15,8 @@ def get_available_gpus():
 
 
 def make_parallel(model):
-    """Join the torchrun process group (no-op when WORLD_SIZE is 1); the model object is unchanged."""
+    """Select this rank's GPU and join the torchrun process group (no-op when WORLD_SIZE is 1); the model
+    object is returned unchanged.  Call it BEFORE building the model (setup_model does)."""
     rank, local_rank, world = parallel.init_distributed()
     if world > 1:
         print("make_parallel: rank %d of %d, RCCL gradient all-reduce over xGMI" % (rank, world))

@@ -1,0 +1,112 @@
+"""Shared helpers of the engine-vs-oracle parity tests (test infrastructure)."""
+import numpy as np
+import torch
+
+from oracle import torch_ref as T
+
+
+def dropout_mask(n, seed, rate=0.1):
+    """numpy restatement of csrc/augment.hip dropout_kernel's counter hash (test-side oracle)."""
+    i = np.arange(n, dtype=np.uint64)
+    x = (i * np.uint64(0x9e3779b9) + np.uint64(seed)) & np.uint64(0xFFFFFFFF)
+    x ^= x >> np.uint64(16)
+    x = (x * np.uint64(0x7feb352d)) & np.uint64(0xFFFFFFFF)
+    x ^= x >> np.uint64(15)
+    x = (x * np.uint64(0x846ca68b)) & np.uint64(0xFFFFFFFF)
+    x ^= x >> np.uint64(16)
+    thresh = np.uint64(int(float(np.float32(rate)) * 4294967296.0))
+    return np.where(x >= thresh, np.float32(1.0) / (np.float32(1.0) - np.float32(rate)), np.float32(0)).astype(np.float32)
+
+
+def randomize_bn(P, gen):
+    """Non-trivial BatchNorm parameters / moving statistics / biases so that every term is exercised."""
+    for k in P:
+        if k.endswith("/gamma"):
+            P[k] = 0.5 + torch.rand(P[k].shape, generator=gen)
+        elif k.endswith("/beta") or k.endswith("/moving_mean") or k.endswith("/bias"):
+            P[k] = 0.2 * torch.randn(P[k].shape, generator=gen)
+        elif k.endswith("/moving_variance"):
+            P[k] = 0.5 + torch.rand(P[k].shape, generator=gen)
+    return P
+
+
+def make_case(H, W, B, seed):
+    """Seeded weights (Keras initialisers + randomised BatchNorm state), frames, targets and the engine's
+    dropout mask for one (geometry, seed).  Returns P, X, Y, mask, drop_seed."""
+    P = randomize_bn(T.init_params(H, W, seed=1000 + seed), torch.Generator().manual_seed(seed))
+    rs = np.random.RandomState(seed)
+    X = torch.tensor(rs.rand(B, H, W, 1) * 2 - 1, dtype=torch.float32)
+    Y = torch.tensor(rs.rand(B, 576), dtype=torch.float32)
+    Y[:, 6::8] = (Y[:, 6::8] > 0.5).float()
+    dseed = 777 + seed
+    mask = torch.tensor(dropout_mask(B * (H // 2) * (W // 2) * 3, dseed).reshape(B, H // 2, W // 2, 3))
+    return P, X, Y, mask, dseed
+
+
+def rel_err(got, ref):
+    """max|got - ref| / max|ref| -- the per-tensor measure every gradient comparison uses."""
+    ref = np.asarray(ref, dtype=np.float64)
+    return float(np.abs(np.asarray(got, dtype=np.float64) - ref).max()) / max(float(np.abs(ref).max()), 1e-12)
+
+
+def oracle_grads(P, X, Y, mask, double, decisions=None, loss_type="same"):
+    """(data_loss, {name: grad}, y_pred, params-with-updated-moving-stats) of the oracle in fp32 or fp64."""
+    if double:
+        tr = T.Trainer({k: v.double() for k, v in P.items()}, loss_type=loss_type)
+        data, _, g, yp = tr.grads(X.double(), Y.double(), drop_mask=mask.double(), include_l2=False, decisions=decisions)
+    else:
+        tr = T.Trainer({k: v.clone() for k, v in P.items()}, loss_type=loss_type)
+        data, _, g, yp = tr.grads(X, Y, drop_mask=mask, include_l2=False, decisions=decisions)
+    return data, g, yp, tr.P
+
+
+def device_decisions(eng):
+    """The discrete decisions (T.Decisions) the engine's last TRAINING forward took, rebuilt on the host from the
+    tensors it keeps for backward, in the oracle's application order:
+      stem LeakyReLUs / block1 ReLUs   sign of the materialised activation (y > 0  <=>  pre-activation > 0)
+      ReLU in front of a depthwise     the engine applies relu(fmaf(yp, scale, shift)) on load and masks the gradient
+                                       with the same expression; yp*scale+shift in float64 has the sign of the exact
+                                       value, which is the sign fmaf rounds
+      max-pools                        the byte arg-max taps the pooling kernel saved for its backward pass."""
+    from spnet_amd import engine as E
+
+    def cpu(t):
+        return t.detach().cpu()
+
+    def lazy_mask(unit):                 # sign of BN(unit.yp) as the consumer computes it
+        C = unit.cout
+        ss = cpu(unit.bn.ss).double()
+        return (cpu(unit.yp).double() * ss[:C] + ss[C:]) > 0
+
+    relu, pool = [], []
+    for node in eng.nodes:
+        if isinstance(node, E.BatchNorm) and node.act != E.ACT_NONE:
+            relu.append(cpu(node.y) > 0)
+        elif isinstance(node, E.StridedBlock):
+            if node.u1.relu_in:
+                relu.append(cpu(node.x) > 0)
+            relu.append(lazy_mask(node.u1))
+            B, OH, OW, C = node.y.shape
+            taps = cpu(node.idx).view(torch.uint8).reshape(B, OH, OW, C).long()
+            pool.append(taps.permute(0, 3, 1, 2).unsqueeze(2))
+        elif isinstance(node, E.MiddleBlock):
+            relu += [cpu(node.x) > 0, lazy_mask(node.u1), lazy_mask(node.u2)]
+        elif isinstance(node, E.ExitBlock):
+            relu += [lazy_mask(node.u1), cpu(node.u2.y) > 0]
+    return T.Decisions(relu, pool)
+
+
+def assert_gradients_match(eng, P, X, Y, mask, tol=5e-3, tie=1e-4, loss_type="same"):
+    """Every parameter gradient of the engine's last forward/backward against the fp64 oracle evaluated on the
+    device's own discrete decisions: max|diff| <= tol * max|ref| on EVERY tensor, and every decision in which the
+    device departs from the oracle's own must have been a tie (|pre-activation| or window gap <= tie x the largest
+    value of that tensor).  Returns (data_loss64, y_pred64, params64, decisions)."""
+    dec = device_decisions(eng)
+    data64, g64, yp64, P64 = oracle_grads(P, X, Y, mask, double=True, decisions=dec, loss_type=loss_type)
+    assert dec._ri == len(dec.relu) and dec._pi == len(dec.pool), "decision sites out of step with the oracle"
+    far = [f for f in dec.flips if f[2] > tie]
+    assert not far, "device decisions differ from the oracle's away from ties: %s" % far[:8]
+    gd = eng.grad_dict()
+    bad = {k: e for k, e in ((k, rel_err(gd[k].numpy(), g64[k].numpy())) for k in g64) if e > tol}
+    assert not bad, sorted(bad.items(), key=lambda kv: -kv[1])[:8]
+    return data64, yp64, P64, dec

@@ -30,3 +30,54 @@ def test_two_rank_data_parallel_equals_single_process(tmp_path):
     assert set(a.files) == set(b.files)
     bad = [k for k in a.files if not np.array_equal(a[k], b[k])]
     assert not bad, "data-parallel run differs from the single-process run in: %s" % bad[:8]
+
+
+def test_bucketed_allreduce_through_rccl_on_one_rank(tmp_path):
+    """The gradient all-reduce on the "nccl" backend (= RCCL): a forced one-rank group on the one GPU executes every
+    bucket's collective on RCCL's stream, launched from the weight-gradient stream while backward is running.
+    The sum over one rank is the identity, so the weights must equal the no-reducer run bit for bit -- any
+    difference is an ordering bug between the two compute streams and RCCL's."""
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    env = dict(os.environ, PYTHONPATH=ROOT, HSA_ENABLE_IPC_MODE_LEGACY="0", RANK="0", LOCAL_RANK="0", WORLD_SIZE="1",
+               MASTER_ADDR="127.0.0.1", MASTER_PORT="29717")
+    env.pop("SPNET_DIST_BACKEND", None)
+    single, rccl = str(tmp_path / "single.npz"), str(tmp_path / "rccl.npz")
+    r = subprocess.run([sys.executable, HELPER, single, "3"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    r = subprocess.run([sys.executable, HELPER, rccl, "3", "rccl1"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-1000:] + r.stderr[-2000:]
+    assert "backend nccl" in r.stdout, r.stdout
+    a, b = np.load(single), np.load(rccl)
+    bad = [k for k in a.files if not np.array_equal(a[k], b[k])]
+    assert not bad, "RCCL run differs from the plain run in: %s" % bad[:8]
+
+
+def test_two_rank_training_through_train_network(tmp_path):
+    """train_spnet.py under torch.distributed.run with two ranks (gloo, both on the one GPU): Model.fit shards every
+    epoch by rank, augments only its shard, all-reduces the gradient buckets, and rank 0 alone writes logs and
+    checkpoints.  The replicas' weights must stay identical."""
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from spnet_amd import fake_espi as F
+    data = tmp_path / "data"
+    F.write_dataset(str(data / "Train"), 64, seed=1)
+    F.write_dataset(str(data / "Val"), 16, seed=2)
+    work = tmp_path / "work"
+    work.mkdir()
+    env = dict(os.environ, PYTHONPATH=ROOT, SPNET_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0",
+               SPNET_DUMP_WEIGHT_SUM=str(work / "wsum"))
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", "29719", os.path.join(ROOT, "train_spnet.py"),
+                        "-d", str(data), "-b", "8", "-e", "2", "--name", "dp"], cwd=str(work), env=env,
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + "\n" + r.stderr[-3000:]
+    assert "SPNet execution completed." in r.stdout
+    logs = [d for d in os.listdir(work / "logs") if d.startswith("dp_")]
+    assert len(logs) == 1                                   # one writer
+    rows = [l for l in open(work / "logs" / logs[0] / "losses.dat") if not l.startswith("#")]
+    assert len(rows) == 2 and all(np.isfinite(float(x.split()[1])) for x in rows)
+    sums = [open(str(work / "wsum") + ".%d" % k).read().strip() for k in (0, 1)]
+    assert sums[0] == sums[1], sums                         # replicas in lock-step

@@ -15,17 +15,7 @@ from oracle import torch_ref as T
 H, W, B = 96, 128, 2
 
 
-def dropout_mask(n, seed, rate=0.1):
-    """numpy restatement of csrc/augment.hip dropout_kernel's counter hash (test-side oracle)."""
-    i = np.arange(n, dtype=np.uint64)
-    x = (i * np.uint64(0x9e3779b9) + np.uint64(seed)) & np.uint64(0xFFFFFFFF)
-    x ^= x >> np.uint64(16)
-    x = (x * np.uint64(0x7feb352d)) & np.uint64(0xFFFFFFFF)
-    x ^= x >> np.uint64(15)
-    x = (x * np.uint64(0x846ca68b)) & np.uint64(0xFFFFFFFF)
-    x ^= x >> np.uint64(16)
-    thresh = np.uint64(int(float(np.float32(rate)) * 4294967296.0))
-    return np.where(x >= thresh, np.float32(1.0) / (np.float32(1.0) - np.float32(rate)), np.float32(0)).astype(np.float32)
+from tests.parity_util import dropout_mask  # noqa: E402,F401  (re-exported for the other test modules)
 
 
 @pytest.fixture(scope="module")
@@ -98,7 +88,8 @@ def test_training_forward_and_gradients(setup):
     for k in P:
         if k.endswith("moving_mean") or k.endswith("moving_variance"):
             np.testing.assert_allclose(sd[k].numpy(), Pc[k].numpy(), rtol=1e-4, atol=1e-5, err_msg=k)
-    # every parameter gradient, tensor by tensor, relative to that tensor's largest entry
+    # every parameter gradient, tensor by tensor, relative to that tensor's largest entry: against the oracle in
+    # fp32 as is, and against the fp64 oracle on the device's discrete decisions (tests/test_shapes_gpu.py)
     gd = eng.grad_dict()
     worst = {}
     for k, g in grads.items():
@@ -108,6 +99,8 @@ def test_training_forward_and_gradients(setup):
         worst[k] = float(np.abs(got - ref).max()) / denom
     bad = {k: v for k, v in worst.items() if v > 5e-3}
     assert not bad, "gradient mismatch (max|diff|/max|ref|): %s" % sorted(bad.items(), key=lambda kv: -kv[1])[:8]
+    from tests.parity_util import assert_gradients_match
+    assert_gradients_match(eng, P, X, Y, mask, tol=1e-3)
 
 
 def test_train_steps_follow_oracle(setup):

@@ -122,11 +122,9 @@ def test_hybrid_loss_gradients_small():
     eng.backward()
     torch.cuda.synchronize()
     np.testing.assert_allclose(float(loss[5]), data, rtol=1e-4)
-    gd = eng.grad_dict()
-    for k in ("FinalOutput/kernel", "block14_sepconv2/pointwise_kernel", "block5_sepconv1/depthwise_kernel", "conv2d_1/kernel"):
-        ref = grads[k].numpy()
-        # BatchNorm over the 24 samples of the 3x4 planes amplifies fp32 rounding on the way down to the stem
-        assert np.abs(gd[k].numpy() - ref).max() <= 1e-2 * np.abs(ref).max() + 1e-12, k
+    # every tensor, on the device's own ReLU / max-pool decisions, fp64 reference (tests/test_shapes_gpu.py)
+    from tests.parity_util import assert_gradients_match
+    assert_gradients_match(eng, P, X, Y, mask, tol=5e-3, loss_type="hybrid")
 
 
 def test_predict_ragged_batches_match():

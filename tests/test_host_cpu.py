@@ -185,6 +185,21 @@ scale = red.finish()
 want = torch.arange(n, dtype=torch.float32) * sum(r + 1 for r in range(world))
 assert torch.equal(g, want), (rank, g[:5])
 assert scale == 1.0 / world
+# bucketed form: pieces launched as their trigger nodes complete (reverse layer order), tail at finish()
+g = torch.arange(n, dtype=torch.float32) * (rank + 1)
+head, blk, stem = object(), object(), object()
+red = parallel.GradReducer(g, [(0, 300, head), (300, 500, head), (800, 1000, blk), (650, 800, stem)], tail=[(500, 650)])
+for node in (head, blk, object(), stem):
+    red.on_node_done(node)
+assert red.launched == 4
+assert red.finish() == 1.0 / world and torch.equal(g, want)
+try:
+    parallel.GradReducer(g, [(0, 300, head)], tail=[(400, 1000)])
+    raise SystemExit("a gap between buckets must be rejected")
+except ValueError:
+    pass
+s1 = parallel.sample_seed(1, 3, 17)
+assert s1 == parallel.sample_seed(1, 3, 17) != parallel.sample_seed(1, 3, 18) and 0 <= s1 < 2 ** 31
 idx = parallel.shard_indices(103, epoch=2, rank=rank, world=world, seed=1, batch_size=4)
 allidx = [None] * world
 dist.all_gather_object(allidx, idx.tolist())

@@ -556,3 +556,59 @@ def test_warp_affine_identity_flip_translate(L):
     want = torch.zeros(H, W, C)
     want[:H - 2, 3:, :] = x[1].cpu()[2:, :W - 3, :]
     assert torch.equal(out[1].cpu(), want)
+
+
+def test_transpose_batched(L):
+    rs = np.random.RandomState(5)
+    shapes = [(728, 728), (64, 128), (1536, 2048), (33, 100), (4, 4)]
+    srcs = [dev(rs.randn(r, c)) for r, c in shapes]
+    dsts = [torch.full((c, r), float("nan"), device="cuda") for r, c in shapes]
+    table = torch.tensor([v for s_, d_, (r, c) in zip(srcs, dsts, shapes) for v in (s_.data_ptr(), d_.data_ptr(), r, c)],
+                         dtype=torch.int64, device="cuda")
+    L.spnet_transpose_batched(table.data_ptr(), len(shapes), max(r for r, _ in shapes), max(c for _, c in shapes), st())
+    for s_, d_ in zip(srcs, dsts):
+        assert torch.equal(d_, s_.t().contiguous())            # a copy: bit-exact
+
+
+@pytest.mark.parametrize("M,N,K", [(6144, 728, 728), (1000, 136, 200), (96, 64, 32), (37, 64, 288), (23250, 128, 128)])
+@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4, 5, 6, 7, 8])
+def test_gemm_with_batchnorm_backward_blended_into_the_a_operand(L, M, N, K, tile):
+    """dX = BN'(g, yp) @ W^T without a BatchNorm-backward pass: spnet_bn_bwd_coeffs* + spnet_gemm_f32_bnblend against
+    autograd through BatchNorm (fp64) followed by the product; dy_out must hold exactly the blended operand."""
+    rs = np.random.RandomState(M + N + K)
+    yp = torch.tensor(rs.randn(M, K) * 1.3 + 0.2, dtype=torch.float64, requires_grad=True)
+    gamma = torch.tensor(rs.rand(K) + 0.5, dtype=torch.float64, requires_grad=True)
+    beta = torch.tensor(rs.randn(K) * 0.2, dtype=torch.float64, requires_grad=True)
+    g = torch.tensor(rs.randn(M, K), dtype=torch.float64)
+    Wt = torch.tensor(rs.randn(K, N) / np.sqrt(K), dtype=torch.float64)        # W^T, output-major
+    mu, var = yp.mean(0), yp.var(0, unbiased=False)
+    y = (yp - mu) * torch.rsqrt(var + 1e-3) * gamma + beta
+    y.backward(g)
+    dy_ref = yp.grad
+    dx_ref = dy_ref @ Wt
+    ypd, gd, gad, bed, wtd = (t.detach().float().cuda() for t in (yp, g, gamma, beta, Wt))
+    save = torch.cat([mu.detach().float(), torch.rsqrt(var.detach() + 1e-3).float()]).cuda()
+    cld = (K + 63) // 64 * 64
+    coef = torch.zeros(3 * cld, device="cuda")
+    dga, dbe = torch.empty(K, device="cuda"), torch.empty(K, device="cuda")
+    ws = torch.empty(L.spnet_bn_ws(M, K), device="cuda")
+    L.spnet_bn_bwd_coeffs(ypd.data_ptr(), gd.data_ptr(), M, K, gad.data_ptr(), bed.data_ptr(), save.data_ptr(),
+                          save[K:].data_ptr(), dga.data_ptr(), dbe.data_ptr(), coef.data_ptr(), cld, ws.data_ptr(), st())
+    close(dga, gamma.grad, rtol=1e-4, atol=1e-4 * np.sqrt(M))
+    close(dbe, beta.grad, rtol=1e-4, atol=1e-4 * np.sqrt(M))
+    assert float(coef.view(3, cld)[:, K:].abs().max()) == 0.0 if cld > K else True
+    dx = torch.full((M, N), float("nan"), device="cuda")
+    dyo = torch.full((M, K), float("nan"), device="cuda")
+    L.spnet_gemm_f32_bnblend(gd.data_ptr(), ypd.data_ptr(), coef.data_ptr(), cld, K, wtd.data_ptr(), N, dx.data_ptr(), N,
+                             M, N, K, tile, dyo.data_ptr(), st())
+    close(dyo, dy_ref, rtol=1e-4, atol=3e-5)
+    close(dx, dx_ref, rtol=1e-4, atol=3e-5 * np.sqrt(K))
+    # the weight gradient's operand is exactly what the data gradient multiplied: recompute the blend on the host
+    a, b, c = coef.view(3, cld)[0, :K].cpu(), coef.view(3, cld)[1, :K].cpu(), coef.view(3, cld)[2, :K].cpu()
+    host = torch.addcmul(torch.addcmul(c.double(), b.double(), ypd.cpu().double()), a.double(), gd.cpu().double())
+    close(dyo, host, rtol=1e-6, atol=1e-6)
+    # without dy_out
+    dx2 = torch.empty_like(dx)
+    L.spnet_gemm_f32_bnblend(gd.data_ptr(), ypd.data_ptr(), coef.data_ptr(), cld, K, wtd.data_ptr(), N, dx2.data_ptr(), N,
+                             M, N, K, tile, None, st())
+    assert torch.equal(dx, dx2)

@@ -1,6 +1,18 @@
 """Odd geometries through the whole engine against the torch-CPU oracle: frame sizes that are not multiples
 of anything (ragged tiles in every kernel, SAME-padding parity changes, 1-pixel planes in the exit flow) and
-batch sizes 1 / 3."""
+batch sizes 1 / 3.
+
+Gradients are compared with the fp64 oracle evaluated ON THE DEVICE'S OWN DISCRETE DECISIONS (ReLU / LeakyReLU
+signs, max-pool arg-max taps; oracle.torch_ref.Decisions).  Why: the network is piecewise linear, and an input
+that sits within fp32 rounding of a kink is legitimately rounded to either side by two correct fp32 programs;
+the gradients then differ by whole terms.  Measured with tools/parity_probe.py over 18 (geometry, seed) pairs:
+the fp32 CPU evaluation of the oracle deviates from its own fp64 evaluation by 2.5e-2 / 2.4e-1 on two of them and
+the device by 5e-2 .. 2e-1 on three OTHER ones, while on all remaining pairs both sit at 1e-5; which pairs are hit
+changes with the summation order.  On shared decisions the comparison is deterministic and tight: every tensor
+of every case -- including the pairs where the device took another branch than the oracle -- must agree to 5e-3
+(observed: ~1e-5), and every decision that differs must have been a tie (|pre-activation| <= 1e-4 of the tensor's
+largest value), so a wrong halo, edge index or mask would show up either as a far-from-tie decision or as a
+gradient error.  No tolerance is widened for any layer."""
 import numpy as np
 import pytest
 import torch
@@ -8,56 +20,31 @@ import torch
 pytestmark = pytest.mark.gpu
 
 from oracle import torch_ref as T
-from tests.test_engine_gpu import dropout_mask
+from tests.parity_util import assert_gradients_match, make_case, rel_err
+
+# seeds 4, 5 of 64x96 and seed 2 of 75x131 are the pairs on which the device takes another branch than the fp64 oracle
+CASES = [(64, 96, 3, 0), (64, 96, 3, 4), (64, 96, 3, 5), (100, 140, 1, 0), (100, 140, 1, 4), (75, 131, 2, 0),
+         (75, 131, 2, 2)]
 
 
-@pytest.mark.parametrize("H,W,B", [(64, 96, 3), (100, 140, 1), (75, 131, 2)])
-def test_forward_and_gradients_on_odd_geometries(H, W, B):
+@pytest.mark.parametrize("H,W,B,seed", CASES)
+def test_forward_and_gradients_on_odd_geometries(H, W, B, seed):
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
     from spnet_amd.engine import Engine
+    P, X, Y, mask, dseed = make_case(H, W, B, seed)
     eng = Engine(H, W, B, device="cuda:0", seed=H)
-    P = T.init_params(H, W, seed=W)
-    g = torch.Generator().manual_seed(B)
-    for k in P:
-        if k.endswith("/gamma"):
-            P[k] = 0.5 + torch.rand(P[k].shape, generator=g)
-        elif k.endswith("/beta") or k.endswith("/moving_mean") or k.endswith("/bias"):
-            P[k] = 0.2 * torch.randn(P[k].shape, generator=g)
-        elif k.endswith("/moving_variance"):
-            P[k] = 0.5 + torch.rand(P[k].shape, generator=g)
-    rs = np.random.RandomState(H + W)
-    X = torch.tensor(rs.rand(B, H, W, 1) * 2 - 1, dtype=torch.float32)
-    Y = torch.tensor(rs.rand(B, 576), dtype=torch.float32)
-    Y[:, 6::8] = (Y[:, 6::8] > 0.5).float()
     eng.load_state_dict(P)
     # inference forward
     want = T.forward(P, X, training=False)
     got = eng.forward(X.cuda(), training=False).cpu()
     assert float(((got - want) ** 2).mean()) <= 1e-8 * max(float((want ** 2).mean()), 1.0)
     # training forward + every parameter gradient
-    seed = 777
-    eng.set_drop_seed(seed)
-    h2, w2 = H // 2, W // 2
-    mask = torch.tensor(dropout_mask(B * h2 * w2 * 3, seed).reshape(B, h2, w2, 3))
-    tr = T.Trainer({k: v.clone() for k, v in P.items()})
-    data, total, grads, yp = tr.grads(X, Y, drop_mask=mask, include_l2=False)
+    eng.set_drop_seed(dseed)
     out = eng.forward(X.cuda(), training=True)
     loss = eng.loss(Y.cuda())
     eng.backward()
     torch.cuda.synchronize()
-    np.testing.assert_allclose(out.cpu().numpy(), yp.numpy(), rtol=2e-3, atol=2e-4 * float(yp.abs().max()))
-    np.testing.assert_allclose(float(loss[5]), data, rtol=1e-4)
-    gd = eng.grad_dict()
-    bad = {}
-    for k, gref in grads.items():
-        ref, got_g = gref.numpy(), gd[k].numpy()
-        err = float(np.abs(got_g - ref).max()) / max(float(np.abs(ref).max()), 1e-12)
-        if err > 5e-3:
-            bad[k] = err
-    # At these sizes a middle-flow BatchNorm sees only a dozen or two samples per channel, so ONE ReLU /
-    # max-pool tie that rounding decides differently on the device shows up as a few-percent error in that
-    # single layer's four tensors (tools/geom_check.py: other seeds of the same geometry are clean to 1e-5).
-    # A wrong index or a missing term would hit many layers or be of order one.
-    layers = {k.split("/")[0].replace("_bn", "") for k in bad}
-    assert len(layers) <= 1 and all(v < 0.3 for v in bad.values()), sorted(bad.items(), key=lambda kv: -kv[1])[:8]
+    data64, yp64, _, _ = assert_gradients_match(eng, P, X, Y, mask, tol=5e-3)
+    assert rel_err(out.cpu().numpy(), yp64.numpy()) <= 5e-4
+    np.testing.assert_allclose(float(loss[5]), data64, rtol=1e-4)

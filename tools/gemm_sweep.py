@@ -43,6 +43,49 @@ def main():
         print("one %s M=%d N=%d K=%d tile=%d: %.1f us %.1f TF" % (form, m, n, k, tile, us, tf))
         sys.exit(0)
 
+    if len(sys.argv) > 1 and sys.argv[1] == "blend":
+        # BatchNorm backward folded into the data-gradient GEMM vs the separate elementwise pass it replaces
+        def t(fn, iters=30):
+            for _ in range(3):
+                fn()
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(iters):
+                fn()
+            e1.record()
+            torch.cuda.synchronize()
+            return e0.elapsed_time(e1) * 1e3 / iters
+        for name, M, N, K in (("mid", 6144, 728, 728), ("b4s2", 24576, 728, 728), ("b3s2", 94752, 256, 256), ("b2s2", 372000, 128, 128),
+                              ("b14a", 1536, 1024, 1536)):
+            g, yp = torch.randn(M, K, device="cuda"), torch.randn(M, K, device="cuda")
+            wt = torch.randn(K, N, device="cuda")
+            dx, dy = torch.empty(M, N, device="cuda"), torch.empty(M, K, device="cuda")
+            cld = (K + 63) // 64 * 64
+            coef = torch.rand(3 * cld, device="cuda")
+            co = torch.rand(3 * K, device="cuda")
+            sv = torch.rand(2 * K, device="cuda")
+            part = torch.rand(64 * 2 * K, device="cuda")
+            dga, dbe = torch.empty(K, device="cuda"), torch.empty(K, device="cuda")
+            plain = t(lambda: L.spnet_gemm_f32(g.data_ptr(), 0, K, wt.data_ptr(), 1, N, dx.data_ptr(), N, M, N, K, 1, ws.data_ptr(), WS, None, 0, st()))
+            blend = t(lambda: L.spnet_gemm_f32_bnblend(g.data_ptr(), yp.data_ptr(), coef.data_ptr(), cld, K, wt.data_ptr(), N, dx.data_ptr(), N, M, N, K, 0, dy.data_ptr(), st()))
+            blend0 = t(lambda: L.spnet_gemm_f32_bnblend(g.data_ptr(), yp.data_ptr(), coef.data_ptr(), cld, K, wt.data_ptr(), N, dx.data_ptr(), N, M, N, K, 0, None, st()))
+            apply_ = t(lambda: L.spnet_bn_bwd_from_partials(yp.data_ptr(), g.data_ptr(), M, K, sv.data_ptr(), sv.data_ptr(), sv.data_ptr(), sv[K:].data_ptr(), 32, part.data_ptr(), dy.data_ptr(), dga.data_ptr(), dbe.data_ptr(), co.data_ptr(), st()))
+            fin = t(lambda: L.spnet_bn_bwd_coeffs_from_partials(32, part.data_ptr(), M, K, sv.data_ptr(), sv.data_ptr(), sv[K:].data_ptr(), dga.data_ptr(), dbe.data_ptr(), coef.data_ptr(), cld, st()))
+            print("blend %-5s M=%-6d N=%-4d K=%-4d | plain gemm %6.1f us | blend+dy_out %6.1f | blend only %6.1f | finalize+apply %6.1f | finalize only %5.1f"
+                  % (name, M, N, K, plain, blend, blend0, apply_, fin), flush=True)
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "ksweep":
+        # fixed cost vs per-K-tile cost of the middle-flow GEMM: time(K) = t0 + slope*K
+        for form in ("fwd", "dgrad", "wgrad"):
+            for tile in (6, 5):
+                res = []
+                for K in (104, 728, 1456, 2912, 5824):
+                    m, n, k = (6144, 728, K) if form != "wgrad" else (728, 728, K * 8)
+                    us, tf = run(form, m, n, k, tile, split=1, iters=30)
+                    res.append("K=%d %6.1fus %5.1fTF" % (k, us, tf))
+                print("ksweep %-5s tile %d | %s" % (form, tile, " | ".join(res)), flush=True)
+        sys.exit(0)
     shapes = [("mid", 6144, 728, 728), ("b2s1", 372000, 128, 64), ("b2s2", 372000, 128, 128), ("b1c2", 372000, 64, 288),
               ("b3s2", 94752, 256, 256), ("b4s2", 24576, 728, 728), ("b14b", 1536, 2048, 1536), ("b13r", 1536, 1024, 728)]
     for name, M, N, K in shapes:

@@ -6,8 +6,13 @@ HBM bytes per launch for the kernel families bench.py reports.
 Corrections (MI355X_MICROARCH.md, 'HBM'): counters are in KB; on gfx950 FETCH_SIZE tallies 128-byte requests as
 64 bytes, so it is doubled; WRITE_SIZE is exact for 16-B-per-lane streaming stores.
 
-usage: pmc_traffic.py <fetch_counter_collection.csv> <write_counter_collection.csv> <steps_in_trace> <out.json>"""
-import collections, csv, json, sys
+The output is stamped with bench.kernel_source_hash() of the tree the passes ran on (and, when given, the commit):
+bench.py refuses to quote the file for any other kernel/plan state.
+
+usage: pmc_traffic.py <fetch_counter_collection.csv> <write_counter_collection.csv> <steps_in_trace> <out.json> [commit]"""
+import collections, csv, json, os, sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 FAMILIES = {
     "gemm": ("gemm_f32_kernel", "reduce_slabs_kernel", "conv3x3_fwd_kernel", "conv3x3_dgrad_kernel", "conv3x3_wgrad_kernel"),
@@ -48,5 +53,8 @@ for fam in FAMILIES:
     out[fam] = {"launches": n, "launches_per_step": n / steps,
                 "hbm_bytes_per_launch": (rd + wr) / max(n, 1),
                 "hbm_read_bytes_per_step": rd / steps, "hbm_write_bytes_per_step": wr / steps}
+from bench import kernel_source_hash
+out["kernel_source_hash"] = kernel_source_hash()
+out["commit"] = sys.argv[5] if len(sys.argv) > 5 else "?"
 json.dump(out, open(sys.argv[4], "w"), indent=1)
 print(json.dumps(out, indent=1))

@@ -23,6 +23,9 @@ from predict_spnet import default_image_dir, predict_network
 def train_network(weights_file="weights.hdf5", datapath=".", fraction=1.0, batch_size=32, epochs=30, pred_grid=[6, 6, 2],
                   noaugment=False, log_dir=".", lr_max=4e-5, freeze_fac=0.7, frozen_epochs=4, random_seed=1):
     np.random.seed(random_seed)
+    # Data parallel (launched by torch.distributed.run): choose this rank's GPU and join the process group before
+    # anything touches the device; rank 0 alone logs, validates and writes checkpoints.
+    rank, _, world = multi_gpu.parallel.init_distributed()
     print("pred_grid = ", pred_grid)
     X_train, Y_train, train_file_list, pred_shape = utils.build_dataset(
         path=datapath + "/Train/", load_frac=fraction, set_means_ranges=True, batch_size=batch_size, pred_grid=pred_grid)
@@ -30,20 +33,22 @@ def train_network(weights_file="weights.hdf5", datapath=".", fraction=1.0, batch
         path=datapath + "/Val/", load_frac=1.0, set_means_ranges=False, batch_size=batch_size, pred_grid=pred_grid)
 
     print("Seting up NN model.  model_type = ", cf.model_type)
-    parallel = int(os.environ.get("WORLD_SIZE", "1")) > 1
+    parallel = world > 1
     model, serial_model = models.setup_model(X_train, Y_train[0].size, no_cp_fatal=False, weights_file=weights_file,
                                              parallel=parallel, freeze_fac=freeze_fac)
 
-    callback_list = [
-        callbacks.MyProgressCallback(X_val=X_val, Y_val=Y_val, val_file_list=val_file_list, log_dir=log_dir,
-                                     pred_shape=pred_shape),
-        callbacks.ParallelCheckpointCallback(model, filepath=weights_file, save_every=5, dir=log_dir),
-        callbacks.OneCycleScheduler(lr_max=lr_max, n_data_points=X_train.shape[0], epochs=epochs, batch_size=batch_size,
-                                    verbose=1),
-    ]
+    callback_list = []
+    if rank == 0:           # logging / validation / checkpoints: one writer
+        callback_list += [
+            callbacks.MyProgressCallback(X_val=X_val, Y_val=Y_val, val_file_list=val_file_list, log_dir=log_dir,
+                                         pred_shape=pred_shape),
+            callbacks.ParallelCheckpointCallback(model, filepath=weights_file, save_every=5, dir=log_dir)]
+    # one optimizer iteration consumes batch_size frames on EVERY rank
+    callback_list.append(callbacks.OneCycleScheduler(lr_max=lr_max, n_data_points=X_train.shape[0], epochs=epochs,
+                                                     batch_size=batch_size * world, verbose=int(rank == 0)))
     if not noaugment:
         print("Adding callback for augment on the fly")
-        callback_list.append(callbacks.AugmentOnTheFly(X_train, Y_train, aug_every=1))
+        callback_list.append(callbacks.AugmentOnTheFly(X_train, Y_train, aug_every=1, seed=random_seed))
 
     fit_args = dict(batch_size=batch_size, shuffle=True, verbose=1, validation_data=(X_val, Y_val), callbacks=callback_list)
     if frozen_epochs > 0 and freeze_fac > 0.0:        # warm-up phase with the first layers frozen
@@ -51,6 +56,14 @@ def train_network(weights_file="weights.hdf5", datapath=".", fraction=1.0, batch
     if freeze_fac > 0.0:
         model = models.unfreeze_model(model, X_train, Y_train, parallel=parallel)
     model.fit(X_train, Y_train, epochs=epochs - frozen_epochs, **fit_args)
+    if os.environ.get("SPNET_DUMP_WEIGHT_SUM"):       # test hook: one checksum of the trained weights per rank
+        import hashlib
+        h = hashlib.sha256()
+        for k, v in model.state_dict().items():
+            if "moving_" not in k:           # BatchNorm statistics are per replica (tower semantics), weights are not
+                h.update(v.numpy().tobytes())
+        with open("%s.%d" % (os.environ["SPNET_DUMP_WEIGHT_SUM"], rank), "w") as f:
+            f.write(h.hexdigest())
     return model
 
 
@@ -113,3 +126,6 @@ if __name__ == '__main__':
             if os.path.exists(f):
                 shutil.copy(f, log_dir)
         print("SPNet execution completed.")
+    import torch.distributed as dist
+    if dist.is_initialized():
+        dist.destroy_process_group()
