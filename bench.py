@@ -246,6 +246,8 @@ def main():
     ap.add_argument("--pool", type=int, default=4096,
                     help="synthetic frames resident per GPU (SURVEY 8d: >= 4,096; 3.2 GB of fp32 frames, far beyond "
                          "the 256 MiB Infinity Cache)")
+    ap.add_argument("--pool-source", choices=["device", "host"], default="device",
+                    help="device: frames rasterised in HBM by csrc/espi.hip (SURVEY 8f-2); host: the PIL generator")
     ap.add_argument("--sustained-seconds", type=float, default=6.0,
                     help="after the timed region keep stepping for this long and report the rate separately "
                          "(clocks under sustained load); 0 = skip")
@@ -281,15 +283,20 @@ def main():
     if world != args.gpus:
         raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, world))
     t_gen = time.perf_counter()
-    X_u8, labels = F.generate(args.pool, seed=1 + rank, workers=max(2, min(16, (os.cpu_count() or 8) // world)))
+    n_host = args.pool if args.pool_source == "host" else 64      # host frames: the whole pool, or the CPU baseline's sample
+    X_u8, labels = F.generate(n_host, seed=1 + rank, workers=max(2, min(16, (os.cpu_count() or 8) // world)))
     Y_host = labels_to_Y(labels)
-    t_gen = time.perf_counter() - t_gen
     rank, local_rank, world = parallel.init_distributed()
     dev = parallel.local_device()                  # (>1 rank per GPU only in gloo rehearsals)
     torch.cuda.set_device(dev)
     # ---- resident in HBM before timing
-    X_pool = torch.from_numpy(F.to_network_input(X_u8)).to(dev)
-    Y_pool = torch.from_numpy(Y_host).to(dev)
+    if args.pool_source == "device":
+        X_pool, labels = F.generate_device(args.pool, seed=1 + rank, device=str(dev))
+        Y_pool = torch.from_numpy(labels_to_Y(labels)).to(dev)
+    t_gen = time.perf_counter() - t_gen
+    if args.pool_source == "host":
+        X_pool = torch.from_numpy(F.to_network_input(X_u8)).to(dev)
+        Y_pool = torch.from_numpy(Y_host).to(dev)
     np.random.seed(1 + rank)
 
     eng = Engine(H, W, BATCH, device=str(dev), seed=0, rank=rank)
@@ -396,7 +403,7 @@ def main():
                        "wgrad_overlap": not args.no_overlap,
                        "host_enqueue_ms_per_step_backpressured": round(1e3 * t_host / args.steps, 3),
                        "host_enqueue_ms_per_step_gpu_idle": round(1e3 * t_host_idle, 3),
-                       "pool_generation_s": round(t_gen, 1)},
+                       "pool_source": args.pool_source, "pool_generation_s": round(t_gen, 1)},
         }
         if sustained is not None:
             result["sustained"] = sustained

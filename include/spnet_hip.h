@@ -23,7 +23,7 @@ extern "C" {
 
 /* ---- dense contractions (MFMA fp32) ---------------------------------------------------------- */
 /* C[M,N] = sum_k A(m,k) B(k,n) (+ bias[n]).  Replaces the pointwise half of SeparableConv2D, the
- * 1x1/stride-2 residual Conv2D, block1_conv2 (after spnet_im2col3x3) and Dense('FinalOutput')
+ * 1x1/stride-2 residual Conv2D and Dense('FinalOutput')
  * (spnet/models.py:357-359, 388), forward, data-gradient and weight-gradient forms.
  * a_major / b_major: 0 = reduction index contiguous (A[m*lda+k], B[n*ldb+k]),
  *                    1 = output index contiguous    (A[k*lda+m], B[k*ldb+n]).
@@ -55,10 +55,7 @@ int spnet_gemm_f32_batched(const float* A0, const float* B0, float* C0, const lo
 int spnet_gemm_f32_bnblend(const float* g, const float* yp, const float* coef, int cld, int lda, const float* B,
                            int ldb, float* C, int ldc, int M, int N, int K, int tile, float* dy_out, void* stream);
 
-/* 3x3 VALID stride-1 patch matrix and its adjoint (block1_conv2 of keras Xception). */
-int spnet_im2col3x3(const float* x, float* col, int B, int H, int W, int C, void* stream);
-int spnet_col2im3x3(const float* dcol, float* dx, int B, int H, int W, int C, void* stream);
-/* The same layer as implicit GEMMs that gather their operand tiles from the NHWC tensors (no patch matrix):
+/* block1_conv2 of keras Xception (3x3 VALID stride 1) as implicit GEMMs that gather their operand tiles from the NHWC tensors (no patch matrix):
  * x [B][H][W][cin], w / dw HWIO [3][3][cin][cout], y / dy [B][H-2][W-2][cout].  (cin, cout) = (32, 64).
  * wgrad splits the pixels over workgroups: workspace >= spnet_conv3x3_wgrad_ws() floats. */
 int spnet_conv3x3_fwd(const float* x, const float* w, float* y, int B, int H, int W, int cin, int cout,
@@ -69,9 +66,9 @@ long spnet_conv3x3_wgrad_ws(int B, int H, int W, int cin, int cout);
 int spnet_conv3x3_wgrad(const float* x, const float* dy, float* dw, int B, int H, int W, int cin, int cout,
                         float* workspace, long ws_floats, void* stream);
 /* njobs matrix transposes in one launch: dst_j[c][r] = src_j[r][c]; jobs: DEVICE array of {src, dst, R, C}
- * (four 64-bit words per job).  The engine keeps W^T of every pointwise kernel (refreshed once per optimizer
- * step), so the data-gradient product dX = dY W^T of keras SeparableConv2D / Conv2D(1x1) runs in the
- * forward operand form (call site spnet/models.py:357-359). */
+ * (four 64-bit words per job).  The engine keeps W^T of the pointwise kernels whose data-gradient product
+ * dX = dY W^T (keras SeparableConv2D / Conv2D(1x1), call site spnet/models.py:357-359) runs through
+ * spnet_gemm_f32_bnblend, which takes B in the forward (output-major) form; refreshed once per optimizer step. */
 int spnet_transpose_batched(const void* jobs, int njobs, int max_rows, int max_cols, void* stream);
 /* out[M][ldc] = sum over nslab slabs of M*N floats, in slab order (the second stage of every K split). */
 int spnet_reduce_slabs(const float* ws, int nslab, int M, int N, float* out, int ldc, void* stream);
@@ -79,21 +76,19 @@ int spnet_reduce_slabs(const float* ws, int nslab, int M, int N, float* out, int
 int spnet_gather_s2(const float* x, float* xs, int B, int H, int W, int C, void* stream);
 int spnet_scatter_add_s2(const float* dxs, float* dx, int B, int H, int W, int C, void* stream);
 
-/* ---- depthwise 3x3 / stride 1 / SAME (34 per forward; keras SeparableConv2D depthwise step) ---- */
-/* w is [3][3][C].  relu_in applies the preceding Activation('relu') on load. */
-int spnet_dwconv3x3_fwd(const float* x, const float* w, float* y, int B, int H, int W, int C,
-                        int relu_in, void* stream);
-/* dx = dw3x3(dy, flip w) * (x_fwd > 0 if relu_in) (+ add, e.g. the residual branch's gradient) */
-int spnet_dwconv3x3_bwd_data(const float* dy, const float* w, float* dx, int B, int H, int W, int C,
-                             int relu_in, const float* x_fwd, const float* add, void* stream);
-long spnet_dwconv3x3_bwd_weight_ws(int B, int H, int W, int C);
-int spnet_dwconv3x3_bwd_weight(const float* x, const float* dy, float* dw, int B, int H, int W, int C,
-                               int relu_in, float* workspace, void* stream);
+/* ---- depthwise 3x3 / SAME (34 stride-1 layers per Xception forward: keras SeparableConv2D depthwise step;
+ *      MobileNet's DepthwiseConv2D, stride 1 | 2).  w is [3][3][C]. ---- */
 int spnet_reduce_rows(const float* in, int P, int L, float* out, void* stream);
 /* njobs independent row reductions in one launch; jobs: DEVICE array of {in, out, P, L} (four 64-bit words
  * per job), max_L = largest L.  (All depthwise weight gradients of a step: spnet_dwconv3x3_tiled_bwd with
  * dw == NULL leaves its partial sums in the workspace.) */
 int spnet_reduce_rows_batched(const void* jobs, int njobs, int max_L, void* stream);
+/* Strided depthwise 3x3 / TF-SAME (keras.applications.mobilenet DepthwiseConv2D, strides 1 or 2; spnet/models.py:346-355).
+ * op 0: out = y [B][ceil(H/s)][ceil(W/s)][C] from a = x, b = w;  op 1: out = dx [B][H][W][C] from a = dy, b = w;
+ * op 2: out = dw [3][3][C] from a = x, b = dy (workspace: spnet_dwconv3x3_strided_ws floats).  H, W: input extent. */
+long spnet_dwconv3x3_strided_ws(int B, int H, int W, int C, int stride);
+int spnet_dwconv3x3_strided(int op, const float* a, const float* b, float* out, int B, int H, int W, int C, int stride,
+                            float* workspace, void* stream);
 /* LDS-tiled forms used by the engine: forward, and the FUSED backward (data + weight gradient in one
  * pass over x and dy).  workspace: spnet_dwconv3x3_tiled_bwd_ws(B,H,W,C) floats. */
 int spnet_dwconv3x3_tiled_fwd(const float* x, const float* w, float* y, int B, int H, int W, int C,
@@ -110,7 +105,7 @@ int spnet_dwconv3x3_tiled_bwd(const float* dy, const float* x_fwd, const float* 
                               const float* bn_invstd, float* bn_partial, const float* bn_x, void* stream);
 
 /* ---- BatchNormalization(axis=-1, momentum .99, eps 1e-3) (spnet/models.py:326-336 + 40 in Xception) --- */
-/* act: 0 none, 1 ReLU, 2 LeakyReLU(0.1) fused behind the affine; residual (or NULL) added last;
+/* act: 0 none, 1 ReLU, 2 LeakyReLU(0.1), 3 ReLU6 (MobileNet) fused behind the affine; residual (or NULL) added last;
  * res_bcast=1 (C<=4 only): residual holds one value per pixel, broadcast over the channels (the
  * stem's skip connection from the 1-channel input, spnet/models.py:337). */
 long spnet_bn_ws(long M, int C);
@@ -169,6 +164,10 @@ int spnet_conv3x3_small(int op, int cin, int cout, int stride, int same, const f
  * (center,size,angle,noobj,class,total); parts = B*5 floats scratch; grad may be NULL. */
 int spnet_ellipse_loss(const float* y_true, const float* y_pred, float* grad, float* parts,
                        float* loss_out, int B, int ncols, int hybrid, void* stream);
+/* SelectiveSigmoid (spnet/models.py:277-298) / the sigmoid columns of the 'compound' head (models.py:379-386,
+ * after InterleaveColumns the sigmoid outputs sit at columns start::step).  backward == 0: y[:, start::step] =
+ * sigmoid(.) in place; backward == 1: grad[:, start::step] *= y (1 - y), y being the post-sigmoid output. */
+int spnet_selective_sigmoid(float* y, float* grad, int B, int ncols, int start, int step, int backward, void* stream);
 /* denorm_Y + cleanup_antinode_vars angle (spnet/utils.py:186-188,56-64; evaluate_spnet.py:70-73):
  * out[B][ncols/8][7] = (cx,cy,a,b,angle_deg,noobj,rings). */
 int spnet_decode(const float* y_norm, const float* means, const float* ranges, float* out, int B,
@@ -178,6 +177,11 @@ int spnet_decode(const float* y_norm, const float* means, const float* ranges, f
 /* Raster IoU of npairs (predicted, true) ellipse rows [npairs][8] (denormalised cx,cy,a,b,cos2t,sin2t,noobj,
  * rings) on an nx x ny canvas; iou[i] = -1 where the true slot is empty or both rasters are. */
 int spnet_ellipse_iou(const float* yp, const float* yt, long npairs, int nx, int ny, double* iou, void* stream);
+
+/* Count metrics (spnet/diagnostics.py:13-59: calc_errors) over [N][ncols] de-normalised grids: counts[7] (int, zeroed
+ * by the caller) = ring_miscounts, ring_truecounts, total_obj, false_obj_pos, false_obj_neg, true_obj_pos,
+ * true_obj_neg; pix_err[N] = centre error of each row's first predictor. */
+int spnet_calc_errors(const float* yp, const float* yt, long N, int ncols, int* counts, float* pix_err, void* stream);
 
 /* ---- optimizer ---------------------------------------------------------------------------------- */
 /* Keras Adam + l2 on the first l2_n elements (spnet/models.py:494, 47-71).  sq_scratch >= 2048 floats.
@@ -194,11 +198,23 @@ int spnet_cutout(const float* src, const int* src_index, float* dst, int N, int 
                  const int* rects, const float* vals, const int* nrect, void* stream);
 int spnet_saltpepper(float* x, int N, int H, int W, const int* coords, int n_salt, int n_pepper,
                      const int* flag, const float* mm, void* stream);
+/* cv2.GaussianBlur(img, (k,k), 0), k = ksize[n] in {0 = copy, 3, 5, 7} per frame (fixed small-kernel table, reflect-101
+ * borders): what blur_inplace (spnet/augmentation.py:66-70) computes and then discards.  dst != src. */
+int spnet_gaussian_blur(const float* src, float* dst, int N, int H, int W, const int* ksize, void* stream);
 int spnet_warp_affine(const float* src, float* dst, int N, int H, int W, int C, const float* minv,
                       void* stream);
 /* Dropout(0.1) of the stem (spnet/models.py:340); same call with dy regenerates the mask in backward. */
 int spnet_dropout(const float* x, float* y, long n, unsigned seed, float rate, const unsigned* seed_dev,
                   void* stream);   /* seed_dev (or NULL): device uint32 overriding seed (hipGraph replay) */
+
+/* ---- synthetic input (gen_fake_espi.py:60-279 without the band-pass mix-up) -------------------------------- */
+/* Rasterises N fake-ESPI frames in device memory from host-drawn parameters: waves [N][5] = amp, wavelength,
+ * thickness, slope, spacing (draw_waves :60-80); nodes [N][7][8] = cx, cy, a, b, angle_deg, rings, start, valid
+ * (draw_antinodes :145-206, draw_rings :101-114); nnode [N].  noise != 0 adds the clipped N(40,40) noise and the
+ * 50 % pixel dropout (gen_images :255-263).  out_f (or NULL): [N][H][W] network input in [-1,1]; out_u8 (or NULL):
+ * the uint8 frame. */
+int spnet_fake_espi(const float* waves, const float* nodes, const int* nnode, int N, int H, int W, unsigned seed,
+                    int noise, float* out_f, unsigned char* out_u8, void* stream);
 
 #ifdef __cplusplus
 }

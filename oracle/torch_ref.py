@@ -50,11 +50,19 @@ def conv2d(x, w_hwio, stride=1, padding="valid"):
     return _nhwc(F.conv2d(xc, w_hwio.permute(3, 2, 0, 1), stride=stride))
 
 
-def dwconv3x3(x, w_33c):
-    """Depthwise 3x3, stride 1, SAME, no bias (tf.nn.depthwise_conv2d inside SeparableConv2D)."""
+def dwconv3x3(x, w_33c, stride=1):
+    """Depthwise 3x3, SAME, no bias (tf.nn.depthwise_conv2d inside SeparableConv2D / MobileNet's DepthwiseConv2D);
+    stride 2 pads the TF way (extra row / column at the bottom / right)."""
     C = x.shape[3]
     w = w_33c.permute(2, 0, 1).reshape(C, 1, 3, 3)
-    return _nhwc(F.conv2d(_nchw(x), w, padding=1, groups=C))
+    if stride == 1:
+        return _nhwc(F.conv2d(_nchw(x), w, padding=1, groups=C))
+    H, W = x.shape[1], x.shape[2]
+    oh, ow = -(-H // stride), -(-W // stride)
+    ph = max((oh - 1) * stride + 3 - H, 0)
+    pw = max((ow - 1) * stride + 3 - W, 0)
+    xc = F.pad(_nchw(x), (pw // 2, pw - pw // 2, ph // 2, ph - ph // 2))
+    return _nhwc(F.conv2d(xc, w, stride=stride, groups=C))
 
 
 def pwconv(x, w_io):
@@ -103,6 +111,21 @@ class Decisions:
             self.flips.append(("relu%d" % (self._ri - 1), n, float(x.detach()[diff].abs().max() / x.detach().abs().max())))
         return torch.where(m, x, slope * x)
 
+    def act6(self, x):
+        """ReLU6 (two kinks): the recorded decision is a byte per element, 0 = clipped to 0, 1 = linear, 2 = clipped to 6."""
+        own = (x > 0).to(torch.uint8) + (x >= 6).to(torch.uint8)
+        if not self.force:
+            self.relu.append(own.detach())
+            return torch.clamp(x, 0.0, 6.0)
+        m = self.relu[self._ri].to(x.device)
+        self._ri += 1
+        diff = m != own
+        n = int(diff.sum())
+        if n:
+            xd = x.detach()[diff]
+            self.flips.append(("relu6_%d" % (self._ri - 1), n, float(torch.minimum(xd.abs(), (xd - 6).abs()).max() / x.detach().abs().max())))
+        return torch.where(m == 1, x, torch.where(m == 2, torch.full_like(x, 6.0), torch.zeros_like(x)))
+
     def pool_taps(self, cols):
         """cols [B,C,9,OH,OW] window entries (-inf padding) -> taps [B,C,1,OH,OW] to gather."""
         own = cols.detach().argmax(2, keepdim=True)
@@ -123,6 +146,10 @@ def _act(x, slope, decisions):
     if decisions is None:
         return F.leaky_relu(x, slope) if slope else F.relu(x)
     return decisions.act(x, slope)
+
+
+def _act6(x, decisions):
+    return torch.clamp(x, 0.0, 6.0) if decisions is None else decisions.act6(x)
 
 
 def maxpool3x3s2_same_decided(x, decisions):
@@ -190,6 +217,19 @@ def xception_layers():
     return L
 
 
+MOBILENET_BLOCKS = [(64, 1), (128, 2), (128, 1), (256, 2), (256, 1), (512, 2), (512, 1), (512, 1), (512, 1), (512, 1),
+                    (512, 1), (1024, 2), (1024, 1)]       # (pointwise filters, depthwise stride) of conv_dw/pw_1..13
+
+
+def mobilenet_out_hw(H, W):
+    h, w = H // 2, W // 2                      # stem avgpool
+    h, w = -(-h // 2), -(-w // 2)              # conv1 3x3/s2 SAME
+    for _, s_ in MOBILENET_BLOCKS:
+        if s_ == 2:
+            h, w = -(-h // 2), -(-w // 2)
+    return h, w
+
+
 def backbone_out_hw(H, W):
     h, w = H // 2, W // 2                      # stem avgpool
     h, w = (h - 3) // 2 + 1, (w - 3) // 2 + 1  # block1_conv1 3x3/s2 valid
@@ -204,9 +244,11 @@ def _glorot(shape, fan_in, fan_out, gen, dtype):
     return ((torch.rand(shape, generator=gen, dtype=torch.float64) * 2 - 1) * lim).to(dtype)
 
 
-def init_params(H, W, n_out=576, seed=0, dtype=torch.float32):
+def init_params(H, W, n_out=576, seed=0, dtype=torch.float32, basemodel="Xception"):
     """Keras default initialisers: glorot_uniform kernels, zero bias, BN gamma 1 / beta 0 /
-    moving_mean 0 / moving_variance 1.  Returns OrderedDict name -> tensor (Keras weight names)."""
+    moving_mean 0 / moving_variance 1.  Returns OrderedDict name -> tensor (Keras weight names).
+    basemodel 'MobileNet': keras.applications.mobilenet.MobileNet(alpha=1, include_top=False) (spnet/models.py:346-355;
+    random initialisation -- the reference's imagenet download is not available)."""
     g = torch.Generator().manual_seed(seed)
     P = OrderedDict()
 
@@ -225,6 +267,21 @@ def init_params(H, W, n_out=576, seed=0, dtype=torch.float32):
     bn("batch_normalization_2", 3)
     conv("conv2d_3", 3, 3, 3)
     bn("batch_normalization_3", 3)
+    if basemodel == "MobileNet":
+        conv("conv1", 3, 3, 32)
+        bn("conv1_bn", 32)
+        cin = 32
+        for i, (cout, _) in enumerate(MOBILENET_BLOCKS, 1):
+            P["conv_dw_%d/depthwise_kernel" % i] = _glorot((3, 3, cin), cin * 9, 9, g, dtype)
+            bn("conv_dw_%d_bn" % i, cin)
+            P["conv_pw_%d/kernel" % i] = _glorot((1, 1, cin, cout), cin, cout, g, dtype)
+            bn("conv_pw_%d_bn" % i, cout)
+            cin = cout
+        h, w = mobilenet_out_hw(H, W)
+        nin = h * w * cin
+        P["FinalOutput/kernel"] = _glorot((nin, n_out), nin, n_out, g, dtype)
+        P["FinalOutput/bias"] = torch.zeros(n_out, dtype=dtype)
+        return P
     for lay in xception_layers():
         kind = lay[0]
         if kind == "conv":
@@ -247,6 +304,10 @@ def init_params(H, W, n_out=576, seed=0, dtype=torch.float32):
 
 L2_KERNELS = ("conv2d_1", "conv2d_2", "conv2d_3", "block1_conv1", "block1_conv2",
               "conv2d_4", "conv2d_5", "conv2d_6", "conv2d_7", "FinalOutput")
+# MobileNet: every layer that still carries a kernel_regularizer after add_regularization's JSON round trip
+# (Conv2D / Dense; DepthwiseConv2D serialises a depthwise_regularizer instead and loses it, like SeparableConv2D)
+L2_KERNELS_MOBILENET = ("conv2d_1", "conv2d_2", "conv2d_3", "conv1") + tuple("conv_pw_%d" % i for i in range(1, 14)) + \
+    ("FinalOutput",)
 
 
 def is_trainable(name):
@@ -311,12 +372,36 @@ def backbone(P, x, training, taps=None, decisions=None):
     return x
 
 
-def forward(P, X, training=False, drop_mask=None, taps=None, decisions=None):
-    """X [B,H,W,1] -> [B,n_out] in normalised units (linear Dense output).  decisions: see Decisions."""
+def backbone_mobilenet(P, x, training, taps=None, decisions=None):
+    """keras.applications.mobilenet.MobileNet(alpha=1, depth_multiplier=1, include_top=False): conv1 3x3/s2 SAME + BN +
+    relu6, then 13 x [depthwise 3x3 (stride 1|2, SAME) + BN + relu6 + pointwise 1x1 + BN + relu6]."""
+    def bn(n, t):
+        t = batchnorm(t, P[n + "/gamma"], P[n + "/beta"], P[n + "/moving_mean"], P[n + "/moving_variance"], training)
+        if taps is not None:
+            taps[n] = t
+        return t
+    x = _act6(bn("conv1_bn", conv2d(x, P["conv1/kernel"], 2, "same")), decisions)
+    for i, (cout, s_) in enumerate(MOBILENET_BLOCKS, 1):
+        x = _act6(bn("conv_dw_%d_bn" % i, dwconv3x3(x, P["conv_dw_%d/depthwise_kernel" % i], s_)), decisions)
+        x = _act6(bn("conv_pw_%d_bn" % i, pwconv(x, P["conv_pw_%d/kernel" % i][0, 0])), decisions)
+    if taps is not None:
+        taps["backbone"] = x
+    return x
+
+
+def forward(P, X, training=False, drop_mask=None, taps=None, decisions=None, sigmoid_cols=None):
+    """X [B,H,W,1] -> [B,n_out] in normalised units (linear Dense output).  decisions: see Decisions.
+    sigmoid_cols=(start, step): the 'compound' head (spnet/models.py:379-386) -- Dense(n_preds, sigmoid) and
+    Dense(rest) re-ordered by InterleaveColumns == one dense layer whose columns start::step pass through a sigmoid."""
     x = stem(P, X, training, drop_mask, taps, decisions)
-    x = backbone(P, x, training, taps, decisions)
+    x = (backbone_mobilenet if "conv1/kernel" in P else backbone)(P, x, training, taps, decisions)
     flat = x.reshape(x.shape[0], -1)          # NHWC flatten order (Keras Flatten on channels_last)
-    return flat @ P["FinalOutput/kernel"] + P["FinalOutput/bias"]
+    y = flat @ P["FinalOutput/kernel"] + P["FinalOutput/bias"]
+    if sigmoid_cols is not None:
+        cols = torch.zeros(y.shape[1], dtype=torch.bool)
+        cols[sigmoid_cols[0]::sigmoid_cols[1]] = True
+        y = torch.where(cols, torch.sigmoid(y), y)
+    return y
 
 
 # ------------------------------------------------------------------ loss / optimiser
@@ -338,15 +423,17 @@ def custom_loss(y_true, y_pred, loss_type="same"):
 
 
 def l2_penalty(P):
-    return sum(L2 * (P[n + "/kernel"] ** 2).sum() for n in L2_KERNELS)
+    names = L2_KERNELS_MOBILENET if "conv1/kernel" in P else L2_KERNELS
+    return sum(L2 * (P[n + "/kernel"] ** 2).sum() for n in names)
 
 
 class Trainer:
     """Keras-style training loop state: params, Adam moments, iteration counter."""
 
-    def __init__(self, P, loss_type="same", eps=1e-7):
+    def __init__(self, P, loss_type="same", eps=1e-7, sigmoid_cols=None):
         self.P = P
         self.loss_type = loss_type
+        self.sigmoid_cols = sigmoid_cols
         self.eps = eps
         self.t = 0
         self.names = [k for k in P if is_trainable(k)]
@@ -359,7 +446,7 @@ class Trainer:
         its optimizer kernel)."""
         leaves = {k: self.P[k].detach().clone().requires_grad_(True) for k in self.names}
         Pg = OrderedDict((k, leaves.get(k, self.P[k])) for k in self.P)
-        yp = forward(Pg, X, training=True, drop_mask=drop_mask, decisions=decisions)
+        yp = forward(Pg, X, training=True, drop_mask=drop_mask, decisions=decisions, sigmoid_cols=self.sigmoid_cols)
         data = custom_loss(Y, yp, self.loss_type)
         total = data + l2_penalty(Pg)
         gs = torch.autograd.grad(total if include_l2 else data, [leaves[k] for k in self.names])

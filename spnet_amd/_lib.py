@@ -26,8 +26,6 @@ P = c_void_p  # device pointers travel as integers
 
 _SIGS = {
     "spnet_gemm_f32": (c_int, [P, c_int, c_int, P, c_int, c_int, P, c_int, c_int, c_int, c_int, c_int, P, c_long, P, c_int, P]),
-    "spnet_im2col3x3": (c_int, [P, P, c_int, c_int, c_int, c_int, P]),
-    "spnet_col2im3x3": (c_int, [P, P, c_int, c_int, c_int, c_int, P]),
     "spnet_conv3x3_fwd": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, P]),
     "spnet_conv3x3_dgrad": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, P]),
     "spnet_conv3x3_wgrad_ws": (c_long, [c_int, c_int, c_int, c_int, c_int]),
@@ -36,10 +34,8 @@ _SIGS = {
     "spnet_transpose_batched": (c_int, [P, c_int, c_int, c_int, P]),
     "spnet_gather_s2": (c_int, [P, P, c_int, c_int, c_int, c_int, P]),
     "spnet_scatter_add_s2": (c_int, [P, P, c_int, c_int, c_int, c_int, P]),
-    "spnet_dwconv3x3_fwd": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, P]),
-    "spnet_dwconv3x3_bwd_data": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, P, P, P]),
-    "spnet_dwconv3x3_bwd_weight_ws": (c_long, [c_int, c_int, c_int, c_int]),
-    "spnet_dwconv3x3_bwd_weight": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, P, P]),
+    "spnet_dwconv3x3_strided_ws": (c_long, [c_int, c_int, c_int, c_int, c_int]),
+    "spnet_dwconv3x3_strided": (c_int, [c_int, P, P, P, c_int, c_int, c_int, c_int, c_int, P, P]),
     "spnet_reduce_rows": (c_int, [P, c_int, c_int, P, P]),
     "spnet_reduce_rows_batched": (c_int, [P, c_int, c_int, P]),
     "spnet_dwconv3x3_tiled_fwd": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, P, P, P]),
@@ -65,13 +61,17 @@ _SIGS = {
     "spnet_avgpool2_bwd": (c_int, [P, P, c_int, c_int, c_int, c_int, P]),
     "spnet_conv3x3_small": (c_int, [c_int, c_int, c_int, c_int, c_int, P, P, P, c_int, c_int, c_int, P, c_long, P]),
     "spnet_ellipse_loss": (c_int, [P, P, P, P, P, c_int, c_int, c_int, P]),
+    "spnet_selective_sigmoid": (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, P]),
     "spnet_decode": (c_int, [P, P, P, P, c_int, c_int, c_int, P]),
     "spnet_ellipse_iou": (c_int, [P, P, c_long, c_int, c_int, P, P]),
+    "spnet_calc_errors": (c_int, [P, P, c_long, c_int, P, P, P]),
     "spnet_adam_step": (c_int, [P, P, P, P, c_long, c_long, c_float, c_float, c_float, c_float, c_float, c_float, P, P, P, P, P]),
     "spnet_minmax": (c_int, [P, c_int, c_long, P, P, P]),
     "spnet_cutout": (c_int, [P, P, P, c_int, c_int, c_int, P, P, P, P]),
     "spnet_saltpepper": (c_int, [P, c_int, c_int, c_int, P, c_int, c_int, P, P, P]),
+    "spnet_gaussian_blur": (c_int, [P, P, c_int, c_int, c_int, P, P]),
     "spnet_warp_affine": (c_int, [P, P, c_int, c_int, c_int, c_int, P, P]),
+    "spnet_fake_espi": (c_int, [P, P, P, c_int, c_int, c_int, c_uint, c_int, P, P, P]),
     "spnet_dropout": (c_int, [P, P, c_long, c_uint, c_float, P, P]),
 }
 

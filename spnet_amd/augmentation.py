@@ -82,7 +82,9 @@ class DeviceAugmenter:
         self.X = X_orig.contiguous()
         self.N, self.H, self.W = X_orig.shape[0], X_orig.shape[1], X_orig.shape[2]
         self.shape = (self.H, self.W, 1)
-        self.real_blur = real_blur          # reserved: default reproduces the reference's no-op blur
+        # False (default): the reference's blur, whose cv2.GaussianBlur result is discarded (augmentation.py:66-70:
+        # RNG consumed, pixels untouched).  True: apply the blur that call computes (csrc/augment.hip).
+        self.real_blur = real_blur
         mm = torch.empty(self.N, 2, device=self.X.device)
         scratch = torch.empty(self.N * 32, device=self.X.device)
         L.spnet_minmax(self.X.data_ptr(), self.N, self.H * self.W, mm.data_ptr(), scratch.data_ptr(), _stream())
@@ -101,6 +103,7 @@ class DeviceAugmenter:
         nrect = np.zeros(B, np.int32)
         coords = np.zeros((B, 2, npts), np.int32)
         flag = np.zeros(B, np.int32)
+        ksize = np.zeros(B, np.int32)
         for j, i in enumerate(indices):
             if seeds is not None:
                 np.random.seed(int(seeds[j]))
@@ -116,8 +119,9 @@ class DeviceAugmenter:
                 flag[j] = 1
                 coords[j, 0, :self.n_salt], coords[j, 1, :self.n_salt] = sp[0], sp[1]
                 coords[j, 0, self.n_salt:], coords[j, 1, self.n_salt:] = sp[2], sp[3]
-            draw_blur_gate()
-        return dict(index=np.asarray(indices, np.int32), rects=rects, vals=vals, nrect=nrect, coords=coords, flag=flag)
+            ksize[j] = draw_blur_gate()
+        return dict(index=np.asarray(indices, np.int32), rects=rects, vals=vals, nrect=nrect, coords=coords, flag=flag,
+                    ksize=ksize)
 
     def apply(self, params, out):
         """out[j] = augmented copy of frame params['index'][j]; out is a device tensor [B,H,W,1]."""
@@ -134,6 +138,10 @@ class DeviceAugmenter:
         L.spnet_minmax(out.data_ptr(), B, self.H * self.W, mm.data_ptr(), mm[2 * B:].data_ptr(), _stream())
         L.spnet_saltpepper(out.data_ptr(), B, self.H, self.W, up["coords"].data_ptr(), self.n_salt, self.n_pepper,
                            up["flag"].data_ptr(), mm.data_ptr(), _stream())
+        if self.real_blur and params["ksize"].any():
+            tmp = torch.empty_like(out)
+            L.spnet_gaussian_blur(out.data_ptr(), tmp.data_ptr(), B, self.H, self.W, up["ksize"].data_ptr(), _stream())
+            out.copy_(tmp)
         return out
 
     def augment(self, indices, out):

@@ -91,7 +91,9 @@ class AugmentOnTheFly(Callback):
     tensor) or already a device tensor.  The augmented set is a second device tensor that the model's
     fit() reads batches from (`model.set_train_frames`)."""
 
-    def __init__(self, X, Y, orig_img_shape=(384, 512), aug_every=1, chunk=256, seed=1):
+    def __init__(self, X, Y, orig_img_shape=(384, 512), aug_every=1, chunk=256, seed=1, real_blur=False):
+        """real_blur=False reproduces the reference, whose Gaussian blur is a no-op (the result of cv2.GaussianBlur is
+        discarded, augmentation.py:66-70); True applies it (train_spnet.py --augment_blur)."""
         super().__init__()
         import torch
         from . import parallel
@@ -105,7 +107,7 @@ class AugmentOnTheFly(Callback):
         dev = parallel.local_device()
         self.X_orig = X if isinstance(X, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(X)).to(dev)
         self.X_aug = torch.empty_like(self.X_orig)
-        self.augmenter = DeviceAugmenter(self.X_orig)
+        self.augmenter = DeviceAugmenter(self.X_orig, real_blur=real_blur)
 
     def set_model(self, model):
         super().set_model(model)

@@ -193,3 +193,49 @@ extern "C" int spnet_dropout(const float* x, float* y, long n, unsigned seed, fl
                      y, n, seed, thresh, 1.0f / (1.0f - rate), seed_dev);
   SPNET_RETURN_LAUNCH_STATUS();
 }
+
+// ---------------------------------------------------------------- Gaussian blur (the reference's intended augmentation)
+// blur_inplace (spnet/augmentation.py:66-70) calls cv2.GaussianBlur(img, (k,k), 0) with k in {3,7} and DISCARDS the
+// result, so the reference's blur is a no-op (the default here too); this kernel is what that call computes, for runs
+// that want the augmentation the author meant (DeviceAugmenter(real_blur=True)).  OpenCV semantics: sigma = 0 with
+// k <= 7 selects the fixed binomial-like kernels below (getGaussianKernel's small_gaussian_tab), borders are
+// BORDER_REFLECT_101, arithmetic in float.  ksize[n] in {0 (copy), 3, 5, 7} per frame.
+__constant__ float kGauss[4][7] = {{1.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f},
+                                   {0.25f, 0.5f, 0.25f, 0.f, 0.f, 0.f, 0.f},
+                                   {0.0625f, 0.25f, 0.375f, 0.25f, 0.0625f, 0.f, 0.f},
+                                   {0.03125f, 0.109375f, 0.21875f, 0.28125f, 0.21875f, 0.109375f, 0.03125f}};
+
+__device__ __forceinline__ int reflect101(int i, int n) {
+  if (i < 0) i = -i;
+  if (i >= n) i = 2 * n - 2 - i;
+  return min(max(i, 0), n - 1);
+}
+
+__global__ __launch_bounds__(256) void gaussian_blur_kernel(const float* __restrict__ src, float* __restrict__ dst,
+                                                            int H, int W, const int* __restrict__ ksize) {
+  const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y, n = blockIdx.z;
+  if (x >= W) return;
+  const long base = (long)n * H * W;
+  const int k = ksize[n];
+  if (k <= 1) {
+    dst[base + (long)y * W + x] = src[base + (long)y * W + x];
+    return;
+  }
+  const int r = k >> 1;
+  const float* kw = kGauss[r];
+  float acc = 0.f;
+  for (int i = -r; i <= r; ++i) {        // columns first within a row (cv2: row filter, then column filter)
+    const float* row = src + base + (long)reflect101(y + i, H) * W;
+    float s = 0.f;
+    for (int j = -r; j <= r; ++j) s = fmaf(kw[j + r], row[reflect101(x + j, W)], s);
+    acc = fmaf(kw[i + r], s, acc);
+  }
+  dst[base + (long)y * W + x] = acc;
+}
+
+extern "C" int spnet_gaussian_blur(const float* src, float* dst, int N, int H, int W, const int* ksize, void* stream) {
+  if (N < 1 || H < 4 || W < 4 || !src || !dst || src == dst || !ksize) return (int)hipErrorInvalidValue;
+  hipLaunchKernelGGL(gaussian_blur_kernel, dim3((W + 255) / 256, H, N), dim3(256), 0, (hipStream_t)stream, src, dst, H, W,
+                     ksize);
+  SPNET_RETURN_LAUNCH_STATUS();
+}

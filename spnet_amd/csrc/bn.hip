@@ -6,7 +6,7 @@
 // All reductions are two-stage and deterministic: per-workgroup partial sums, then a finalize kernel
 // that combines them in a fixed order in double precision.
 //
-// Activation fused behind the affine: 0 none, 1 ReLU, 2 LeakyReLU(0.1).
+// Activation fused behind the affine: 0 none, 1 ReLU, 2 LeakyReLU(0.1), 3 ReLU6 (keras.applications.mobilenet.relu6).
 #include "common.h"
 
 #define BN_MAX_PARTS 256
@@ -14,11 +14,13 @@
 __device__ __forceinline__ float act_fwd(float v, int act) {
   if (act == 1) return fmaxf(v, 0.f);
   if (act == 2) return v > 0.f ? v : 0.1f * v;
+  if (act == 3) return fminf(fmaxf(v, 0.f), 6.f);
   return v;
 }
 __device__ __forceinline__ float act_grad(float out_pre, int act) {
   if (act == 1) return out_pre > 0.f ? 1.f : 0.f;
   if (act == 2) return out_pre > 0.f ? 1.f : 0.1f;
+  if (act == 3) return (out_pre > 0.f && out_pre < 6.f) ? 1.f : 0.f;
   return 1.f;
 }
 

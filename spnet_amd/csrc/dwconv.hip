@@ -1,16 +1,12 @@
-// Depthwise 3x3 / stride 1 / SAME convolutions on NHWC fp32 tensors (C % 4 == 0): the depthwise
-// step of keras SeparableConv2D inside Xception (call site spnet/models.py:357-359; 34 layers per
-// forward).  Pure HBM-bound work (9 MAC per 8 bytes): lanes run along the channel axis so every
-// global access is a 16-byte-per-lane coalesced segment; each thread slides a 3-row register window
-// down a strip of output rows so a tile row is fetched once per strip instead of three times.
+// Depthwise 3x3 / SAME convolutions on NHWC fp32 tensors (C % 4 == 0): the depthwise step of keras
+// SeparableConv2D inside Xception (call site spnet/models.py:357-359; 34 stride-1 layers per forward) and MobileNet's
+// DepthwiseConv2D (stride 1 | 2, spnet/models.py:346-355).  Pure HBM-bound work (9 MAC per 8 bytes): lanes run along
+// the channel axis so every global access is a 16-byte-per-lane coalesced segment.
 //
-//   fwd        y  = dw3x3(relu?(x), w)
-//   bwd_data   dx = dw3x3(dy, flip(w)) * (x > 0 if relu_in) (+ add)
-//   bwd_weight dw[tap][c] = sum_{b,h,w} relu?(x)[b,h+kh-1,w+kw-1,c] * dy[b,h,w,c]   (two-stage, deterministic)
+//   LDS-tiled stride-1 kernels (forward; fused backward = data + weight gradient + producer BatchNorm sums)
+//   strided gather kernels (stride 1 | 2: forward, data gradient, weight gradient)
+//   row reductions shared by the two-stage (deterministic) weight-gradient sums
 #include "common.h"
-#include <stdlib.h>
-
-#define DW_STRIP 4
 
 __device__ __forceinline__ float4 f4_relu(float4 v) {
   return make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));
@@ -20,177 +16,6 @@ __device__ __forceinline__ void f4_fma(float4& a, const float4 x, const float4 w
   a.y = fmaf(x.y, w.y, a.y);
   a.z = fmaf(x.z, w.z, a.z);
   a.w = fmaf(x.w, w.w, a.w);
-}
-
-// MODE 0: forward (optional relu on load).  MODE 1: backward-data (taps flipped; epilogue masks with
-// the saved forward input and adds `add`).
-template <int MODE>
-__global__ __launch_bounds__(256) void dw3x3_kernel(const float* __restrict__ in,
-                                                    const float* __restrict__ wt,
-                                                    float* __restrict__ out, int Bn, int H, int W,
-                                                    int C, int relu_in, const float* __restrict__ xmask,
-                                                    const float* __restrict__ add) {
-  const int c4n = C >> 2;
-  const int nstrip = (H + DW_STRIP - 1) / DW_STRIP;
-  const long total = (long)Bn * nstrip * W * c4n;
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
-       i += (long)gridDim.x * blockDim.x) {
-    const int c4 = (int)(i % c4n);
-    long t = i / c4n;
-    const int w = (int)(t % W);
-    t /= W;
-    const int s = (int)(t % nstrip);
-    const int b = (int)(t / nstrip);
-    const int h0 = s * DW_STRIP;
-    const int c = c4 * 4;
-
-    float4 k[9];
-#pragma unroll
-    for (int tp = 0; tp < 9; ++tp) {
-      const int src = (MODE == 1) ? (8 - tp) : tp;
-      k[tp] = *reinterpret_cast<const float4*>(wt + (long)src * C + c);
-    }
-    float4 acc[DW_STRIP];
-#pragma unroll
-    for (int r = 0; r < DW_STRIP; ++r) acc[r] = make_float4(0.f, 0.f, 0.f, 0.f);
-
-    const float* base = in + (long)b * H * W * C + c;
-#pragma unroll
-    for (int rr = 0; rr < DW_STRIP + 2; ++rr) {
-      const int h = h0 - 1 + rr;
-      if (h < 0 || h >= H) continue;
-      const float* rowp = base + (long)h * W * C;
-      float4 v[3];
-#pragma unroll
-      for (int dw = 0; dw < 3; ++dw) {
-        const int ww = w - 1 + dw;
-        if (ww >= 0 && ww < W) {
-          float4 x = *reinterpret_cast<const float4*>(rowp + (long)ww * C);
-          if (MODE == 0 && relu_in) x = f4_relu(x);
-          v[dw] = x;
-        } else {
-          v[dw] = make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-      }
-      // input row rr contributes to output row r = rr - kh (kh = 0..2)
-#pragma unroll
-      for (int kh = 0; kh < 3; ++kh) {
-        const int r = rr - kh;
-        if (r >= 0 && r < DW_STRIP) {
-#pragma unroll
-          for (int dw = 0; dw < 3; ++dw) f4_fma(acc[r], v[dw], k[kh * 3 + dw]);
-        }
-      }
-    }
-#pragma unroll
-    for (int r = 0; r < DW_STRIP; ++r) {
-      const int h = h0 + r;
-      if (h >= H) break;
-      const long o = (((long)b * H + h) * W + w) * C + c;
-      float4 res = acc[r];
-      if (MODE == 1) {
-        if (relu_in) {
-          const float4 xm = *reinterpret_cast<const float4*>(xmask + o);
-          res.x = xm.x > 0.f ? res.x : 0.f;
-          res.y = xm.y > 0.f ? res.y : 0.f;
-          res.z = xm.z > 0.f ? res.z : 0.f;
-          res.w = xm.w > 0.f ? res.w : 0.f;
-        }
-        if (add) {
-          const float4 a = *reinterpret_cast<const float4*>(add + o);
-          res.x += a.x; res.y += a.y; res.z += a.z; res.w += a.w;
-        }
-      }
-      *reinterpret_cast<float4*>(out + o) = res;
-    }
-  }
-}
-
-// Stage 1 of the weight gradient.  Work unit = one image row segment (b, h, w in [w0, w0+SEG)).
-// blockDim = (CL, 256/CL): x runs over channel quads, y over units; per-thread 9 float4 partial sums
-// are combined across y in LDS and one partial [9][C] row is written per workgroup (grid.y rows).
-#define DWW_SEG 32
-__global__ __launch_bounds__(256) void dw3x3_bwd_weight_partial_kernel(
-    const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ partial, int Bn,
-    int H, int W, int C, int relu_in) {
-  extern __shared__ __attribute__((aligned(16))) float4 red[];   // [blockDim.y][9][blockDim.x]
-  const int c4n = C >> 2;
-  const int c4 = blockIdx.x * blockDim.x + threadIdx.x;
-  const bool active = c4 < c4n;
-  const int c = c4 * 4;
-  const int nseg = (W + DWW_SEG - 1) / DWW_SEG;
-  const long nunits = (long)Bn * H * nseg;
-
-  float4 acc[9];
-#pragma unroll
-  for (int tp = 0; tp < 9; ++tp) acc[tp] = make_float4(0.f, 0.f, 0.f, 0.f);
-
-  if (active) {
-    for (long u = (long)blockIdx.y * blockDim.y + threadIdx.y; u < nunits;
-         u += (long)gridDim.y * blockDim.y) {
-      const int sg = (int)(u % nseg);
-      long t = u / nseg;
-      const int h = (int)(t % H);
-      const int b = (int)(t / H);
-      const int w0 = sg * DWW_SEG;
-      const int w1 = min(W, w0 + DWW_SEG);
-      const float* xb = x + (long)b * H * W * C + c;
-      const float* dyr = dy + (((long)b * H + h) * W) * C + c;
-      // sliding 3x3 window over columns: win[kh][0..2] = x[h+kh-1][w-1..w+1]
-      float4 win[3][3];
-      const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-      for (int kh = 0; kh < 3; ++kh) {
-        const int hh = h + kh - 1;
-        const bool hv = (hh >= 0 && hh < H);
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-          const int ww = w0 - 1 + j;
-          float4 v = zero;
-          if (hv && ww >= 0 && ww < W) {
-            v = *reinterpret_cast<const float4*>(xb + ((long)hh * W + ww) * C);
-            if (relu_in) v = f4_relu(v);
-          }
-          win[kh][j] = v;
-        }
-      }
-      for (int w = w0; w < w1; ++w) {
-#pragma unroll
-        for (int kh = 0; kh < 3; ++kh) {
-          const int hh = h + kh - 1;
-          float4 v = zero;
-          if (hh >= 0 && hh < H && w + 1 < W) {
-            v = *reinterpret_cast<const float4*>(xb + ((long)hh * W + w + 1) * C);
-            if (relu_in) v = f4_relu(v);
-          }
-          win[kh][2] = v;
-        }
-        const float4 g = *reinterpret_cast<const float4*>(dyr + (long)w * C);
-#pragma unroll
-        for (int kh = 0; kh < 3; ++kh) {
-#pragma unroll
-          for (int kw = 0; kw < 3; ++kw) f4_fma(acc[kh * 3 + kw], win[kh][kw], g);
-          win[kh][0] = win[kh][1];
-          win[kh][1] = win[kh][2];
-        }
-      }
-    }
-  }
-  const int bx = blockDim.x, by = blockDim.y;
-#pragma unroll
-  for (int tp = 0; tp < 9; ++tp) red[(threadIdx.y * 9 + tp) * bx + threadIdx.x] = acc[tp];
-  __syncthreads();
-  if (threadIdx.y == 0 && active) {
-#pragma unroll
-    for (int tp = 0; tp < 9; ++tp) {
-      float4 s = red[tp * bx + threadIdx.x];
-      for (int y = 1; y < by; ++y) {
-        const float4 v = red[(y * 9 + tp) * bx + threadIdx.x];
-        s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
-      }
-      *reinterpret_cast<float4*>(partial + ((long)blockIdx.y * 9 + tp) * C + c) = s;
-    }
-  }
 }
 
 // ================================================================================================
@@ -451,6 +276,131 @@ __global__ __launch_bounds__(256) void dw3x3_tile_bwd_kernel(
   }
 }
 
+// ================================================================================================
+// Strided depthwise 3x3 / SAME (keras.applications.mobilenet: DepthwiseConv2D((3,3), padding='same', strides=(2,2)),
+// call site spnet/models.py:346-355).  TF SAME: out = ceil(in/s), pad_total = max((out-1)*s + 3 - in, 0), floor(half)
+// before.  One thread per (pixel, channel quad); these layers are a small share of a MobileNet step, so the plain
+// gather forms are used (the stride-1 layers run the LDS-tiled kernels above).
+//   fwd        y[b,oh,ow,c]  = sum_k x[b, oh*s-pt+kh, ow*s-pl+kw, c] w[k,c]
+//   bwd_data   dx[b,h,w,c]   = sum over the windows containing (h,w) of dy * w[tap]
+//   bwd_weight dw[k,c]       = sum_{b,oh,ow} x[...] dy[b,oh,ow,c]      (per-workgroup partial rows + reduce_rows)
+// ================================================================================================
+__global__ __launch_bounds__(256) void dw3x3_strided_fwd_kernel(const float* __restrict__ x, const float* __restrict__ wt,
+                                                                float* __restrict__ y, int Bn, int H, int W, int C,
+                                                                int OH, int OW, int s, int pt, int pl) {
+  const int c4n = C >> 2;
+  const long total = (long)Bn * OH * OW * c4n;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int c4 = (int)(i % c4n);
+    long t = i / c4n;
+    const int ow = (int)(t % OW);
+    t /= OW;
+    const int oh = (int)(t % OH);
+    const int b = (int)(t / OH);
+    const int c = c4 * 4;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh) {
+      const int h = oh * s - pt + kh;
+      if (h < 0 || h >= H) continue;
+#pragma unroll
+      for (int kw = 0; kw < 3; ++kw) {
+        const int w = ow * s - pl + kw;
+        if (w < 0 || w >= W) continue;
+        f4_fma(acc, *reinterpret_cast<const float4*>(x + (((long)b * H + h) * W + w) * C + c),
+               *reinterpret_cast<const float4*>(wt + (long)(kh * 3 + kw) * C + c));
+      }
+    }
+    *reinterpret_cast<float4*>(y + i * 4) = acc;
+  }
+}
+
+__global__ __launch_bounds__(256) void dw3x3_strided_bwd_data_kernel(const float* __restrict__ dy,
+                                                                     const float* __restrict__ wt,
+                                                                     float* __restrict__ dx, int Bn, int H, int W, int C,
+                                                                     int OH, int OW, int s, int pt, int pl) {
+  const int c4n = C >> 2;
+  const long total = (long)Bn * H * W * c4n;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int c4 = (int)(i % c4n);
+    long t = i / c4n;
+    const int w = (int)(t % W);
+    t /= W;
+    const int h = (int)(t % H);
+    const int b = (int)(t / H);
+    const int c = c4 * 4;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh) {
+      const int hh = h + pt - kh;                    // = oh * s
+      if (hh < 0 || hh % s) continue;
+      const int oh = hh / s;
+      if (oh >= OH) continue;
+#pragma unroll
+      for (int kw = 0; kw < 3; ++kw) {
+        const int ww = w + pl - kw;
+        if (ww < 0 || ww % s) continue;
+        const int ow = ww / s;
+        if (ow >= OW) continue;
+        f4_fma(acc, *reinterpret_cast<const float4*>(dy + (((long)b * OH + oh) * OW + ow) * C + c),
+               *reinterpret_cast<const float4*>(wt + (long)(kh * 3 + kw) * C + c));
+      }
+    }
+    *reinterpret_cast<float4*>(dx + i * 4) = acc;
+  }
+}
+
+// blockDim = (CL, 256/CL): x over channel quads, y over output pixels; one partial [9][C] row per workgroup row.
+__global__ __launch_bounds__(256) void dw3x3_strided_bwd_weight_kernel(const float* __restrict__ x,
+                                                                       const float* __restrict__ dy,
+                                                                       float* __restrict__ partial, int Bn, int H, int W,
+                                                                       int C, int OH, int OW, int s, int pt, int pl) {
+  extern __shared__ __attribute__((aligned(16))) float4 red[];   // [blockDim.y][9][blockDim.x]
+  const int c4n = C >> 2;
+  const int c4 = blockIdx.x * blockDim.x + threadIdx.x;
+  const bool active = c4 < c4n;
+  const int c = c4 * 4;
+  float4 acc[9];
+#pragma unroll
+  for (int tp = 0; tp < 9; ++tp) acc[tp] = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (active) {
+    const long npix = (long)Bn * OH * OW;
+    for (long u = (long)blockIdx.y * blockDim.y + threadIdx.y; u < npix; u += (long)gridDim.y * blockDim.y) {
+      const int ow = (int)(u % OW);
+      long t = u / OW;
+      const int oh = (int)(t % OH);
+      const int b = (int)(t / OH);
+      const float4 g = *reinterpret_cast<const float4*>(dy + u * C + c);
+#pragma unroll
+      for (int kh = 0; kh < 3; ++kh) {
+        const int h = oh * s - pt + kh;
+        if (h < 0 || h >= H) continue;
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) {
+          const int w = ow * s - pl + kw;
+          if (w < 0 || w >= W) continue;
+          f4_fma(acc[kh * 3 + kw], *reinterpret_cast<const float4*>(x + (((long)b * H + h) * W + w) * C + c), g);
+        }
+      }
+    }
+  }
+  const int bx = blockDim.x, by = blockDim.y;
+#pragma unroll
+  for (int tp = 0; tp < 9; ++tp) red[(threadIdx.y * 9 + tp) * bx + threadIdx.x] = acc[tp];
+  __syncthreads();
+  if (threadIdx.y == 0 && active) {
+#pragma unroll
+    for (int tp = 0; tp < 9; ++tp) {
+      float4 sm = red[tp * bx + threadIdx.x];
+      for (int yy = 1; yy < by; ++yy) {
+        const float4 v = red[(yy * 9 + tp) * bx + threadIdx.x];
+        sm.x += v.x; sm.y += v.y; sm.z += v.z; sm.w += v.w;
+      }
+      *reinterpret_cast<float4*>(partial + ((long)blockIdx.y * 9 + tp) * C + c) = sm;
+    }
+  }
+}
+
 // out[l] = sum_p in[p*L + l]   (deterministic order; used by several two-stage reductions).
 // Workgroup = 16 columns x 16 interleaved row groups; grid.y > 1 splits the rows into grid.y strided
 // slices written to out[y*L + l] (a second call then folds the slices).
@@ -490,56 +440,6 @@ static int chan_lanes(int c4n) {
   int cl = 8;
   while (cl < c4n && cl < 64) cl <<= 1;
   return cl;
-}
-
-extern "C" int spnet_dwconv3x3_fwd(const float* x, const float* w, float* y, int B, int H, int W,
-                                   int C, int relu_in, void* stream) {
-  if (C & 3) return (int)hipErrorInvalidValue;
-  const long total = (long)B * ((H + DW_STRIP - 1) / DW_STRIP) * W * (C / 4);
-  hipLaunchKernelGGL(dw3x3_kernel<0>, dim3(spnet_ew_grid(total, 256)), dim3(256), 0,
-                     (hipStream_t)stream, x, w, y, B, H, W, C, relu_in, (const float*)nullptr,
-                     (const float*)nullptr);
-  SPNET_RETURN_LAUNCH_STATUS();
-}
-
-extern "C" int spnet_dwconv3x3_bwd_data(const float* dy, const float* w, float* dx, int B, int H,
-                                        int W, int C, int relu_in, const float* x_fwd,
-                                        const float* add, void* stream) {
-  if (C & 3) return (int)hipErrorInvalidValue;
-  if (relu_in && !x_fwd) return (int)hipErrorInvalidValue;
-  const long total = (long)B * ((H + DW_STRIP - 1) / DW_STRIP) * W * (C / 4);
-  hipLaunchKernelGGL(dw3x3_kernel<1>, dim3(spnet_ew_grid(total, 256)), dim3(256), 0,
-                     (hipStream_t)stream, dy, w, dx, B, H, W, C, relu_in, x_fwd, add);
-  SPNET_RETURN_LAUNCH_STATUS();
-}
-
-// workspace must hold spnet_dwconv3x3_bwd_weight_ws(B,H,W,C) floats.
-extern "C" long spnet_dwconv3x3_bwd_weight_ws(int B, int H, int W, int C) {
-  const int cl = chan_lanes(C / 4);
-  const int by = 256 / cl;
-  const long nunits = (long)B * H * ((W + DWW_SEG - 1) / DWW_SEG);
-  long gy = (nunits + by - 1) / by;
-  if (gy > 512) gy = 512;
-  if (gy < 1) gy = 1;
-  return gy * 9 * C;
-}
-
-extern "C" int spnet_dwconv3x3_bwd_weight(const float* x, const float* dy, float* dw, int B, int H,
-                                          int W, int C, int relu_in, float* workspace, void* stream) {
-  if (C & 3) return (int)hipErrorInvalidValue;
-  const int c4n = C / 4;
-  const int cl = chan_lanes(c4n);
-  const int by = 256 / cl;
-  const long nunits = (long)B * H * ((W + DWW_SEG - 1) / DWW_SEG);
-  long gy = (nunits + by - 1) / by;
-  if (gy > 512) gy = 512;
-  if (gy < 1) gy = 1;
-  dim3 grid((c4n + cl - 1) / cl, (unsigned)gy), block(cl, by);
-  const size_t shm = (size_t)by * 9 * cl * sizeof(float4);
-  hipLaunchKernelGGL(dw3x3_bwd_weight_partial_kernel, grid, block, shm, (hipStream_t)stream, x, dy,
-                     workspace, B, H, W, C, relu_in);
-  launch_reduce_rows(workspace, (int)gy, 9 * C, dw, nullptr, (hipStream_t)stream);
-  SPNET_RETURN_LAUNCH_STATUS();
 }
 
 // Many independent row reductions in one launch: job j folds in_j[P_j][L_j] into out_j[L_j].  jobs (device
@@ -582,30 +482,69 @@ extern "C" int spnet_reduce_rows(const float* in, int P, int L, float* out, void
   SPNET_RETURN_LAUNCH_STATUS();
 }
 
+// ---------------------------------------------------------------- strided entry points
+static void same_pad(int in, int s, int* out, int* before) {
+  *out = (in + s - 1) / s;
+  int total = (*out - 1) * s + 3 - in;
+  if (total < 0) total = 0;
+  *before = total / 2;
+}
+
+static int dws_rows(int B, int OH, int OW, int C) {
+  const int cl = chan_lanes(C / 4);
+  const int by = 256 / cl;
+  long gy = ((long)B * OH * OW + (long)by * 8 - 1) / ((long)by * 8);
+  if (gy > 256) gy = 256;
+  return gy < 1 ? 1 : (int)gy;
+}
+
+// floats of workspace for spnet_dwconv3x3_strided_bwd_weight
+extern "C" long spnet_dwconv3x3_strided_ws(int B, int H, int W, int C, int stride) {
+  int OH, OW, pt, pl;
+  same_pad(H, stride, &OH, &pt);
+  same_pad(W, stride, &OW, &pl);
+  return (long)dws_rows(B, OH, OW, C) * 9 * C;
+}
+
+// op 0: y = dw(x, w) ; op 1: dx = dw^T(dy, w) ; op 2: dw = sum x (x) dy (workspace: spnet_dwconv3x3_strided_ws floats).
+// a = x (op 0, 2) or dy (op 1); b = w (op 0, 1) or dy (op 2); H, W = INPUT extent; stride 1 or 2.
+extern "C" int spnet_dwconv3x3_strided(int op, const float* a, const float* b, float* out, int B, int H, int W, int C,
+                                       int stride, float* workspace, void* stream) {
+  if ((C & 3) || (stride != 1 && stride != 2) || op < 0 || op > 2) return (int)hipErrorInvalidValue;
+  hipStream_t st = (hipStream_t)stream;
+  int OH, OW, pt, pl;
+  same_pad(H, stride, &OH, &pt);
+  same_pad(W, stride, &OW, &pl);
+  if (op == 0) {
+    const long total = (long)B * OH * OW * (C / 4);
+    hipLaunchKernelGGL(dw3x3_strided_fwd_kernel, dim3(spnet_ew_grid(total, 256)), dim3(256), 0, st, a, b, out, B, H, W, C,
+                       OH, OW, stride, pt, pl);
+  } else if (op == 1) {
+    const long total = (long)B * H * W * (C / 4);
+    hipLaunchKernelGGL(dw3x3_strided_bwd_data_kernel, dim3(spnet_ew_grid(total, 256)), dim3(256), 0, st, a, b, out, B, H,
+                       W, C, OH, OW, stride, pt, pl);
+  } else {
+    if (!workspace) return (int)hipErrorInvalidValue;
+    const int cl = chan_lanes(C / 4), by = 256 / cl;
+    const int gy = dws_rows(B, OH, OW, C);
+    dim3 grid((C / 4 + cl - 1) / cl, gy), block(cl, by);
+    hipLaunchKernelGGL(dw3x3_strided_bwd_weight_kernel, grid, block, (size_t)by * 9 * cl * sizeof(float4), st, a, b,
+                       workspace, B, H, W, C, OH, OW, stride, pt, pl);
+    launch_reduce_rows(workspace, gy, 9 * C, out, nullptr, st);
+  }
+  SPNET_RETURN_LAUNCH_STATUS();
+}
+
 // ---------------------------------------------------------------- tiled entry points
 struct DwGeom { int cfg, th, tw, cc4, tiles_h, tiles_w, cchunks; long nblk; size_t lds_fwd, lds_bwd; };
 // cfg 1: 6x8 pixel tile x 16 channel quads (exit flow, 6x8 planes); cfg 0: 12x16 tile x 8 quads;
 // cfg 2 (forward only): 24x16 tile x 8 quads for the large planes (halo read overhead 1.22 instead of 1.31)
-// cfg 3: 6x16 tile x 8 quads for planes so small that 12-row tiles give the chip less than ~4 workgroups per CU (the
-// middle flow's 12x16 planes: 736 workgroups that all load, then all compute, then all store -- half-height tiles
-// double the workgroups, shorten each one's serial load/compute/store chain and let the phases of different
-// workgroups overlap)
-static int dw_small_tiles() {
-  static int v = -1;
-  if (v < 0) {
-    const char* e = getenv("SPNET_DW_SMALL");
-    v = (e && e[0] == '0') ? 0 : 1;
-  }
-  return v;
-}
 static DwGeom dw_geom(int B, int H, int W, int C, bool fwd) {
   DwGeom g;
   g.cfg = (H <= 6 && W <= 8) ? 1 : 0;   // (a 24x16 forward tile was tried: 60 KB of LDS halves residency and loses)
-  if (g.cfg == 0 && dw_small_tiles()) {
-    const long nblk12 = (long)B * ((H + 11) / 12) * ((W + 15) / 16) * ((C / 4 + 7) / 8);
-    if (nblk12 < 4 * 256 && H > 6) g.cfg = 3;
-  }
-  g.th = (g.cfg == 1 || g.cfg == 3) ? 6 : (g.cfg == 2 ? 24 : 12);
+  // (measured and dropped, round 2: 6x16 half-height tiles for the middle flow's 12x16 planes -- twice the workgroups,
+  // forward 11.1 -> 10.8 us but backward 16.5 -> 18.4 us)
+  g.th = g.cfg == 1 ? 6 : (g.cfg == 2 ? 24 : 12);
   g.tw = g.cfg == 1 ? 8 : 16;
   g.cc4 = g.cfg == 1 ? 16 : 8;
   g.tiles_h = (H + g.th - 1) / g.th;
@@ -628,7 +567,6 @@ extern "C" int spnet_dwconv3x3_tiled_fwd(const float* x, const float* w, float* 
                      in_shift)
   if (g.cfg == 1) DW_FWD(16, 8, 6);
   else if (g.cfg == 2) DW_FWD(8, 16, 24);
-  else if (g.cfg == 3) DW_FWD(8, 16, 6);
   else DW_FWD(8, 16, 12);
 #undef DW_FWD
   SPNET_RETURN_LAUNCH_STATUS();
@@ -663,10 +601,6 @@ extern "C" int spnet_dwconv3x3_tiled_bwd(const float* dy, const float* x_fwd, co
   const DwGeom g = dw_geom(B, H, W, C, false);
   if (g.cfg == 1)
     hipLaunchKernelGGL((dw3x3_tile_bwd_kernel<16, 8, 6>), dim3((unsigned)g.nblk), dim3(256), g.lds_bwd,
-                       (hipStream_t)stream, dy, x_fwd, w, dx, workspace, add, H, W, C, relu_in, g.tiles_h,
-                       g.tiles_w, g.cchunks, in_scale, in_shift, bn_mean, bn_invstd, bn_partial, bn_x);
-  else if (g.cfg == 3)
-    hipLaunchKernelGGL((dw3x3_tile_bwd_kernel<8, 16, 6>), dim3((unsigned)g.nblk), dim3(256), g.lds_bwd,
                        (hipStream_t)stream, dy, x_fwd, w, dx, workspace, add, H, W, C, relu_in, g.tiles_h,
                        g.tiles_w, g.cchunks, in_scale, in_shift, bn_mean, bn_invstd, bn_partial, bn_x);
   else

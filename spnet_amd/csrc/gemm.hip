@@ -1,5 +1,5 @@
-// fp32 MFMA GEMM for the pointwise (1x1) convolutions, the stride-2 residual convs, block1_conv2
-// (through im2col) and the Dense head:  C[M,N] = sum_k A(m,k) * B(k,n)
+// fp32 MFMA GEMM for the pointwise (1x1) convolutions, the stride-2 residual convs and the Dense head
+// (block1_conv2 runs the same tile machinery as implicit GEMMs in conv_gemm.hip):  C[M,N] = sum_k A(m,k) * B(k,n)
 //
 // Replaces the TensorFlow/cuDNN kernels behind keras SeparableConv2D's pointwise step, Conv2D(1x1)
 // and Dense (call sites spnet/models.py:357-359, 388).  Arithmetic is exact f32: the
@@ -473,62 +473,8 @@ extern "C" int spnet_gemm_f32_colstats(const float* A, int a_major, int lda, con
 }
 
 // ------------------------------------------------------------------------------------------------
-// im2col / col2im for block1_conv2 (3x3, stride 1, VALID, Cin % 4 == 0) and the stride-2 row
-// gather / scatter of the 1x1 residual convs (TF SAME on a 1x1/s2 conv samples the even pixels).
+// Stride-2 row gather / scatter of the 1x1 residual convs (TF SAME on a 1x1/s2 conv samples the even pixels).
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void im2col3x3_kernel(const float* __restrict__ x,
-                                                        float* __restrict__ col, int Bn, int H, int W,
-                                                        int C, int OH, int OW) {
-  const int c4n = C / 4;
-  const long total = (long)Bn * OH * OW * 9 * c4n;
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
-       i += (long)gridDim.x * blockDim.x) {
-    const int c4 = (int)(i % c4n);
-    long t = i / c4n;
-    const int tap = (int)(t % 9);
-    t /= 9;
-    const int ow = (int)(t % OW);
-    t /= OW;
-    const int oh = (int)(t % OH);
-    const int b = (int)(t / OH);
-    const int kh = tap / 3, kw = tap % 3;
-    const float4 v = *reinterpret_cast<const float4*>(
-        x + (((long)b * H + oh + kh) * W + ow + kw) * C + c4 * 4);
-    *reinterpret_cast<float4*>(col + i * 4) = v;
-  }
-}
-
-__global__ __launch_bounds__(256) void col2im3x3_kernel(const float* __restrict__ dcol,
-                                                        float* __restrict__ dx, int Bn, int H, int W,
-                                                        int C, int OH, int OW) {
-  const int c4n = C / 4;
-  const long total = (long)Bn * H * W * c4n;
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
-       i += (long)gridDim.x * blockDim.x) {
-    const int c4 = (int)(i % c4n);
-    long t = i / c4n;
-    const int w = (int)(t % W);
-    t /= W;
-    const int h = (int)(t % H);
-    const int b = (int)(t / H);
-    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-    for (int kh = 0; kh < 3; ++kh) {
-      const int oh = h - kh;
-      if (oh < 0 || oh >= OH) continue;
-#pragma unroll
-      for (int kw = 0; kw < 3; ++kw) {
-        const int ow = w - kw;
-        if (ow < 0 || ow >= OW) continue;
-        const float4 v = *reinterpret_cast<const float4*>(
-            dcol + (((long)b * OH + oh) * OW + ow) * (9L * C) + (kh * 3 + kw) * C + c4 * 4);
-        s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
-      }
-    }
-    *reinterpret_cast<float4*>(dx + i * 4) = s;
-  }
-}
-
 __global__ __launch_bounds__(256) void gather_s2_kernel(const float* __restrict__ x,
                                                         float* __restrict__ xs, int Bn, int H, int W,
                                                         int C, int OH, int OW) {
@@ -598,24 +544,6 @@ extern "C" int spnet_transpose_batched(const void* jobs, int njobs, int max_rows
   if (!jobs || njobs < 1 || max_rows < 1 || max_cols < 1) return (int)hipErrorInvalidValue;
   hipLaunchKernelGGL(transpose_batched_kernel, dim3((max_cols + 31) / 32, (max_rows + 31) / 32, njobs), dim3(256), 0,
                      (hipStream_t)stream, reinterpret_cast<const long long*>(jobs));
-  SPNET_RETURN_LAUNCH_STATUS();
-}
-
-extern "C" int spnet_im2col3x3(const float* x, float* col, int B, int H, int W, int C, void* stream) {
-  if (C & 3) return (int)hipErrorInvalidValue;
-  const int OH = H - 2, OW = W - 2;
-  const long total = (long)B * OH * OW * 9 * (C / 4);
-  hipLaunchKernelGGL(im2col3x3_kernel, dim3(spnet_ew_grid(total, 256)), dim3(256), 0,
-                     (hipStream_t)stream, x, col, B, H, W, C, OH, OW);
-  SPNET_RETURN_LAUNCH_STATUS();
-}
-
-extern "C" int spnet_col2im3x3(const float* dcol, float* dx, int B, int H, int W, int C, void* stream) {
-  if (C & 3) return (int)hipErrorInvalidValue;
-  const int OH = H - 2, OW = W - 2;
-  const long total = (long)B * H * W * (C / 4);
-  hipLaunchKernelGGL(col2im3x3_kernel, dim3(spnet_ew_grid(total, 256)), dim3(256), 0,
-                     (hipStream_t)stream, dcol, dx, B, H, W, C, OH, OW);
   SPNET_RETURN_LAUNCH_STATUS();
 }
 

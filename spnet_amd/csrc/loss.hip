@@ -143,3 +143,32 @@ extern "C" int spnet_decode(const float* y_norm, const float* means, const float
                      y_norm, means, ranges, out, B, ncols, sigmoid_noobj);
   SPNET_RETURN_LAUNCH_STATUS();
 }
+
+// ---------------------------------------------------------------- sigmoid output columns
+// SelectiveSigmoid (spnet/models.py:277-298) and the 'compound' head (models.py:379-386: Dense(n_preds, sigmoid)
+// + Dense(rest) concatenated and re-ordered by InterleaveColumns, i.e. ONE dense layer whose columns start::step
+// pass through a sigmoid).  mode 0: y[:, start::step] = sigmoid(y[:, start::step]) in place;
+// mode 1: g[:, start::step] *= y (1 - y) with y the POST-sigmoid output (backward).
+__global__ __launch_bounds__(256) void selective_sigmoid_kernel(float* __restrict__ y, float* __restrict__ g, int Bn,
+                                                                int ncols, int start, int step, int mode) {
+  const int per = (ncols - start + step - 1) / step;
+  const long total = (long)Bn * per;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long o = (i / per) * ncols + start + (i % per) * step;
+    if (mode == 0) {
+      y[o] = 1.f / (1.f + expf(-y[o]));
+    } else {
+      const float s = y[o];
+      g[o] *= s * (1.f - s);
+    }
+  }
+}
+
+extern "C" int spnet_selective_sigmoid(float* y, float* grad, int B, int ncols, int start, int step, int backward,
+                                       void* stream) {
+  if (B < 1 || ncols < 1 || start < 0 || start >= ncols || step < 1 || (backward && !grad)) return (int)hipErrorInvalidValue;
+  const long total = (long)B * ((ncols - start + step - 1) / step);
+  hipLaunchKernelGGL(selective_sigmoid_kernel, dim3(spnet_ew_grid(total, 256)), dim3(256), 0, (hipStream_t)stream, y,
+                     grad, B, ncols, start, step, backward ? 1 : 0);
+  SPNET_RETURN_LAUNCH_STATUS();
+}

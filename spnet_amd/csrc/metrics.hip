@@ -86,3 +86,47 @@ extern "C" int spnet_ellipse_iou(const float* yp, const float* yt, long npairs, 
   hipLaunchKernelGGL(ellipse_iou_kernel, dim3((unsigned)npairs), dim3(256), 0, (hipStream_t)stream, yp, yt, nx, ny, iou);
   SPNET_RETURN_LAUNCH_STATUS();
 }
+
+// ---------------------------------------------------------------- count metrics (spnet/diagnostics.py:13-59: calc_errors)
+// Yp / Yt: [N][ncols] de-normalised grids, 8 variables per predictor (noobj at 6, rings at 7).  counts[7] (int, zeroed
+// by the caller) = ring_miscounts, ring_truecounts, total_obj, false_obj_pos, false_obj_neg, true_obj_pos,
+// true_obj_neg; pix_err[N] = centre distance of the FIRST predictor of each row (the reference's diff[:,0], diff[:,1]).
+// int(round(x)) in the reference is round-half-even = rintf.  Integer atomics: the result does not depend on order.
+__global__ __launch_bounds__(256) void calc_errors_kernel(const float* __restrict__ yp, const float* __restrict__ yt,
+                                                          long npairs, int npred, int* __restrict__ counts,
+                                                          float* __restrict__ pix_err) {
+  __shared__ int sc[7];
+  if (threadIdx.x < 7) sc[threadIdx.x] = 0;
+  __syncthreads();
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < npairs; i += (long)gridDim.x * blockDim.x) {
+    const float* p = yp + i * 8;
+    const float* t = yt + i * 8;
+    const bool there = (int)rintf(t[6]) == 0, predicted = (int)rintf(p[6]) == 0;
+    if (there) {
+      atomicAdd(&sc[2], 1);
+      if (predicted) {
+        atomicAdd(&sc[5], 1);
+        atomicAdd(fabsf(t[7] - p[7]) > 0.5f ? &sc[0] : &sc[1], 1);
+      } else {
+        atomicAdd(&sc[4], 1);
+      }
+    } else {
+      atomicAdd(predicted ? &sc[3] : &sc[6], 1);
+    }
+    if (i % npred == 0) {
+      const float dx = p[0] - t[0], dy = p[1] - t[1];
+      pix_err[i / npred] = sqrtf(dx * dx + dy * dy);
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < 7 && sc[threadIdx.x]) atomicAdd(&counts[threadIdx.x], sc[threadIdx.x]);
+}
+
+extern "C" int spnet_calc_errors(const float* yp, const float* yt, long N, int ncols, int* counts, float* pix_err,
+                                 void* stream) {
+  if (N < 1 || ncols < 8 || (ncols & 7) || !counts || !pix_err) return (int)hipErrorInvalidValue;
+  const long npairs = N * (ncols / 8);
+  hipLaunchKernelGGL(calc_errors_kernel, dim3(spnet_ew_grid(npairs, 256)), dim3(256), 0, (hipStream_t)stream, yp, yt,
+                     npairs, ncols / 8, counts, pix_err);
+  SPNET_RETURN_LAUNCH_STATUS();
+}

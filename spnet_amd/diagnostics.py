@@ -20,7 +20,26 @@ import numpy as np
 from . import config as cf
 
 
-def calc_errors(Yp, Yt):
+def _calc_errors_device(Yp, Yt):
+    """calc_errors in one HIP launch (csrc/metrics.hip: spnet_calc_errors); same nine return values."""
+    import torch
+    from . import _lib as L
+    dev = torch.device("cuda", torch.cuda.current_device())
+    yp = torch.as_tensor(np.ascontiguousarray(Yp, dtype=np.float32)).to(dev)
+    yt = torch.as_tensor(np.ascontiguousarray(Yt, dtype=np.float32)).to(dev)
+    counts = torch.zeros(7, dtype=torch.int32, device=dev)
+    pix = torch.empty(yp.shape[0], dtype=torch.float32, device=dev)
+    L.spnet_calc_errors(yp.data_ptr(), yt.data_ptr(), yp.shape[0], yp.shape[1], counts.data_ptr(), pix.data_ptr(),
+                        torch.cuda.current_stream().cuda_stream)
+    c = [int(v) for v in counts.cpu().numpy()]
+    pix_err = pix.cpu().numpy()
+    return (c[0], c[1], c[2], c[3], c[4], c[5], c[6], pix_err, int(np.argmax(pix_err)))
+
+
+def calc_errors(Yp, Yt, device=False):
+    """device=True: the same counts from the GPU (vars_per_pred == 8 layouts)."""
+    if device and cf.vars_per_pred == 8:
+        return _calc_errors_device(Yp, Yt)
     n_pred = int(Yt.shape[1] / cf.vars_per_pred)
     diff = Yp - Yt
     pix_err = np.sqrt(diff[:, 0] ** 2 + diff[:, 1] ** 2)

@@ -27,7 +27,10 @@ from . import _lib as L
 BN_EPS = 1e-3
 BN_MOMENTUM = 0.99
 L2_COEF = 1e-4
-ACT_NONE, ACT_RELU, ACT_LRELU = 0, 1, 2
+ACT_NONE, ACT_RELU, ACT_LRELU, ACT_RELU6 = 0, 1, 2, 3
+# keras.applications.mobilenet.MobileNet(alpha=1): (pointwise filters, depthwise stride) of conv_dw/pw_1..13
+MOBILENET_BLOCKS = [(64, 1), (128, 2), (128, 1), (256, 2), (256, 1), (512, 2), (512, 1), (512, 1), (512, 1), (512, 1),
+                    (512, 1), (1024, 2), (1024, 1)]
 K_MAJOR, OUT_MAJOR = 0, 1
 WS_FLOATS = 48 * 1024 * 1024       # shared scratch (192 MiB), carved into regions (float offsets):
 WS_GEMM = (0, 16 * 1024 * 1024)                       # split-K slabs
@@ -92,9 +95,19 @@ def backbone_out_hw(H, W):
     return h, w
 
 
-def param_specs(H, W, n_out=576):
+def mobilenet_out_hw(H, W):
+    h, w = H // 2, W // 2
+    h, w = (h + 1) // 2, (w + 1) // 2
+    for _, s_ in MOBILENET_BLOCKS:
+        if s_ == 2:
+            h, w = (h + 1) // 2, (w + 1) // 2
+    return h, w
+
+
+def param_specs(H, W, n_out=576, backbone="Xception"):
     """[(keras_name, shape, trainable, l2)] -- l2-regularised kernels first (run-log line 98 of the
-    reference: conv2d_1..3, block1_conv1, block1_conv2, conv2d_4..7, FinalOutput)."""
+    reference: conv2d_1..3, block1_conv1, block1_conv2, conv2d_4..7, FinalOutput).  backbone 'MobileNet'
+    (spnet/models.py:346-355): conv1 + 13 depthwise/pointwise pairs, l2 on the Conv2D / Dense kernels."""
     specs = []
 
     def bn(name, c):
@@ -109,6 +122,20 @@ def param_specs(H, W, n_out=576):
     bn("batch_normalization_2", 3)
     specs.append(("conv2d_3/kernel", (3, 3, 3, 3), True, True))
     bn("batch_normalization_3", 3)
+    if backbone == "MobileNet":
+        specs.append(("conv1/kernel", (3, 3, 3, 32), True, True))
+        bn("conv1_bn", 32)
+        cin = 32
+        for i, (cout, _) in enumerate(MOBILENET_BLOCKS, 1):
+            specs.append(("conv_dw_%d/depthwise_kernel" % i, (3, 3, cin), True, False))
+            bn("conv_dw_%d_bn" % i, cin)
+            specs.append(("conv_pw_%d/kernel" % i, (1, 1, cin, cout), True, True))
+            bn("conv_pw_%d_bn" % i, cout)
+            cin = cout
+        h, w = mobilenet_out_hw(H, W)
+        specs.append(("FinalOutput/kernel", (h * w * cin, n_out), True, True))
+        specs.append(("FinalOutput/bias", (n_out,), True, False))
+        return specs
     specs.append(("block1_conv1/kernel", (3, 3, 3, 32), True, True))
     bn("block1_conv1_bn", 32)
     specs.append(("block1_conv2/kernel", (3, 3, 32, 64), True, True))
@@ -149,11 +176,17 @@ def _glorot_fans(name, shape):
 
 class Engine:
     def __init__(self, H, W, batch, n_out=576, device="cuda:0", loss_type="same", seed=0,
-                 train=True, adam_eps=1e-7, share_from=None, rank=0):
+                 train=True, adam_eps=1e-7, share_from=None, rank=0, sigmoid_cols=None, backbone="Xception"):
         """rank: data-parallel rank, mixed into the initial dropout seed so that replicas draw different masks."""
         if not torch.cuda.is_available():
             raise RuntimeError("spnet_amd.Engine needs a HIP device (no CPU fallback)")
         self.H, self.W, self.B, self.n_out = int(H), int(W), int(batch), int(n_out)
+        # (start, step) of the output columns that pass through a sigmoid: the 'compound' head of the reference
+        # (models.py:379-386) = one dense layer with sigmoid 'noobj' columns once InterleaveColumns has re-ordered them
+        self.sigmoid_cols = sigmoid_cols
+        if backbone not in ("Xception", "MobileNet"):
+            raise NotImplementedError("backbone %r: this build implements Xception and MobileNet" % (backbone,))
+        self.backbone = backbone
         self.dev = torch.device(device)
         self.loss_type = loss_type
         self.train_capable = bool(train)
@@ -219,7 +252,7 @@ class Engine:
 
     # ------------------------------------------------------------------ parameters
     def _build_params(self, seed):
-        specs = param_specs(self.H, self.W, self.n_out)
+        specs = param_specs(self.H, self.W, self.n_out, self.backbone)
         # Flat layout: [l2-regularised kernels, the Dense head's first] [all depthwise kernels] [everything else in
         # forward order].  The l2 set is a prefix (weight decay inside the fused optimizer); the head kernel (73 % of
         # the bytes, produced first in backward) is one contiguous range at offset 0; the depthwise gradients, which
@@ -352,6 +385,8 @@ class Engine:
         s = BatchNorm(self, c3.y, 3, "batch_normalization_3", ACT_NONE, residual=px.y, res_bcast=True); n.append(s)
         d = Dropout(self, s.y, 0.1); n.append(d)
         self.stem_out = d.y
+        if self.backbone == "MobileNet":
+            return self._build_mobilenet(d.y)
         # ---- Xception entry flow, block 1
         e1 = SmallConv(self, d.y, 3, 32, 2, False, "block1_conv1"); n.append(e1)
         b1 = BatchNorm(self, e1.y, 32, "block1_conv1_bn", ACT_RELU); n.append(b1)
@@ -376,7 +411,25 @@ class Engine:
             prev_middle = node if blk[0] == "middle" else None
             x = node.y
         self.backbone_out = x
-        head = Dense(self, x, self.n_out, "FinalOutput"); n.append(head)
+        self._build_head(x)
+
+    def _build_mobilenet(self, x):
+        """keras.applications.mobilenet.MobileNet(include_top=False) behind the stem (spnet/models.py:346-355)."""
+        n = self.nodes
+        pad = PadSame(self, x, 3, 2); n.append(pad)
+        c1 = SmallConv(self, pad.y, 3, 32, 2, False, "conv1"); n.append(c1)
+        b1 = BatchNorm(self, c1.y, 32, "conv1_bn", ACT_RELU6); n.append(b1)
+        x, cin = b1.y, 32
+        for i, (cout, stride) in enumerate(MOBILENET_BLOCKS, 1):
+            blk = MobileBlock(self, x, i, cin, cout, stride); n.append(blk)
+            x, cin = blk.y, cout
+        self.backbone_out = x
+        self._build_head(x)
+
+    def _build_head(self, x):
+        tr = self.train_capable
+        B = self.B
+        head = Dense(self, x, self.n_out, "FinalOutput"); self.nodes.append(head)
         self.out = head.y
         if tr:
             self.y_true = self.new(B, self.n_out)
@@ -406,6 +459,9 @@ class Engine:
             self._infer_fresh = self._coeff_ver != self._wver[0]
         for node in self.nodes:
             node.fwd(training)
+        if self.sigmoid_cols is not None:
+            L.spnet_selective_sigmoid(L.ptr(self.out), None, self.B, self.n_out, self.sigmoid_cols[0],
+                                      self.sigmoid_cols[1], 0, _stream())
         if not training:
             self._coeff_ver = self._wver[0]
         return self.out
@@ -436,6 +492,9 @@ class Engine:
         """Back-propagates self.dout (filled by loss()) into self.grad.  on_node_done(node) is called
         after each node's launches are enqueued (used to start the gradient all-reduce early)."""
         g = self.dout
+        if self.sigmoid_cols is not None:      # through the sigmoid columns: dout *= y (1 - y)
+            L.spnet_selective_sigmoid(L.ptr(self.out), L.ptr(self.dout), self.B, self.n_out, self.sigmoid_cols[0],
+                                      self.sigmoid_cols[1], 1, _stream())
         self.deferred_wgrads = []
         if self._wT_ver[0] != self._tver[0]:    # weights were loaded / re-initialised since the last optimizer step
             self.refresh_transposes()
@@ -459,9 +518,10 @@ class Engine:
         return self._wT[wname]
 
     def refresh_transposes(self):
-        """One batched launch: W^T of every pointwise kernel whose layer back-propagates a data gradient, so
-        that dX = dY W^T reads its B operand in the forward (output-major) form.  ~160 MB of traffic per step
-        against 36 data-gradient GEMMs that each run 10 % faster."""
+        """One batched launch: W^T of the pointwise kernels whose data-gradient GEMM blends the BatchNorm backward
+        into its A operand (Pointwise.blend) -- that kernel exists in the forward operand form only.  (Round 2 also
+        measured ALL data-gradient GEMMs on transposed copies: the forward form is no faster than the K-major-B
+        form, 61.5 vs 69.2 us on 6144x728x728, so the other layers read W in place.)"""
         if not self._wT:
             self._wT_ver[0] = self._tver[0]
             return
@@ -825,11 +885,16 @@ class Dropout(Node):
 class Pointwise:
     """1x1 conv as GEMM over flattened pixels: y[M,cout] = x[M,cin] @ W[cin,cout]."""
 
-    def __init__(self, eng, M, cin, cout, wname, defer_wgrad=False):
+    def __init__(self, eng, M, cin, cout, wname, defer_wgrad=False, allow_blend=True):
         self.e, self.M, self.cin, self.cout = eng, M, cin, cout
         self.w = eng.P(wname)
         self.gw = eng.G(wname) if eng.train_capable else None
-        self.wT = eng.transposed(wname) if eng.train_capable else None     # [cout][cin], for the data gradient
+        # BatchNorm backward blended into the data-gradient GEMM's A operand (bwd_blend) instead of an elementwise
+        # pass of its own.  The blend reads BOTH g and yp once per COLUMN tile of dX, so it only pays while dX has
+        # one or two column tiles; measured on MI355X (tools/gemm_sweep.py blend, us incl. the BN kernels):
+        #   cin 128 (M 372,000): 242 -> 202     cin 256 (M 94,752): 163 -> 189     cin 728 (M 6,144): 85 -> 99
+        self.blend = bool(allow_blend and eng.train_capable and cin <= 128 and os.environ.get("SPNET_BN_BLEND", "1") != "0")
+        self.wT = eng.transposed(wname) if self.blend else None     # [cout][cin]: forward operand form for the blend
         self.defer_wgrad = defer_wgrad      # dW is left to Engine.flush_deferred_wgrads() (one batched launch)
 
     def fwd(self, x, y):
@@ -856,8 +921,8 @@ class Pointwise:
             with torch.cuda.stream(side):
                 _gemm(x, OUT_MAJOR, self.cin, dy, OUT_MAJOR, self.cout, self.gw, self.cout, self.cin, self.cout,
                       self.M, e, region=WS_GEMM2)
-        if dx is not None:      # dx[M,cin] = dy[M,cout] @ W^T[cout,cin]: the forward operand form on the transposed copy
-            _gemm(dy, K_MAJOR, self.cout, self.wT, OUT_MAJOR, self.cin, dx, self.cin, self.M, self.cin, self.cout, e)
+        if dx is not None:      # dx[M,cin] = dy[M,cout] @ W^T: W read in place as a K-major B operand
+            _gemm(dy, K_MAJOR, self.cout, self.w, K_MAJOR, self.cout, dx, self.cin, self.M, self.cin, self.cout, e)
 
 
     def bwd_blend(self, x, g, yp, bn, dyb, dx):
@@ -1068,7 +1133,7 @@ class SepConvBN:
             eng.dw_reduce_jobs.append((self.wpart, self.gwd, self.rows_src, 9 * cin))
             # BatchNorm-backward output dy: written once by the blending data-gradient GEMM for the weight gradient
             # (units with an activation behind their BN take the unfused path and use dbn / the incoming buffer)
-            self.blend = (act == ACT_NONE or mode != "apply") and os.environ.get("SPNET_BN_BLEND", "1") != "0"
+            self.blend = (act == ACT_NONE or mode != "apply") and self.pw.blend
             self.dyb = eng.new(B, H, W, cout) if self.blend else None
             self.dbn = None if (bwd_inplace or self.blend) else eng.new(B, H, W, cout)
         if src.bn is not None and hasattr(src, "owner"):
@@ -1190,7 +1255,7 @@ class StridedBlock(Node):
         if eng.train_capable:
             self.idx = torch.empty(B * OH * OW * (c2 // 4), device=eng.dev, dtype=torch.int32)
             self.dxs = eng.new(B, OH, OW, cin)
-            self.blend = os.environ.get("SPNET_BN_BLEND", "1") != "0"
+            self.blend = self.pwr.blend
             self.dyr = eng.new(B, OH, OW, c2) if self.blend else None
             self.dpool = eng.new(B, H, W, c2)
         else:
@@ -1251,6 +1316,93 @@ class ExitBlock(Node):
 
     def bwd(self, g):
         return self.u1.bwd(self.u2.bwd(g))
+
+
+class PadSame(Node):
+    """TF 'same' zero padding of a k x k / stride s convolution made explicit (extra row / column at the bottom /
+    right), so that the VALID direct-conv kernels serve MobileNet's conv1 (Conv2D(32, 3, strides 2, padding='same'))."""
+
+    def __init__(self, eng, x, k, s):
+        self.e, self.x = eng, x
+        self.pnames = []
+        B, H, W, C = x.shape
+        oh, ow = (H + s - 1) // s, (W + s - 1) // s
+        ph, pw = max((oh - 1) * s + k - H, 0), max((ow - 1) * s + k - W, 0)
+        self.pt, self.pl, self.H, self.W = ph // 2, pw // 2, H, W
+        self.y = torch.zeros(B, H + ph, W + pw, C, device=eng.dev, dtype=torch.float32)   # the border stays zero
+        self.dx = eng.new(*x.shape) if eng.train_capable else None
+
+    def _inner(self, t):
+        return t[:, self.pt:self.pt + self.H, self.pl:self.pl + self.W, :]
+
+    def fwd(self, training):
+        self._inner(self.y).copy_(self.x)
+
+    def bwd(self, g):
+        self.dx.copy_(self._inner(g))
+        return self.dx
+
+
+class MobileBlock(Node):
+    """One depthwise-separable block of keras MobileNet (_depthwise_conv_block): DepthwiseConv2D 3x3 (stride 1|2,
+    'same') - BN - relu6 - Conv2D 1x1 - BN - relu6.  Stride-1 depthwise layers run the LDS-tiled kernels (fused data +
+    weight gradient backward), stride-2 ones the strided gather kernels; both BatchNorms are materialised."""
+
+    def __init__(self, eng, x, i, cin, cout, stride):
+        self.e, self.x, self.cin, self.cout, self.stride = eng, x, cin, cout, stride
+        self.pnames = ["conv_dw_%d" % i, "conv_dw_%d_bn" % i, "conv_pw_%d" % i, "conv_pw_%d_bn" % i]
+        B, H, W, _ = x.shape
+        self.H, self.W = H, W
+        OH, OW = (H + stride - 1) // stride, (W + stride - 1) // stride
+        self.M = B * OH * OW
+        self.wd = eng.P("conv_dw_%d/depthwise_kernel" % i)
+        self.z = eng.new(B, OH, OW, cin)
+        self.bn_dw = BatchNorm(eng, self.z, cin, "conv_dw_%d_bn" % i, ACT_RELU6)
+        self.pw = Pointwise(eng, self.M, cin, cout, "conv_pw_%d/kernel" % i, allow_blend=False)
+        self.yp = eng.new(B, OH, OW, cout)
+        self.bn = BN(eng, cout, self.M, "conv_pw_%d_bn" % i)
+        self.y = eng.new(B, OH, OW, cout)
+        if eng.train_capable:
+            self.gwd = eng.G("conv_dw_%d/depthwise_kernel" % i)
+            self.da = eng.new(B, OH, OW, cin)
+            self.dx = eng.new(B, H, W, cin)
+            if stride == 1:
+                self.wpart = eng.new(L.spnet_dwconv3x3_tiled_bwd_ws(B, H, W, cin))
+                eng.dw_reduce_jobs.append((self.wpart, self.gwd, L.spnet_dwconv3x3_tiled_rows(B, H, W, cin), 9 * cin))
+            else:
+                self.ws = eng.new(L.spnet_dwconv3x3_strided_ws(B, H, W, cin, stride))
+
+    def fwd(self, training):
+        e = self.e
+        if self.stride == 1:
+            L.spnet_dwconv3x3_tiled_fwd(L.ptr(self.x), L.ptr(self.wd), L.ptr(self.z), e.B, self.H, self.W, self.cin, 0,
+                                        None, None, _stream())
+        else:
+            L.spnet_dwconv3x3_strided(0, L.ptr(self.x), L.ptr(self.wd), L.ptr(self.z), e.B, self.H, self.W, self.cin,
+                                      self.stride, None, _stream())
+        self.bn_dw.fwd(training)
+        if training:
+            self.bn.finalize(self.pw.fwd_colstats(self.bn_dw.y, self.yp))
+        else:
+            self.pw.fwd(self.bn_dw.y, self.yp)
+            self.bn.infer()
+        self.bn.apply(self.yp, self.y, ACT_RELU6)
+
+    def bwd(self, g):
+        e = self.e
+        dy = self.bn.bwd_full(self.yp, g, g, ACT_RELU6)           # in place: g is not needed again
+        self.pw.bwd(self.bn_dw.y, dy, self.da)
+        dz = self.bn_dw.bwd(self.da)
+        if self.stride == 1:
+            L.spnet_dwconv3x3_tiled_bwd(L.ptr(dz), L.ptr(self.x), L.ptr(self.wd), L.ptr(self.dx), None, e.B, self.H,
+                                        self.W, self.cin, 0, None, L.ptr(self.wpart), None, None, None, None, None, None,
+                                        _stream())
+        else:
+            L.spnet_dwconv3x3_strided(1, L.ptr(dz), L.ptr(self.wd), L.ptr(self.dx), e.B, self.H, self.W, self.cin,
+                                      self.stride, None, _stream())
+            L.spnet_dwconv3x3_strided(2, L.ptr(self.x), L.ptr(dz), L.ptr(self.gwd), e.B, self.H, self.W, self.cin,
+                                      self.stride, L.ptr(self.ws), _stream())
+        return self.dx
 
 
 class Dense(Node):

@@ -37,37 +37,22 @@ def _overlaps(a, b):
     return not (a[2] < b[0] or a[0] > b[2] or a[3] < b[1] or a[1] > b[3])
 
 
-def _draw_waves(d, rs):
+def draw_params(seed):
+    """All random PARAMETERS of one frame, drawn in the generator's order from RandomState(seed):
+    waves = (amp, wavelength, thickness, slope, spacing) (draw_waves, gen_fake_espi.py:60-80) and
+    nodes = [(cx, cy, a, b, angle, rings, ring_start)] (draw_antinodes :145-206 incl. the non-overlap rejection
+    loop, draw_rings' rand_start :107).  Returns (waves, nodes, rs) -- rs continues with the noise / dropout draws
+    of the host rasteriser."""
+    rs = np.random.RandomState(seed)
     amp = rs.randint(10, 201)
     wavelength = rs.randint(100, IM_W // 2 + 1)
     thick = rs.randint(15, 41)
     slope = 3 * (rs.rand() - .5)
     lo = thick + thick * int(abs(1.5 * slope))
     spacing = rs.randint(lo, max(lo, IM_H // 3) + 1)
-    xs = np.arange(IM_W)
-    base = slope * xs + amp * np.cos(xs / wavelength)
-    for j in range(60 + IM_H // spacing):
-        y0 = j * spacing - IM_W * abs(slope)
-        ys = (y0 + base).astype(np.int64)
-        if ys.max() < -thick or ys.min() > IM_H + thick:
-            continue
-        d.line(list(zip(xs.tolist(), ys.tolist())), fill=0, width=thick, joint="curve")
-
-
-def _draw_rings(d, rs, center, axes, angle, rings):
-    nwb = max(2 * rings, 1)
-    thick = max(int(round(min(axes) / nwb)), 1)
-    start = rs.randint(0, 2)
-    for j in range(nwb):
-        col = 0 if (start + j) % 2 == 0 else 138
-        ax = [a * (j + 1) / (nwb + 1) for a in axes]
-        pts = _ellipse_pts(center, ax, angle)
-        d.line(pts + [pts[0]], fill=col, width=thick, joint="curve")
-
-
-def _draw_antinodes(d, rs, count):
-    boxes, rows = [], []
-    for _ in range(count):
+    waves = (amp, wavelength, thick, slope, spacing)
+    boxes, nodes = [], []
+    for _ in range(rs.randint(1, 8)):
         axes = sorted((rs.randint(15, int(IM_W / 3.5) + 1), rs.randint(15, int(IM_H / 3.5) + 1)), reverse=True)
         rings = rs.randint(1, min(axes[1] // 8, 11) + 1)
         if axes[1] / rings < MIN_LINE_WIDTH:
@@ -86,24 +71,87 @@ def _draw_antinodes(d, rs, count):
             angle = rs.randint(1, 181)
             box = _ellipse_box(center, axes, angle)
         if tries < 2000:
-            _draw_rings(d, rs, center, axes, angle, rings)
-            rows.append((center[0], center[1], axes[0], axes[1], angle, rings))
+            nodes.append((center[0], center[1], axes[0], axes[1], angle, rings, rs.randint(0, 2)))
             boxes.append(box)
-    return rows
+    return waves, nodes, rs
+
+
+def _draw_waves(d, waves):
+    amp, wavelength, thick, slope, spacing = waves
+    xs = np.arange(IM_W)
+    base = slope * xs + amp * np.cos(xs / wavelength)
+    for j in range(60 + IM_H // spacing):
+        y0 = j * spacing - IM_W * abs(slope)
+        ys = (y0 + base).astype(np.int64)
+        if ys.max() < -thick or ys.min() > IM_H + thick:
+            continue
+        d.line(list(zip(xs.tolist(), ys.tolist())), fill=0, width=thick, joint="curve")
+
+
+def _draw_rings(d, center, axes, angle, rings, start):
+    nwb = max(2 * rings, 1)
+    thick = max(int(round(min(axes) / nwb)), 1)
+    for j in range(nwb):
+        col = 0 if (start + j) % 2 == 0 else 138
+        ax = [a * (j + 1) / (nwb + 1) for a in axes]
+        pts = _ellipse_pts(center, ax, angle)
+        d.line(pts + [pts[0]], fill=col, width=thick, joint="curve")
+
+
+def raster_host(waves, nodes):
+    """The noise-free canvas of one frame, rasterised with PIL: uint8 [384,512]."""
+    img = Image.new("L", (IM_W, IM_H), 128)
+    d = ImageDraw.Draw(img)
+    _draw_waves(d, waves)
+    for cx, cy, a, b, angle, rings, start in nodes:
+        _draw_rings(d, (cx, cy), (a, b), angle, rings, start)
+    return np.asarray(img, dtype=np.uint8)
 
 
 def gen_frame(seed):
     """One frame: (uint8 [384,512] image, [(cx,cy,a,b,angle,rings), ...])."""
-    rs = np.random.RandomState(seed)
-    img = Image.new("L", (IM_W, IM_H), 128)
-    d = ImageDraw.Draw(img)
-    _draw_waves(d, rs)
-    rows = _draw_antinodes(d, rs, rs.randint(1, 8))
-    a = np.asarray(img, dtype=np.float32)
+    waves, nodes, rs = draw_params(seed)
+    a = raster_host(waves, nodes).astype(np.float32)
     noise = np.clip(np.rint(rs.normal(40, 40, a.shape)), 0, 255)      # cv2.randn into a uint8 image saturates
     a = np.minimum(a + noise, 255)
     a *= rs.randint(0, 2, a.shape)                                      # drop half of the pixels
-    return a.astype(np.uint8), rows
+    return a.astype(np.uint8), [n[:6] for n in nodes]
+
+
+def frame_seeds(n, seed):
+    return [seed * 1000003 + i for i in range(n)]
+
+
+def generate_device(n, seed=0, device="cuda:0", noise=True, want_u8=False, chunk=1024):
+    """n frames rasterised directly in HBM (csrc/espi.hip): the SAME per-frame parameters as generate(n, seed)
+    (so the labels are identical), pixels from the analytic device rasteriser, sensor noise / dropout from a
+    counter-based RNG.  Returns (float32 device tensor [n,384,512,1] in [-1,1], label rows[, uint8 device tensor])."""
+    import torch
+    from . import _lib as L
+    dev = torch.device(device)
+    X = torch.empty((n, IM_H, IM_W, 1), dtype=torch.float32, device=dev)
+    U = torch.empty((n, IM_H, IM_W), dtype=torch.uint8, device=dev) if want_u8 else None
+    labels = []
+    st = torch.cuda.current_stream(dev).cuda_stream
+    for lo in range(0, n, chunk):
+        hi = min(n, lo + chunk)
+        waves = np.zeros((hi - lo, 5), np.float32)
+        nodes = np.zeros((hi - lo, 7, 8), np.float32)
+        nn = np.zeros(hi - lo, np.int32)
+        for k, s in enumerate(frame_seeds(n, seed)[lo:hi]):
+            w, nd, _ = draw_params(s)
+            waves[k] = w
+            nn[k] = len(nd)
+            for j, node in enumerate(nd):
+                nodes[k, j, :7] = node
+                nodes[k, j, 7] = 1.0
+            labels.append([node[:6] for node in nd])
+        wd, ndd, nnd = (torch.from_numpy(a).to(dev) for a in (waves, nodes, nn))
+        L.spnet_fake_espi(wd.data_ptr(), ndd.data_ptr(), nnd.data_ptr(), hi - lo, IM_H, IM_W,
+                          (seed * 2654435761 + lo * 97 + 12345) & 0xFFFFFFFF, int(bool(noise)), X[lo:hi].data_ptr(),
+                          U[lo:hi].data_ptr() if U is not None else None, st)
+        torch.cuda.current_stream(dev).synchronize()       # wd / ndd / nnd are freed on return
+    return (X, labels, U) if want_u8 else (X, labels)
 
 
 def rows_to_csv(rows):
@@ -114,7 +162,7 @@ def rows_to_csv(rows):
 
 def generate(n, seed=0, workers=None):
     """n frames -> (uint8 [n,384,512], list of label rows).  Deterministic in (n, seed)."""
-    seeds = [seed * 1000003 + i for i in range(n)]
+    seeds = frame_seeds(n, seed)
     workers = workers or min(os.cpu_count() or 1, 16)
     if workers > 1 and n >= 16:
         p = Pool(workers)

@@ -83,6 +83,13 @@ class SelectiveSigmoid:
         self.sigmoid_stretch = 1
 
     def __call__(self, x):
+        torch = _torch()
+        if isinstance(x, torch.Tensor) and x.is_cuda and self.end is None and x.dtype == torch.float32:
+            from . import _lib as L             # device tensors: the HIP kernel, out of place like the Keras layer
+            y = x.contiguous().clone()
+            L.spnet_selective_sigmoid(y.data_ptr(), None, y.shape[0], y.shape[1], self.start, self.skip, 0,
+                                      torch.cuda.current_stream().cuda_stream)
+            return y
         y = np.array(x, dtype=np.float32, copy=True)
         sl = slice(self.start, self.end, self.skip)
         y[:, sl] = self.sigmoid_stretch / (1.0 + np.exp(-y[:, sl]))
@@ -125,16 +132,23 @@ class _Optimizer:
         self.lr = lr
 
 
-def keras_layer_table():
+def keras_layer_table(basemodel=None):
     """Ordered (layer_name, [weight-name prefixes]) list approximating base_model.layers of the
     reference (144 entries: 13 stem layers incl. the input + 131 Xception layers; run log
     'Freezing 0 / 144 layers').  Used only to translate freeze_fac into a set of frozen tensors."""
-    from .engine import xception_plan
+    from .engine import MOBILENET_BLOCKS, xception_plan
     t = [("input_1", []), ("conv2d_1", ["conv2d_1"]), ("average_pooling2d_1", []),
          ("batch_normalization_1", ["batch_normalization_1"]), ("leaky_re_lu_1", []), ("conv2d_2", ["conv2d_2"]),
          ("batch_normalization_2", ["batch_normalization_2"]), ("leaky_re_lu_2", []), ("conv2d_3", ["conv2d_3"]),
          ("batch_normalization_3", ["batch_normalization_3"]), ("average_pooling2d_2", []), ("add_1", []),
          ("dropout_1", [])]
+    if (basemodel or cf.basemodel) == 'MobileNet':       # keras.applications.mobilenet layer order
+        t += [("conv1", ["conv1"]), ("conv1_bn", ["conv1_bn"]), ("conv1_relu", [])]
+        for i in range(1, len(MOBILENET_BLOCKS) + 1):
+            for kind in ("dw", "pw"):
+                n = "conv_%s_%d" % (kind, i)
+                t += [(n, [n]), (n + "_bn", [n + "_bn"]), (n + "_relu", [])]
+        return t
     for n in ("block1_conv1", "block1_conv2"):
         t += [(n, [n]), (n + "_bn", [n + "_bn"]), (n + "_act", [])]
 
@@ -168,8 +182,10 @@ class Model:
         # Select this rank's GPU (and join the torchrun process group) BEFORE anything is allocated: every plan,
         # callback buffer and kernel launch of this process then lives on cuda:LOCAL_RANK.
         self.rank, _, self.world = parallel.init_distributed()
-        if cf.basemodel != 'Xception':
-            raise NotImplementedError("this build implements the Xception backbone (cf.basemodel=%r)" % cf.basemodel)
+        if cf.basemodel not in ('Xception', 'MobileNet'):
+            raise NotImplementedError("this build implements the Xception and MobileNet backbones (cf.basemodel=%r)"
+                                      % cf.basemodel)
+        self.basemodel = cf.basemodel
         self.input_shape = tuple(int(v) for v in input_shape)
         H, W = self.input_shape[0], self.input_shape[1]
         self.H, self.W, self.Y0size = H, W, int(Y0size)
@@ -183,8 +199,15 @@ class Model:
         self.optimizer = _Optimizer(1e-5)
         self.trainable = True
         self.stop_training = False
-        self.layers = [name for name, _ in keras_layer_table()] + ["flatten_1", "FinalOutput"]
+        self.layers = [name for name, _ in keras_layer_table(self.basemodel)] + ["flatten_1", "FinalOutput"]
         self.freeze_fac = freeze_fac
+        # 'compound' head (models.py:379-386): Dense(n_preds, sigmoid) 'SigmoidOutput' + Dense(rest) 'DenseOutput',
+        # concatenated and re-ordered by InterleaveColumns(start_index=cf.ind_noobj) = one [K, Y0size] dense layer in
+        # FINAL column order whose columns ind_noobj::vars_per_pred pass through a sigmoid (engine: sigmoid_cols).
+        self.compound = (cf.model_type == 'compound')
+        if self.compound and self.Y0size % cf.vars_per_pred != 0:
+            raise ValueError("Y0size (=" + str(self.Y0size) + ") must be a multiple of cf.vars_per_pred (=" +
+                             str(cf.vars_per_pred) + ")")
         self._Engine = Engine
         self._engines = {}
         self._root = None
@@ -207,7 +230,9 @@ class Model:
                 for a in ("grad", "m", "v"):       # optimizer state lives beside the weights it updates
                     setattr(root, a, torch.zeros(root.n_theta, device=root.dev, dtype=torch.float32))
             eng = self._Engine(self.H, self.W, batch, n_out=self.Y0size, device=self.device, loss_type=cf.loss_type,
-                               seed=self.seed, train=train, share_from=root, rank=self.rank)
+                               seed=self.seed, train=train, share_from=root, rank=self.rank,
+                               sigmoid_cols=(cf.ind_noobj, cf.vars_per_pred) if self.compound else None,
+                               backbone=self.basemodel)
             if root is None:
                 self._root = eng
             self._engines[key] = eng
@@ -218,7 +243,7 @@ class Model:
     def _apply_freeze(self, freeze_fac):
         torch = _torch()
         self._frozen_prefixes = []
-        table = keras_layer_table()
+        table = keras_layer_table(self.basemodel)
         n_freeze = int(len(table) * freeze_fac)
         if freeze_fac == 1.0:
             n_freeze = len(table)
@@ -235,16 +260,43 @@ class Model:
 
     # -- weights ----------------------------------------------------------------------------------
     def get_weights(self):
-        return [v.numpy() for v in self._root.state_dict().values()]
+        return [v.numpy() for v in self.state_dict().values()]
 
     def set_weights(self, weights):
-        names = self._root.spec_order
-        self._root.load_state_dict(dict(zip(names, weights)))
+        self.load_state_dict(dict(zip(list(self.state_dict().keys()), weights)))
+
+    def _head_columns(self):
+        """(sigmoid columns, dense columns) of the engine's FinalOutput kernel for the 'compound' head."""
+        sig = list(range(cf.ind_noobj, self.Y0size, cf.vars_per_pred))
+        return sig, [c for c in range(self.Y0size) if c not in set(sig)]
 
     def state_dict(self):
-        return self._root.state_dict()
+        """name -> CPU tensor.  'compound' models expose the reference's two head layers (SigmoidOutput, DenseOutput:
+        the column blocks InterleaveColumns interleaves) instead of the engine's single FinalOutput."""
+        sd = self._root.state_dict()
+        if not self.compound:
+            return sd
+        sig, rest = self._head_columns()
+        out = type(sd)()
+        for k, v in sd.items():
+            if k == "FinalOutput/kernel":
+                out["SigmoidOutput/kernel"], out["DenseOutput/kernel"] = v[:, sig].contiguous(), v[:, rest].contiguous()
+            elif k == "FinalOutput/bias":
+                out["SigmoidOutput/bias"], out["DenseOutput/bias"] = v[sig].contiguous(), v[rest].contiguous()
+            else:
+                out[k] = v
+        return out
 
     def load_state_dict(self, sd):
+        if self.compound and "SigmoidOutput/kernel" in sd:
+            torch = _torch()
+            sig, rest = self._head_columns()
+            sd = dict(sd)
+            K = sd["SigmoidOutput/kernel"].shape[0]
+            w, b = torch.empty(K, self.Y0size), torch.empty(self.Y0size)
+            w[:, sig], w[:, rest] = torch.as_tensor(sd.pop("SigmoidOutput/kernel")), torch.as_tensor(sd.pop("DenseOutput/kernel"))
+            b[sig], b[rest] = torch.as_tensor(sd.pop("SigmoidOutput/bias")), torch.as_tensor(sd.pop("DenseOutput/bias"))
+            sd["FinalOutput/kernel"], sd["FinalOutput/bias"] = w, b
         self._root.load_state_dict(sd)
 
     def count_params(self):
@@ -255,20 +307,21 @@ class Model:
     def save_weights(self, path):
         from safetensors.torch import save_file
         meta = {"format": "spnet_amd-weights-v1", "input_shape": json.dumps(self.input_shape), "Y0size": str(self.Y0size),
-                "basemodel": cf.basemodel}
-        save_file({k: v.contiguous() for k, v in self._root.state_dict().items()}, path, metadata=meta)
+                "basemodel": self.basemodel}
+        save_file({k: v.contiguous() for k, v in self.state_dict().items()}, path, metadata=meta)
 
     def load_weights(self, path, by_name=False):
         from safetensors.torch import load_file
-        self._root.load_state_dict(load_file(path))
+        self.load_state_dict(load_file(path))
 
     def save(self, path):
         """'Whole model' file = weights + the configuration needed to rebuild the plan."""
         from safetensors.torch import save_file
         meta = {"format": "spnet_amd-model-v1", "input_shape": json.dumps(self.input_shape), "Y0size": str(self.Y0size),
-                "basemodel": cf.basemodel, "model_type": cf.model_type, "loss_type": cf.loss_type,
+                "basemodel": self.basemodel, "model_type": "compound" if self.compound else cf.model_type,
+                "loss_type": cf.loss_type,
                 "optimizer_iterations": str(self._root.t)}
-        save_file({k: v.contiguous() for k, v in self._root.state_dict().items()}, path, metadata=meta)
+        save_file({k: v.contiguous() for k, v in self.state_dict().items()}, path, metadata=meta)
 
     # -- data plumbing ----------------------------------------------------------------------------
     def set_train_frames(self, host_array, device_tensor):
@@ -439,11 +492,8 @@ def create_model_functional(X, Y0size=576, freeze_fac=0.75, quick_setup=False):
     (models.py:302-424)."""
     print("Using functional API model, cf.basemodel =", cf.basemodel)
     print("X[0].shape = ", X[0].shape)
-    if cf.model_type == 'compound':
-        raise NotImplementedError("model_type 'compound' (sigmoid head + InterleaveColumns) is a legacy head of the "
-                                  "reference; use 'monolithic'/'big' with loss_type 'hybrid' instead")
     model = Model(X[0].shape, Y0size=Y0size, freeze_fac=freeze_fac)
-    n_layers = len(keras_layer_table())
+    n_layers = len(keras_layer_table(model.basemodel))
     print("Freezing ", int(n_layers * freeze_fac), "/", n_layers, " layers of base_model")
     total, trainable = model.count_params()
     frozen = 0
@@ -496,7 +546,15 @@ def load_model(path, custom_objects=None):
     with safe_open(path, framework="pt") as f:
         meta = f.metadata() or {}
     shape = tuple(json.loads(meta.get("input_shape", "[331, 331, 1]")))
-    model = Model(shape, Y0size=int(meta.get("Y0size", 576)), freeze_fac=0.0)
+    saved_type, old_type, old_base = meta.get("model_type"), cf.model_type, cf.basemodel
+    try:                                   # head variant and backbone are part of the saved model, not of the caller's config
+        if saved_type in ("compound", "monolithic", "big"):
+            cf.model_type = saved_type
+        if meta.get("basemodel") in ("Xception", "MobileNet"):
+            cf.basemodel = meta["basemodel"]
+        model = Model(shape, Y0size=int(meta.get("Y0size", 576)), freeze_fac=0.0)
+    finally:
+        cf.model_type, cf.basemodel = old_type, old_base
     model.load_weights(path)
     return model
 

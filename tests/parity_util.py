@@ -30,10 +30,10 @@ def randomize_bn(P, gen):
     return P
 
 
-def make_case(H, W, B, seed):
+def make_case(H, W, B, seed, basemodel="Xception"):
     """Seeded weights (Keras initialisers + randomised BatchNorm state), frames, targets and the engine's
     dropout mask for one (geometry, seed).  Returns P, X, Y, mask, drop_seed."""
-    P = randomize_bn(T.init_params(H, W, seed=1000 + seed), torch.Generator().manual_seed(seed))
+    P = randomize_bn(T.init_params(H, W, seed=1000 + seed, basemodel=basemodel), torch.Generator().manual_seed(seed))
     rs = np.random.RandomState(seed)
     X = torch.tensor(rs.rand(B, H, W, 1) * 2 - 1, dtype=torch.float32)
     Y = torch.tensor(rs.rand(B, 576), dtype=torch.float32)
@@ -49,13 +49,13 @@ def rel_err(got, ref):
     return float(np.abs(np.asarray(got, dtype=np.float64) - ref).max()) / max(float(np.abs(ref).max()), 1e-12)
 
 
-def oracle_grads(P, X, Y, mask, double, decisions=None, loss_type="same"):
+def oracle_grads(P, X, Y, mask, double, decisions=None, loss_type="same", sigmoid_cols=None):
     """(data_loss, {name: grad}, y_pred, params-with-updated-moving-stats) of the oracle in fp32 or fp64."""
     if double:
-        tr = T.Trainer({k: v.double() for k, v in P.items()}, loss_type=loss_type)
+        tr = T.Trainer({k: v.double() for k, v in P.items()}, loss_type=loss_type, sigmoid_cols=sigmoid_cols)
         data, _, g, yp = tr.grads(X.double(), Y.double(), drop_mask=mask.double(), include_l2=False, decisions=decisions)
     else:
-        tr = T.Trainer({k: v.clone() for k, v in P.items()}, loss_type=loss_type)
+        tr = T.Trainer({k: v.clone() for k, v in P.items()}, loss_type=loss_type, sigmoid_cols=sigmoid_cols)
         data, _, g, yp = tr.grads(X, Y, drop_mask=mask, include_l2=False, decisions=decisions)
     return data, g, yp, tr.P
 
@@ -78,9 +78,17 @@ def device_decisions(eng):
         ss = cpu(unit.bn.ss).double()
         return (cpu(unit.yp).double() * ss[:C] + ss[C:]) > 0
 
+    def state6(y):                       # ReLU6: 0 = clipped to 0, 1 = linear, 2 = clipped to 6 (T.Decisions.act6)
+        y = cpu(y)
+        return (y > 0).to(torch.uint8) + (y >= 6).to(torch.uint8)
+
     relu, pool = [], []
     for node in eng.nodes:
-        if isinstance(node, E.BatchNorm) and node.act != E.ACT_NONE:
+        if isinstance(node, E.BatchNorm) and node.act == E.ACT_RELU6:
+            relu.append(state6(node.y))
+        elif isinstance(node, E.MobileBlock):
+            relu += [state6(node.bn_dw.y), state6(node.y)]
+        elif isinstance(node, E.BatchNorm) and node.act != E.ACT_NONE:
             relu.append(cpu(node.y) > 0)
         elif isinstance(node, E.StridedBlock):
             if node.u1.relu_in:
@@ -96,13 +104,14 @@ def device_decisions(eng):
     return T.Decisions(relu, pool)
 
 
-def assert_gradients_match(eng, P, X, Y, mask, tol=5e-3, tie=1e-4, loss_type="same"):
+def assert_gradients_match(eng, P, X, Y, mask, tol=5e-3, tie=1e-4, loss_type="same", sigmoid_cols=None):
     """Every parameter gradient of the engine's last forward/backward against the fp64 oracle evaluated on the
     device's own discrete decisions: max|diff| <= tol * max|ref| on EVERY tensor, and every decision in which the
     device departs from the oracle's own must have been a tie (|pre-activation| or window gap <= tie x the largest
     value of that tensor).  Returns (data_loss64, y_pred64, params64, decisions)."""
     dec = device_decisions(eng)
-    data64, g64, yp64, P64 = oracle_grads(P, X, Y, mask, double=True, decisions=dec, loss_type=loss_type)
+    data64, g64, yp64, P64 = oracle_grads(P, X, Y, mask, double=True, decisions=dec, loss_type=loss_type,
+                                          sigmoid_cols=sigmoid_cols)
     assert dec._ri == len(dec.relu) and dec._pi == len(dec.pool), "decision sites out of step with the oracle"
     far = [f for f in dec.flips if f[2] > tie]
     assert not far, "device decisions differ from the oracle's away from ties: %s" % far[:8]

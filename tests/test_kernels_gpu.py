@@ -142,32 +142,6 @@ def test_gemm_rejects_misaligned(L):
         L.spnet_gemm_f32(a.data_ptr(), 0, 6, a.data_ptr(), 1, 6, a.data_ptr(), 6, 8, 6, 6, 0, None, 0, None, 0, st())
 
 
-@pytest.mark.parametrize("B,H,W,C", [(2, 12, 16, 728), (3, 7, 5, 64), (1, 93, 125, 128), (2, 6, 8, 1536), (1, 1, 1, 8)])
-@pytest.mark.parametrize("relu_in", [0, 1])
-def test_dwconv(L, B, H, W, C, relu_in):
-    rs = np.random.RandomState(C + H)
-    x = torch.tensor(rs.randn(B, H, W, C), dtype=torch.float32, requires_grad=True)
-    w = torch.tensor(rs.randn(3, 3, C) * 0.3, dtype=torch.float32, requires_grad=True)
-    add = torch.tensor(rs.randn(B, H, W, C), dtype=torch.float32)
-    xin = torch.relu(x) if relu_in else x
-    y = T.dwconv3x3(xin, w)
-    dy = torch.tensor(rs.randn(B, H, W, C), dtype=torch.float32)
-    y.backward(dy)
-    xd, wd, dyd = x.detach().cuda(), w.detach().cuda(), dy.cuda()
-    yd = torch.empty_like(xd)
-    L.spnet_dwconv3x3_fwd(xd.data_ptr(), wd.data_ptr(), yd.data_ptr(), B, H, W, C, relu_in, st())
-    close(yd, y.detach(), rtol=1e-5, atol=1e-5)
-    dxd = torch.empty_like(xd)
-    addd = add.cuda()
-    L.spnet_dwconv3x3_bwd_data(dyd.data_ptr(), wd.data_ptr(), dxd.data_ptr(), B, H, W, C, relu_in,
-                               xd.data_ptr() if relu_in else None, addd.data_ptr(), st())
-    close(dxd, x.grad + add, rtol=1e-5, atol=1e-5)
-    ws = torch.empty(L.spnet_dwconv3x3_bwd_weight_ws(B, H, W, C), device="cuda")
-    dwd = torch.empty(3, 3, C, device="cuda")
-    L.spnet_dwconv3x3_bwd_weight(xd.data_ptr(), dyd.data_ptr(), dwd.data_ptr(), B, H, W, C, relu_in, ws.data_ptr(), st())
-    close(dwd, w.grad, rtol=1e-4, atol=1e-4 * np.sqrt(B * H * W))
-
-
 @pytest.mark.parametrize("B,H,W,C", [(2, 12, 16, 728), (3, 7, 5, 64), (1, 93, 125, 128), (2, 6, 8, 1536), (1, 1, 1, 8),
                                      (2, 24, 32, 256), (1, 47, 63, 128), (2, 13, 17, 40)])
 @pytest.mark.parametrize("relu_in", [0, 1])
@@ -447,24 +421,9 @@ def test_conv3x3_implicit_gemm(L, B, H, W):
         L.spnet_conv3x3_wgrad(xd.data_ptr(), dyd.data_ptr(), dwd.data_ptr(), B, H, W, 32, 64, ws.data_ptr(), n - 1, st())
 
 
-def test_im2col_col2im_gather_scatter(L):
+def test_gather_scatter_stride2(L):
     rs = np.random.RandomState(9)
-    B, H, W, C = 2, 9, 11, 32
-    x = torch.tensor(rs.randn(B, H, W, C), dtype=torch.float32, requires_grad=True)
-    w = torch.tensor(rs.randn(3, 3, C, 64) * 0.1, dtype=torch.float32)
-    y = T.conv2d(x, w, 1, "valid")
-    dy = torch.tensor(rs.randn(*y.shape), dtype=torch.float32)
-    y.backward(dy)
-    M = B * (H - 2) * (W - 2)
-    col = torch.empty(M, 9 * C, device="cuda")
-    xd = x.detach().cuda()
-    L.spnet_im2col3x3(xd.data_ptr(), col.data_ptr(), B, H, W, C, st())
-    got = (col.cpu().double() @ w.reshape(9 * C, 64).double()).reshape(y.shape)
-    close(got, y.detach(), rtol=1e-5, atol=1e-5)
-    dcol = (dy.reshape(M, 64).double() @ w.reshape(9 * C, 64).double().T).float().cuda()
-    dx = torch.empty(B, H, W, C, device="cuda")
-    L.spnet_col2im3x3(dcol.data_ptr(), dx.data_ptr(), B, H, W, C, st())
-    close(dx, x.grad, rtol=1e-5, atol=1e-5)
+    B, C = 2, 32
     for (h, w_) in [(9, 11), (8, 6)]:
         xx = dev(rs.randn(B, h, w_, C))
         xs = torch.empty(B, (h + 1) // 2, (w_ + 1) // 2, C, device="cuda")
@@ -612,3 +571,66 @@ def test_gemm_with_batchnorm_backward_blended_into_the_a_operand(L, M, N, K, til
     L.spnet_gemm_f32_bnblend(gd.data_ptr(), ypd.data_ptr(), coef.data_ptr(), cld, K, wtd.data_ptr(), N, dx2.data_ptr(), N,
                              M, N, K, tile, None, st())
     assert torch.equal(dx, dx2)
+
+
+def test_gaussian_blur_matches_opencv_semantics(L):
+    """cv2.GaussianBlur(img, (k,k), 0): fixed small kernels for k <= 7, reflect-101 borders (scipy 'mirror')."""
+    from scipy.ndimage import correlate1d
+    rs = np.random.RandomState(2)
+    N, H, W = 5, 37, 53
+    x = rs.rand(N, H, W).astype(np.float32) * 2 - 1
+    ks = np.array([0, 3, 7, 5, 3], np.int32)
+    taps = {3: [0.25, 0.5, 0.25], 5: [0.0625, 0.25, 0.375, 0.25, 0.0625],
+            7: [0.03125, 0.109375, 0.21875, 0.28125, 0.21875, 0.109375, 0.03125]}
+    want = x.copy().astype(np.float64)
+    for n in range(N):
+        if ks[n]:
+            k = np.array(taps[int(ks[n])])
+            want[n] = correlate1d(correlate1d(x[n].astype(np.float64), k, axis=1, mode="mirror"), k, axis=0, mode="mirror")
+    xd, kd = dev(x), torch.from_numpy(ks).cuda()
+    out = torch.full((N, H, W), float("nan"), device="cuda")
+    L.spnet_gaussian_blur(xd.data_ptr(), out.data_ptr(), N, H, W, kd.data_ptr(), st())
+    close(out, want, rtol=1e-6, atol=1e-6)
+    assert torch.equal(out[0], xd[0])                      # k = 0: the frame passes through unchanged
+
+
+def test_augmenter_real_blur_flag(L):
+    """Default = the reference's no-op blur; real_blur=True blurs exactly the frames whose gate opened, with the same
+    RNG consumption (so everything else about the augmented set is unchanged)."""
+    import random
+    from spnet_amd.augmentation import DeviceAugmenter
+    X = torch.tensor(np.random.RandomState(7).rand(24, 64, 80, 1).astype(np.float32) * 2 - 1).cuda()
+    outs, rng = [], []
+    for flag in (False, True):
+        aug = DeviceAugmenter(X, real_blur=flag)
+        np.random.seed(11)
+        random.seed(11)
+        params = aug.draw(list(range(24)))
+        o = torch.empty_like(X)
+        aug.apply(params, o)
+        outs.append(o.cpu().numpy())
+        rng.append(np.random.rand())
+    assert rng[0] == rng[1]
+    ks = params["ksize"]
+    assert set(np.unique(ks)) <= {0, 3, 7} and (ks > 0).any() and (ks == 0).any()
+    for n in range(24):
+        same = np.array_equal(outs[0][n], outs[1][n])
+        assert same == (ks[n] == 0), (n, ks[n])
+
+
+def test_calc_errors_on_device_matches_host(L):
+    """diagnostics.calc_errors(device=True): integer counts identical to the host loop (which is pinned by the
+    reference's own calc_errors through tests/golden), pixel errors to rounding."""
+    from spnet_amd import diagnostics as D
+    rs = np.random.RandomState(9)
+    N = 37
+    Yt = rs.rand(N, 576).astype(np.float32) * 20
+    Yp = Yt + rs.randn(N, 576).astype(np.float32)
+    Yt[:, 6::8] = (rs.rand(N, 72) > 0.6)
+    Yp[:, 6::8] = rs.rand(N, 72)
+    Yp[0, 6] = 0.5                    # round-half-even cases of int(round(.))
+    Yp[1, 6] = 1.5
+    host, devr = D.calc_errors(Yp, Yt), D.calc_errors(Yp, Yt, device=True)
+    assert host[:7] == devr[:7] and sum(host[:7]) > 0
+    np.testing.assert_allclose(devr[7], host[7], rtol=1e-6)
+    assert host[8] == devr[8]

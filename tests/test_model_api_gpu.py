@@ -168,3 +168,51 @@ def test_inference_coefficients_follow_weight_changes(data):
     ref = M.build_model(X, Y0size=576, freeze_fac=0.0)
     ref.set_weights([a * 0.5 for a in w])
     np.testing.assert_array_equal(q, ref.predict(X, batch_size=8))
+
+
+def test_compound_head_model(tmp_path):
+    """model_type 'compound' (models.py:379-386): sigmoid 'noobj' outputs through SigmoidOutput + InterleaveColumns.
+    Forward and every gradient against the oracle's restatement, the reference's two head layers in the checkpoint,
+    and the whole-model file brings the head variant back."""
+    import torch
+    from oracle import torch_ref as T
+    from spnet_amd import config as cf
+    from spnet_amd import models as M
+    from tests.parity_util import assert_gradients_match, make_case, rel_err
+    H, W, B = 96, 128, 2
+    P, X, Y, mask, dseed = make_case(H, W, B, 1)
+    old = cf.model_type
+    try:
+        cf.model_type = 'compound'
+        model = M.create_model_functional(X.numpy(), Y0size=576, freeze_fac=0.0)
+    finally:
+        cf.model_type = old
+    sd = model.state_dict()
+    assert "FinalOutput/kernel" not in sd and tuple(sd["SigmoidOutput/kernel"].shape)[1] == 72
+    assert tuple(sd["DenseOutput/kernel"].shape)[1] == 504 and tuple(sd["DenseOutput/bias"].shape) == (504,)
+    model._root.load_state_dict(P)                      # engine-level names (one FinalOutput kernel in final column order)
+    sc = (cf.ind_noobj, cf.vars_per_pred)
+    want = T.forward(P, X, training=False, sigmoid_cols=sc).numpy()
+    got = model.predict(X.numpy(), batch_size=B)
+    assert float(((got - want) ** 2).mean()) <= 1e-8 * max(float((want ** 2).mean()), 1.0)
+    assert got[:, 6::8].min() > 0 and got[:, 6::8].max() < 1      # sigmoid columns where InterleaveColumns puts them
+    # the interleaving itself: SigmoidOutput column p is output column 6 + 8p
+    np.testing.assert_array_equal(model.state_dict()["SigmoidOutput/kernel"].numpy(), P["FinalOutput/kernel"].numpy()[:, 6::8])
+    eng = model._engine(B, train=True)
+    eng.set_drop_seed(dseed)
+    out = eng.forward(X.cuda(), training=True)
+    eng.loss(Y.cuda())
+    eng.backward()
+    torch.cuda.synchronize()
+    _, yp64, _, _ = assert_gradients_match(eng, P, X, Y, mask, tol=5e-3, sigmoid_cols=sc)
+    assert rel_err(out.cpu().numpy(), yp64.numpy()) <= 5e-4
+    # checkpoint round trips keep the head variant
+    path = str(tmp_path / "full_model.h5")
+    model.save(path)
+    again = M.load_model(path)
+    assert again.compound and "SigmoidOutput/kernel" in again.state_dict()
+    np.testing.assert_array_equal(again.predict(X.numpy(), batch_size=B), got)
+    w = model.get_weights()
+    again.set_weights([a * 0 for a in w])
+    z = again.predict(X.numpy(), batch_size=B)
+    assert np.allclose(z[:, 6::8], 0.5) and float(np.abs(np.delete(z, np.s_[6::8], axis=1)).max()) < 1e-3

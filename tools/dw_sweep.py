@@ -31,8 +31,8 @@ for name, H, W, C in shapes:
     f1 = timeit(lambda: L.spnet_dwconv3x3_tiled_fwd(x.data_ptr(), w.data_ptr(), y.data_ptr(), B, H, W, C, 1, sc.data_ptr(), sh.data_ptr(), st()))
     b0 = timeit(lambda: L.spnet_dwconv3x3_tiled_bwd(dy.data_ptr(), x.data_ptr(), w.data_ptr(), dx.data_ptr(), dw.data_ptr(), B, H, W, C, 1, None, ws.data_ptr(), None, None, None, None, None, None, st()))
     b1 = timeit(lambda: L.spnet_dwconv3x3_tiled_bwd(dy.data_ptr(), x.data_ptr(), w.data_ptr(), dx.data_ptr(), dw.data_ptr(), B, H, W, C, 1, add.data_ptr(), ws.data_ptr(), sc.data_ptr(), sh.data_ptr(), mu.data_ptr(), isd.data_ptr(), bnp.data_ptr(), None, st()))
-    o0 = timeit(lambda: L.spnet_dwconv3x3_fwd(x.data_ptr(), w.data_ptr(), y.data_ptr(), B, H, W, C, 1, st()))
-    print("%-5s T=%6.1fMB | fwd %6.1fus (%.2f TB/s) fwd+aff %6.1fus | bwd %6.1fus (%.2f TB/s alg 3T) bwd fused %6.1fus | old strip fwd %6.1fus"
+    o0 = timeit(lambda: L.spnet_dwconv3x3_strided(0, x.data_ptr(), w.data_ptr(), y.data_ptr(), B, H, W, C, 1, None, st()))
+    print("%-5s T=%6.1fMB | fwd %6.1fus (%.2f TB/s) fwd+aff %6.1fus | bwd %6.1fus (%.2f TB/s alg 3T) bwd fused %6.1fus | gather fwd (stride-1 form of the strided kernel) %6.1fus"
           % (name, T, f0, 2 * T / f0, f1, b0, 3 * T / b0, b1, o0), flush=True)
 print("--- calibration: elementwise kernels on the same tensors")
 for name, H, W, C in shapes:

@@ -21,7 +21,8 @@ from predict_spnet import default_image_dir, predict_network
 
 
 def train_network(weights_file="weights.hdf5", datapath=".", fraction=1.0, batch_size=32, epochs=30, pred_grid=[6, 6, 2],
-                  noaugment=False, log_dir=".", lr_max=4e-5, freeze_fac=0.7, frozen_epochs=4, random_seed=1):
+                  noaugment=False, log_dir=".", lr_max=4e-5, freeze_fac=0.7, frozen_epochs=4, random_seed=1,
+                  augment_blur=False):
     np.random.seed(random_seed)
     # Data parallel (launched by torch.distributed.run): choose this rank's GPU and join the process group before
     # anything touches the device; rank 0 alone logs, validates and writes checkpoints.
@@ -48,7 +49,8 @@ def train_network(weights_file="weights.hdf5", datapath=".", fraction=1.0, batch
                                                      batch_size=batch_size * world, verbose=int(rank == 0)))
     if not noaugment:
         print("Adding callback for augment on the fly")
-        callback_list.append(callbacks.AugmentOnTheFly(X_train, Y_train, aug_every=1, seed=random_seed))
+        callback_list.append(callbacks.AugmentOnTheFly(X_train, Y_train, aug_every=1, seed=random_seed,
+                                                       real_blur=augment_blur))
 
     fit_args = dict(batch_size=batch_size, shuffle=True, verbose=1, validation_data=(X_val, Y_val), callbacks=callback_list)
     if frozen_epochs > 0 and freeze_fac > 0.0:        # warm-up phase with the first layers frozen
@@ -88,6 +90,8 @@ if __name__ == '__main__':
     p.add_argument('--model_type', default=None, help="override spnet.config.model_type ('monolithic' | 'big')")
     p.add_argument('--loss_type', default=None, help="override spnet.config.loss_type ('same' | 'hybrid')")
     p.add_argument('--backbone', default=None, help="override spnet.config.basemodel")
+    p.add_argument('--augment_blur', action='store_true',
+                   help="apply the Gaussian blur of the on-the-fly augmentation (the reference computes and discards it)")
     args = p.parse_args()
     print("Command line ~= \n", ' '.join(sys.argv))
     print("args = ", args)
@@ -104,7 +108,8 @@ if __name__ == '__main__':
     model = train_network(weights_file=args.weights, datapath=args.datapath, fraction=args.fraction,
                           batch_size=args.batch_size, epochs=args.epochs, pred_grid=pred_grid, noaugment=args.noaugment,
                           log_dir=log_dir, lr_max=args.lrmax, freeze_fac=args.freeze_fac,
-                          frozen_epochs=args.frozen_epochs, random_seed=args.random_seed)
+                          frozen_epochs=args.frozen_epochs, random_seed=args.random_seed,
+                          augment_blur=args.augment_blur)
 
     if int(os.environ.get("RANK", "0")) == 0:
         print("\n----------------------------\nStarting model evaluation...")
