@@ -159,6 +159,13 @@ int spnet_avgpool2_bwd(const float* dy, float* dx, int B, int H, int W, int C, v
 int spnet_conv3x3_small(int op, int cin, int cout, int stride, int same, const float* a, const float* b,
                         float* out, int B, int H, int W, float* workspace, long ws_floats, void* stream);
 
+/* The stem's first three layers fused (spnet/models.py:321-323, 337): conv2d_1 (1 -> 3, 3x3 'same', no bias) +
+ * AveragePooling2D(2), and the skip connection's AveragePooling2D(2) of the input frame.
+ * op 0: a = w [3][3][1][3]; out = p1 [B][H/2][W/2][3], out2 = px [B][H/2][W/2].
+ * op 2: a = dp1 (gradient of p1); out = dw [3][3][1][3]; workspace >= 512*27 floats.  (No data gradient: x is the input.) */
+int spnet_stem_head(int op, const float* x, const float* a, float* out, float* out2, int B, int H, int W,
+                    float* workspace, long ws_floats, void* stream);
+
 /* ---- loss / decode ---------------------------------------------------------------------------- */
 /* custom_loss + my_loss terms + d/dy_pred (spnet/models.py:557-633).  loss_out[6] =
  * (center,size,angle,noobj,class,total); parts = B*5 floats scratch; grad may be NULL. */
@@ -203,6 +210,12 @@ int spnet_saltpepper(float* x, int N, int H, int W, const int* coords, int n_sal
 int spnet_gaussian_blur(const float* src, float* dst, int N, int H, int W, const int* ksize, void* stream);
 int spnet_warp_affine(const float* src, float* dst, int N, int H, int W, int C, const float* minv,
                       void* stream);
+/* cv2.warpAffine as OpenCV computes it for 8-bit images (INTER_LINEAR, zero border; rotate_image / translate_image,
+ * spnet/augmentation.py:193-194, 232): 1/32-pixel fixed-point coordinates, 15-bit integer bilinear weights.  src / dst
+ * hold 8-bit values as fp32; xrow [N][H][2] = (X0, Y0), xcol [N][W][2] = (adelta, bdelta): the host-rounded row and
+ * column terms of the INVERTED matrix, scaled by 1024 (+ round_delta 16 in X0 / Y0). */
+int spnet_warp_affine_fixed(const float* src, float* dst, int N, int H, int W, int C, const int* xrow, const int* xcol,
+                            void* stream);
 /* Dropout(0.1) of the stem (spnet/models.py:340); same call with dy regenerates the mask in backward. */
 int spnet_dropout(const float* x, float* y, long n, unsigned seed, float rate, const unsigned* seed_dev,
                   void* stream);   /* seed_dev (or NULL): device uint32 overriding seed (hipGraph replay) */

@@ -460,7 +460,10 @@ class Trainer:
         with torch.no_grad():
             for k in self.names:
                 g = gs[k]
-                self.m[k].mul_(b1).add_((1 - b1) * g)
-                self.v[k].mul_(b2).add_((1 - b2) * g * g)
+                # (1. - beta) evaluated in the parameters' precision, as the Keras/TF graph does (see numpy_ref.adam_step)
+                one = torch.ones((), dtype=g.dtype)
+                c1, c2 = one - torch.tensor(b1, dtype=g.dtype), one - torch.tensor(b2, dtype=g.dtype)
+                self.m[k].mul_(b1).add_(c1 * g)
+                self.v[k].mul_(b2).add_(c2 * g * g)
                 self.P[k].sub_(lr_t * self.m[k] / (self.v[k].sqrt() + self.eps))
         return data, total

@@ -3,8 +3,9 @@
   cv2.flip / cv2.getRotationMatrix2D / cv2.warpAffine as the reference calls them in
   spnet/augmentation.py:82-112 (flip_image), :184-207 (rotate_image), :216-239 (translate_image),
   driven by augment_preproc.py:74-99.
-Bilinear interpolation with exact float weights and a zero border (OpenCV quantises the weights to
-1/32 pixel and rounds in fixed point, so its uint8 result can differ by 1 grey level).
+warp_affine: bilinear interpolation with exact float weights and a zero border (float images).
+warp_affine_cv2: OpenCV's fixed-point algorithm for 8-bit images (1/32-pixel coordinates, 15-bit weights), the path the
+reference's uint8 frames take.
 """
 import numpy as np
 
@@ -36,6 +37,43 @@ def warp_affine(img, M):
     top = at(y0, x0) + wx * (at(y0, x0 + 1) - at(y0, x0))
     bot = at(y0 + 1, x0) + wx * (at(y0 + 1, x0 + 1) - at(y0 + 1, x0))
     return top + wy * (bot - top)
+
+
+def warp_affine_cv2(img, M):
+    """cv2.warpAffine(uint8 img [H,W,C], M, (W,H)) restated from OpenCV 3.4's published algorithm (modules/imgproc/src/
+    imgwarp.cpp: warpAffine, WarpAffineInvoker, remapBilinear with the fixed-point table; INTER_LINEAR, BORDER_CONSTANT
+    0) in plain integer numpy -- PARITY UNPINNED like the rest of this file (OpenCV cannot run here), but the
+    arithmetic is integer, so a faithful restatement is bit-exact by construction:
+      M inverted in double; adelta/bdelta = cvRound(M00|M10 * x * 2^10); X0/Y0 = cvRound((M01|M11 * y + M02|M12) * 2^10)
+      + 16; X = (X0 + adelta) >> 5 (1/32 px); weights (32-fy)(32-fx)*32 of 2^15 (int16 table: 32768 saturates to
+      32767, harmless for 8-bit pixels); result = (sum w p + 2^14) >> 15."""
+    H, W = img.shape[:2]
+    m = np.asarray(M, np.float64).reshape(2, 3).copy()
+    D = m[0, 0] * m[1, 1] - m[0, 1] * m[1, 0]
+    D = 1.0 / D if D != 0 else 0.0
+    A11, A22 = m[1, 1] * D, m[0, 0] * D
+    m[0, 0], m[0, 1], m[1, 0], m[1, 1] = A11, m[0, 1] * -D, m[1, 0] * -D, A22
+    b1 = -m[0, 0] * m[0, 2] - m[0, 1] * m[1, 2]
+    b2 = -m[1, 0] * m[0, 2] - m[1, 1] * m[1, 2]
+    m[0, 2], m[1, 2] = b1, b2
+    xs, ys = np.arange(W, dtype=np.float64), np.arange(H, dtype=np.float64)
+    adelta, bdelta = np.rint(m[0, 0] * xs * 1024).astype(np.int64), np.rint(m[1, 0] * xs * 1024).astype(np.int64)
+    X0 = np.rint((m[0, 1] * ys + m[0, 2]) * 1024).astype(np.int64) + 16
+    Y0 = np.rint((m[1, 1] * ys + m[1, 2]) * 1024).astype(np.int64) + 16
+    X = (X0[:, None] + adelta[None, :]) >> 5
+    Y = (Y0[:, None] + bdelta[None, :]) >> 5
+    sx, sy, fx, fy = X >> 5, Y >> 5, X & 31, Y & 31
+    src = img.astype(np.int64)
+
+    def at(y, x):
+        ok = (y >= 0) & (y < H) & (x >= 0) & (x < W)
+        out = np.zeros(y.shape + src.shape[2:], np.int64)
+        out[ok] = src[y[ok], x[ok]]
+        return out
+    w00 = np.minimum((32 - fy) * (32 - fx) * 32, 32767)[..., None]
+    w01, w10, w11 = ((32 - fy) * fx * 32)[..., None], (fy * (32 - fx) * 32)[..., None], (fy * fx * 32)[..., None]
+    v = (at(sy, sx) * w00 + at(sy, sx + 1) * w01 + at(sy + 1, sx) * w10 + at(sy + 1, sx + 1) * w11 + (1 << 14)) >> 15
+    return np.clip(v, 0, 255).astype(np.uint8)
 
 
 def flip(img, code):

@@ -60,6 +60,7 @@ _SIGS = {
     "spnet_avgpool2_fwd": (c_int, [P, P, c_int, c_int, c_int, c_int, P]),
     "spnet_avgpool2_bwd": (c_int, [P, P, c_int, c_int, c_int, c_int, P]),
     "spnet_conv3x3_small": (c_int, [c_int, c_int, c_int, c_int, c_int, P, P, P, c_int, c_int, c_int, P, c_long, P]),
+    "spnet_stem_head": (c_int, [c_int, P, P, P, P, c_int, c_int, c_int, P, c_long, P]),
     "spnet_ellipse_loss": (c_int, [P, P, P, P, P, c_int, c_int, c_int, P]),
     "spnet_selective_sigmoid": (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, P]),
     "spnet_decode": (c_int, [P, P, P, P, c_int, c_int, c_int, P]),
@@ -71,6 +72,7 @@ _SIGS = {
     "spnet_saltpepper": (c_int, [P, c_int, c_int, c_int, P, c_int, c_int, P, P, P]),
     "spnet_gaussian_blur": (c_int, [P, P, c_int, c_int, c_int, P, P]),
     "spnet_warp_affine": (c_int, [P, P, c_int, c_int, c_int, c_int, P, P]),
+    "spnet_warp_affine_fixed": (c_int, [P, P, c_int, c_int, c_int, c_int, P, P, P]),
     "spnet_fake_espi": (c_int, [P, P, P, c_int, c_int, c_int, c_uint, c_int, P, P, P]),
     "spnet_dropout": (c_int, [P, P, c_long, c_uint, c_float, P, P]),
 }

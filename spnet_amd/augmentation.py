@@ -217,6 +217,41 @@ def _warp(img, minv):
     return out
 
 
+def cv2_fixed_point_terms(M, H, W):
+    """Row / column terms of cv2.warpAffine's fixed-point coordinate computation for a FORWARD 2x3 matrix M (OpenCV 3.4
+    imgwarp.cpp, warpAffine + WarpAffineInvoker): M is inverted in double precision exactly as OpenCV does it, then
+    adelta[x] = cvRound(M00*x*1024), bdelta[x] = cvRound(M10*x*1024), X0[y] = cvRound((M01*y + M02)*1024) + 16,
+    Y0[y] = cvRound((M11*y + M12)*1024) + 16 (cvRound = round-half-even = np.rint).  Returns int32 arrays
+    xrow [H,2] = (X0, Y0), xcol [W,2] = (adelta, bdelta)."""
+    m = np.asarray(M, np.float64).reshape(2, 3).copy()
+    D = m[0, 0] * m[1, 1] - m[0, 1] * m[1, 0]
+    D = 1.0 / D if D != 0 else 0.0
+    A11, A22 = m[1, 1] * D, m[0, 0] * D
+    m[0, 0], m[0, 1], m[1, 0], m[1, 1] = A11, m[0, 1] * -D, m[1, 0] * -D, A22
+    b1 = -m[0, 0] * m[0, 2] - m[0, 1] * m[1, 2]
+    b2 = -m[1, 0] * m[0, 2] - m[1, 1] * m[1, 2]
+    m[0, 2], m[1, 2] = b1, b2
+    xs, ys = np.arange(W, dtype=np.float64), np.arange(H, dtype=np.float64)
+    xcol = np.stack([np.rint(m[0, 0] * xs * 1024.0), np.rint(m[1, 0] * xs * 1024.0)], 1).astype(np.int32)
+    xrow = np.stack([np.rint((m[0, 1] * ys + m[0, 2]) * 1024.0) + 16, np.rint((m[1, 1] * ys + m[1, 2]) * 1024.0) + 16],
+                    1).astype(np.int32)
+    return xrow, xcol
+
+
+def _warp_cv2(img, M):
+    """cv2.warpAffine(img, M, (W,H)) for a uint8 image [H,W,C] and a FORWARD matrix: OpenCV's fixed-point algorithm on
+    the device (csrc/augment.hip: warp_affine_fixed_kernel)."""
+    if not torch.cuda.is_available():
+        raise RuntimeError("spnet_amd.augmentation warps run on the GPU (no CPU fallback)")
+    H, W, C = img.shape
+    xrow, xcol = cv2_fixed_point_terms(M, H, W)
+    src = torch.from_numpy(np.ascontiguousarray(img, dtype=np.float32)).cuda()
+    dst = torch.empty_like(src)
+    xr, xc = torch.from_numpy(xrow).cuda(), torch.from_numpy(xcol).cuda()
+    L.spnet_warp_affine_fixed(src.data_ptr(), dst.data_ptr(), 1, H, W, C, xr.data_ptr(), xc.data_ptr(), _stream())
+    return dst.cpu().numpy().astype(np.uint8)
+
+
 def _invert_affine(M):
     A = np.vstack([np.asarray(M, np.float64), [0, 0, 1]])
     return np.linalg.inv(A)[:2]
@@ -261,7 +296,8 @@ def rotate_image(img, metadata, file_prefix, rot_angle, rot_origin=None):
     if rot_origin is None:
         rot_origin = (width / 2, height / 2)
     M = rotation_matrix_2d(rot_origin, rot_angle, 1.0)
-    out = _warp(img, _invert_affine(M))
+    # 8-bit images (the offline set, augment_preproc.py) take OpenCV's fixed-point path like the reference's call does
+    out = _warp_cv2(img, M) if img.dtype == np.uint8 else _warp(img, _invert_affine(M))
     new_md = []
     for cx, cy, a, b, angle, rings in metadata:
         angle = cleanup_angle(angle + rot_angle)
@@ -277,7 +313,7 @@ def translate_image(img, metadata, file_prefix, trans_index):
     trans_max = 40
     xt = int(round(trans_max * (2 * np.random.random() - 1)))
     yt = int(round(trans_max * (2 * np.random.random() - 1)))
-    out = _warp(img, [[1, 0, -xt], [0, 1, -yt]])
+    out = _warp_cv2(img, [[1, 0, xt], [0, 1, yt]]) if img.dtype == np.uint8 else _warp(img, [[1, 0, -xt], [0, 1, -yt]])
     new_md = [[cx + xt, cy + yt, a, b, angle, rings] for cx, cy, a, b, angle, rings in metadata]
     return out, new_md, file_prefix[:] + "_t" + str(xt) + ',' + str(yt)
 

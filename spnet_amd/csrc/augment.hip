@@ -239,3 +239,48 @@ extern "C" int spnet_gaussian_blur(const float* src, float* dst, int N, int H, i
                      ksize);
   SPNET_RETURN_LAUNCH_STATUS();
 }
+
+// ---------------------------------------------------------------- cv2.warpAffine, fixed-point form (8-bit images)
+// What OpenCV 3.4 computes for cv2.warpAffine(uint8 image, M, (w,h)) with the defaults the reference uses
+// (INTER_LINEAR, BORDER_CONSTANT 0; spnet/augmentation.py:193-194, 232): source coordinates in 1/32-pixel fixed
+// point, X = (X0[y] + adelta[x]) >> 5 with X0 / adelta the host-rounded (cvRound, 10 fractional bits) row and column
+// terms of the inverted matrix, bilinear weights (32-fy)(32-fx)*32 of 2^15 and a rounded 15-bit shift.  Integer
+// arithmetic end to end: the result is exactly the integer OpenCV's algorithm yields, not a float approximation of it.
+// src / dst hold 8-bit values as fp32 [N][H][W][C]; xrow [N][H][2] = (X0, Y0), xcol [N][W][2] = (adelta, bdelta).
+__global__ __launch_bounds__(256) void warp_affine_fixed_kernel(const float* __restrict__ src, float* __restrict__ dst,
+                                                                int H, int W, int C, const int* __restrict__ xrow,
+                                                                const int* __restrict__ xcol) {
+  const int n = blockIdx.y;
+  const long hw = (long)H * W;
+  const float* s = src + (long)n * hw * C;
+  float* o = dst + (long)n * hw * C;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < hw; i += (long)gridDim.x * blockDim.x) {
+    const int y = (int)(i / W), x = (int)(i % W);
+    const int X = (xrow[((long)n * H + y) * 2] + xcol[((long)n * W + x) * 2]) >> 5;
+    const int Y = (xrow[((long)n * H + y) * 2 + 1] + xcol[((long)n * W + x) * 2 + 1]) >> 5;
+    const int sx = X >> 5, sy = Y >> 5, fx = X & 31, fy = Y & 31;
+    const int w00 = min((32 - fy) * (32 - fx) * 32, 32767), w01 = (32 - fy) * fx * 32;   // int16 table entries
+    const int w10 = fy * (32 - fx) * 32, w11 = fy * fx * 32;
+    const bool y0 = sy >= 0 && sy < H, y1 = sy + 1 >= 0 && sy + 1 < H;
+    const bool x0 = sx >= 0 && sx < W, x1 = sx + 1 >= 0 && sx + 1 < W;
+    for (int ch = 0; ch < C; ++ch) {
+      const int p00 = (y0 && x0) ? (int)s[((long)sy * W + sx) * C + ch] : 0;
+      const int p01 = (y0 && x1) ? (int)s[((long)sy * W + sx + 1) * C + ch] : 0;
+      const int p10 = (y1 && x0) ? (int)s[((long)(sy + 1) * W + sx) * C + ch] : 0;
+      const int p11 = (y1 && x1) ? (int)s[((long)(sy + 1) * W + sx + 1) * C + ch] : 0;
+      const int v = (p00 * w00 + p01 * w01 + p10 * w10 + p11 * w11 + (1 << 14)) >> 15;
+      o[i * C + ch] = (float)min(max(v, 0), 255);
+    }
+  }
+}
+
+extern "C" int spnet_warp_affine_fixed(const float* src, float* dst, int N, int H, int W, int C, const int* xrow,
+                                       const int* xcol, void* stream) {
+  if (N < 1 || !src || !dst || src == dst || !xrow || !xcol) return (int)hipErrorInvalidValue;
+  const long hw = (long)H * W;
+  int gx = (int)((hw + 255) / 256);
+  if (gx > 256) gx = 256;
+  hipLaunchKernelGGL(warp_affine_fixed_kernel, dim3(gx, N), dim3(256), 0, (hipStream_t)stream, src, dst, H, W, C, xrow,
+                     xcol);
+  SPNET_RETURN_LAUNCH_STATUS();
+}

@@ -440,3 +440,135 @@ extern "C" int spnet_conv3x3_small(int op, int cin, int cout, int stride, int sa
     return conv_small_dispatch<3, 32, 2, 0>(op, a, b, out, B, H, W, workspace, ws_floats, st);
   return (int)hipErrorInvalidValue;
 }
+
+// ================================================================================================
+// Stem head, fused: conv2d_1 (1 -> 3, 3x3 SAME) + AveragePooling2D(2) and the skip connection's
+// AveragePooling2D(2) of the input (spnet/models.py:321-323, 337).  The full-resolution 3-channel tensor
+// (75 MB per 32 frames of 384x512, the largest activation of the network) is never written or read:
+//   forward   thread = one pooled pixel: its 4x4 input window (zero padded) gives the four conv outputs of the
+//             2x2 pooling cell; same accumulation order as conv3x3_small_fwd_kernel + avgpool2_fwd_kernel, so the
+//             result is bit-identical to the unfused pair
+//   backward  dW[kh][kw][c] = sum over pooled pixels of 0.25*dp[c] * (the four window entries the tap sees);
+//             the pooling backward (a 4x upsampled, 75 MB gradient) is folded into the weight-gradient sum.
+//             The layer has no data gradient (it reads the input frame).
+// ================================================================================================
+__global__ __launch_bounds__(256) void stem_head_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                            float* __restrict__ p1, float* __restrict__ px, int Bn, int H,
+                                                            int W, int OH, int OW) {
+  __shared__ float ws[27];
+  if (threadIdx.x < 27) ws[threadIdx.x] = w[threadIdx.x];
+  __syncthreads();
+  const long total = (long)Bn * OH * OW;
+  for (long p = (long)xcd_remap(blockIdx.x, gridDim.x) * blockDim.x + threadIdx.x; p < total;
+       p += (long)gridDim.x * blockDim.x) {
+    const int ow = (int)(p % OW);
+    long t = p / OW;
+    const int oh = (int)(t % OH);
+    const int b = (int)(t / OH);
+    float win[4][4];                             // rows 2oh-1 .. 2oh+2, columns 2ow-1 .. 2ow+2
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int h = 2 * oh - 1 + r;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const int ww = 2 * ow - 1 + c;
+        win[r][c] = (h >= 0 && h < H && ww >= 0 && ww < W) ? x[((long)b * H + h) * W + ww] : 0.f;
+      }
+    }
+    float cv[2][2][3];
+#pragma unroll
+    for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+      for (int dx = 0; dx < 2; ++dx) {
+        float acc[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+          for (int kw = 0; kw < 3; ++kw) {
+            // taps outside the image contribute nothing (the unfused kernel skips them; adding 0*w is the same value)
+            const float xv = win[dy + kh][dx + kw];
+#pragma unroll
+            for (int co = 0; co < 3; ++co) acc[co] = fmaf(xv, ws[(kh * 3 + kw) * 3 + co], acc[co]);
+          }
+#pragma unroll
+        for (int co = 0; co < 3; ++co) cv[dy][dx][co] = acc[co];
+      }
+#pragma unroll
+    for (int co = 0; co < 3; ++co)
+      p1[p * 3 + co] = ((cv[0][0][co] + cv[0][1][co]) + (cv[1][0][co] + cv[1][1][co])) * 0.25f;
+    px[p] = ((win[1][1] + win[1][2]) + (win[2][1] + win[2][2])) * 0.25f;
+  }
+}
+
+__global__ __launch_bounds__(256) void stem_head_bwd_weight_kernel(const float* __restrict__ x,
+                                                                   const float* __restrict__ dp,
+                                                                   float* __restrict__ partial, int Bn, int H, int W,
+                                                                   int OH, int OW) {
+  __shared__ float red[4][27];
+  float acc[27];
+#pragma unroll
+  for (int i = 0; i < 27; ++i) acc[i] = 0.f;
+  const long total = (long)Bn * OH * OW;
+  for (long p = (long)xcd_remap(blockIdx.x, gridDim.x) * blockDim.x + threadIdx.x; p < total;
+       p += (long)gridDim.x * blockDim.x) {
+    const int ow = (int)(p % OW);
+    long t = p / OW;
+    const int oh = (int)(t % OH);
+    const int b = (int)(t / OH);
+    float win[4][4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int h = 2 * oh - 1 + r;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const int ww = 2 * ow - 1 + c;
+        win[r][c] = (h >= 0 && h < H && ww >= 0 && ww < W) ? x[((long)b * H + h) * W + ww] : 0.f;
+      }
+    }
+    float g[3];
+#pragma unroll
+    for (int co = 0; co < 3; ++co) g[co] = 0.25f * dp[p * 3 + co];      // AveragePooling2D backward
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+      for (int kw = 0; kw < 3; ++kw) {
+        const float xs = (win[kh][kw] + win[kh][kw + 1]) + (win[kh + 1][kw] + win[kh + 1][kw + 1]);
+#pragma unroll
+        for (int co = 0; co < 3; ++co) acc[(kh * 3 + kw) * 3 + co] = fmaf(xs, g[co], acc[(kh * 3 + kw) * 3 + co]);
+      }
+  }
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+  for (int i = 0; i < 27; ++i) {
+    const float s = wave_sum(acc[i]);
+    if (lane == 0) red[wv][i] = s;
+  }
+  __syncthreads();
+  if (threadIdx.x < 27)
+    partial[(long)blockIdx.x * 27 + threadIdx.x] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+
+// op 0: p1 [B][H/2][W/2][3] = avgpool2(conv3x3_same(x, w)), px [B][H/2][W/2] = avgpool2(x)   (a = w, out = p1, out2 = px)
+// op 2: dw [3][3][1][3] from the gradient dp1 of p1                                          (a = dp1, out = dw)
+extern "C" int spnet_stem_head(int op, const float* x, const float* a, float* out, float* out2, int B, int H, int W,
+                               float* workspace, long ws_floats, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  const int OH = H / 2, OW = W / 2;
+  if (OH < 1 || OW < 1 || !x || !a || !out) return (int)hipErrorInvalidValue;
+  const long total = (long)B * OH * OW;
+  if (op == 0) {
+    if (!out2) return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(stem_head_fwd_kernel, dim3(spnet_ew_grid(total, 256)), dim3(256), 0, st, x, a, out, out2, B, H, W,
+                       OH, OW);
+  } else if (op == 2) {
+    int parts = spnet_cdiv(total, 256 * 8);
+    if (parts > 512) parts = 512;
+    if (parts < 1) parts = 1;
+    if (!workspace || (long)parts * 27 > ws_floats) return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(stem_head_bwd_weight_kernel, dim3(parts), dim3(256), 0, st, x, a, workspace, B, H, W, OH, OW);
+    return spnet_reduce_rows(workspace, parts, 27, out, (void*)st);
+  } else {
+    return (int)hipErrorInvalidValue;
+  }
+  SPNET_RETURN_LAUNCH_STATUS();
+}

@@ -375,14 +375,12 @@ class Engine:
         # ---- stem (spnet/models.py:321-340)
         H2, W2 = H // 2, W // 2
         n = self.nodes
-        c1 = SmallConv(self, self.x_in, 1, 3, 1, True, "conv2d_1", need_dx=False); n.append(c1)
-        p1 = AvgPool(self, c1.y, 3); n.append(p1)
-        a1 = BatchNorm(self, p1.y, 3, "batch_normalization_1", ACT_LRELU); n.append(a1)
+        sh = StemHead(self, self.x_in, "conv2d_1"); n.append(sh)      # conv2d_1 + both average pools, one kernel
+        a1 = BatchNorm(self, sh.y, 3, "batch_normalization_1", ACT_LRELU); n.append(a1)
         c2 = SmallConv(self, a1.y, 3, 3, 1, True, "conv2d_2"); n.append(c2)
         a2 = BatchNorm(self, c2.y, 3, "batch_normalization_2", ACT_LRELU); n.append(a2)
         c3 = SmallConv(self, a2.y, 3, 3, 1, True, "conv2d_3"); n.append(c3)
-        px = AvgPool(self, self.x_in, 1, need_dx=False); n.append(px)
-        s = BatchNorm(self, c3.y, 3, "batch_normalization_3", ACT_NONE, residual=px.y, res_bcast=True); n.append(s)
+        s = BatchNorm(self, c3.y, 3, "batch_normalization_3", ACT_NONE, residual=sh.px, res_bcast=True); n.append(s)
         d = Dropout(self, s.y, 0.1); n.append(d)
         self.stem_out = d.y
         if self.backbone == "MobileNet":
@@ -804,6 +802,42 @@ class SmallConv(Node):
         if self.need_dx:
             self._call(1, g, self.w, self.dx)
             return self.dx
+        return None
+
+
+class StemHead(Node):
+    """conv2d_1 (1 -> 3, 3x3 same) + AveragePooling2D(2) and the skip connection's AveragePooling2D(2) of the input
+    (spnet/models.py:321-323, 337) in one kernel each way: the full-resolution 3-channel tensor is never materialised
+    (75 MB per step at batch 32) and its pooling backward is folded into the weight-gradient sum."""
+
+    def __init__(self, eng, x, name):
+        self.e, self.x = eng, x
+        self.pnames = [name]
+        B, H, W, _ = x.shape
+        self.H, self.W = H, W
+        self.w = eng.P(name + "/kernel")
+        self.y = eng.new(B, H // 2, W // 2, 3)
+        self.px = eng.new(B, H // 2, W // 2, 1)
+        self.gw = eng.G(name + "/kernel") if eng.train_capable else None
+
+    def fwd(self, training):
+        L.spnet_stem_head(0, L.ptr(self.x), L.ptr(self.w), L.ptr(self.y), L.ptr(self.px), self.e.B, self.H, self.W,
+                          None, 0, _stream())
+
+    def bwd(self, g):
+        e = self.e
+        side = e.wgrad_stream
+        region = WS_MISC if side is None else WS_GEMM2
+
+        def call():
+            L.spnet_stem_head(2, L.ptr(self.x), L.ptr(g), L.ptr(self.gw), None, e.B, self.H, self.W, e.ws_ptr(region),
+                              region[1], _stream())
+        if side is None:
+            call()
+        else:           # weight gradient off the data-gradient chain (see Pointwise.bwd)
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                call()
         return None
 
 

@@ -9,7 +9,6 @@ not bitwise, those of the reference.  Exactly one PNG per CSV is written (the re
 a *_bp.png that would trip build_dataset's file-count assertion, utils.py:455-459).
 """
 import os
-from multiprocessing import Pool
 
 import numpy as np
 from PIL import Image, ImageDraw
@@ -164,8 +163,21 @@ def generate(n, seed=0, workers=None):
     """n frames -> (uint8 [n,384,512], list of label rows).  Deterministic in (n, seed)."""
     seeds = frame_seeds(n, seed)
     workers = workers or min(os.cpu_count() or 1, 16)
+    # Worker processes are FORKED: safe only while this process has not initialised the GPU (a forked copy of a
+    # HIP-initialised, multi-threaded process crashes or hangs).  Afterwards: small sets serially, large ones from
+    # freshly spawned interpreters.
+    ctx = None
     if workers > 1 and n >= 16:
-        p = Pool(workers)
+        import multiprocessing
+        import sys
+        torch = sys.modules.get("torch")
+        gpu_live = bool(torch is not None and torch.cuda.is_available() and torch.cuda.is_initialized())
+        if not gpu_live:
+            ctx = multiprocessing.get_context("fork")
+        elif n >= 512:
+            ctx = multiprocessing.get_context("spawn")
+    if ctx is not None:
+        p = ctx.Pool(workers)
         try:
             res = p.map(gen_frame, seeds, chunksize=max(1, n // (workers * 4)))
         finally:                     # let the workers exit normally (Pool.__exit__ would terminate() = SIGTERM them)

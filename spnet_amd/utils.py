@@ -15,7 +15,7 @@ import math
 import os
 import random
 from functools import partial
-from multiprocessing import Pool, cpu_count
+from multiprocessing import cpu_count
 from operator import itemgetter
 
 import numpy as np
@@ -150,9 +150,19 @@ def build_X(total_load, img_file_list, force_dim=224, grayscale=False):
     worker = partial(_load_one, force_dim, grayscale)
     nproc = min(cpu_count(), max(1, total_load // 64))
     if nproc > 1:
-        with Pool(nproc) as pool:
+        # forked workers are only safe while this process has not initialised the GPU (train_spnet.py evaluates and
+        # predicts after training in one process): afterwards load from freshly spawned interpreters
+        import multiprocessing
+        import sys
+        torch = sys.modules.get("torch")
+        gpu_live = bool(torch is not None and torch.cuda.is_available() and torch.cuda.is_initialized())
+        pool = multiprocessing.get_context("spawn" if gpu_live else "fork").Pool(nproc)
+        try:
             for i, arr in enumerate(pool.imap(worker, img_file_list[0:total_load], chunksize=32)):
                 X[i] = arr
+        finally:
+            pool.close()
+            pool.join()
     else:
         for i in range(total_load):
             X[i] = worker(img_file_list[i])

@@ -487,6 +487,44 @@ def test_adam_matches_keras_form(L):
     close(l2out[0], 1e-4 * np.sum(p[:l2n].astype(np.float64) ** 2), rtol=1e-5, atol=0)
 
 
+def test_adam_many_steps_full_size_with_mask_and_device_lr(L):
+    """The optimizer path to rounding, at scale: 3.1 M parameters (ragged vector tail), l2 prefix, frozen-element mask,
+    gradient scale (1/world), the step size read from device memory (train_step's path), five consecutive steps against
+    the Keras-form oracle -- every element within a few ulp of the fp32 reference after every step."""
+    import math
+    rs = np.random.RandomState(6)
+    n, l2n = 3_100_003 // 4 * 4 + 64, 1_000_000
+    p = rs.randn(n).astype(np.float32)
+    m, v = np.zeros(n, np.float32), np.zeros(n, np.float32)
+    mask = (rs.rand(n) > 0.25).astype(np.float32)
+    pd, md, vd, maskd = dev(p), dev(m), dev(v), dev(mask)
+    sq, l2out = torch.empty(2048, device="cuda"), torch.empty(2, device="cuda")
+    lr_dev = torch.zeros(1, device="cuda")
+    wp, wm, wv = p.copy(), m.copy(), v.copy()
+    lr, scale = 2e-4, 0.125
+    for t in range(1, 6):
+        g = (rs.randn(n) * (10.0 ** rs.uniform(-6, 0, n))).astype(np.float32)      # gradients over six decades
+        lr_t = lr * math.sqrt(1 - 0.999 ** t) / (1 - 0.9 ** t)
+        lr_dev.fill_(float(np.float32(lr_t)))
+        want_l2 = 1e-4 * np.sum(wp[:l2n].astype(np.float64) ** 2)
+        L.spnet_adam_step(pd.data_ptr(), dev(g).data_ptr(), md.data_ptr(), vd.data_ptr(), n, l2n, 0.0, 0.9, 0.999, 1e-7, 1e-4,
+                          scale, maskd.data_ptr(), sq.data_ptr(), l2out.data_ptr(), lr_dev.data_ptr(), st())
+        gs = g * np.float32(scale)
+        a = R.adam_step(wp[:l2n], gs[:l2n], wm[:l2n], wv[:l2n], t, lr, l2=1e-4)
+        b = R.adam_step(wp[l2n:], gs[l2n:], wm[l2n:], wv[l2n:], t, lr)
+        np_, nm, nv = (np.concatenate([x, y]) for x, y in zip(a, b))
+        keep = mask > 0
+        wp, wm, wv = np.where(keep, np_, wp), np.where(keep, nm, wm), np.where(keep, nv, wv)
+        close(l2out[0], want_l2, rtol=1e-5, atol=0)
+        # a step is at most lr_t per element: agreement to 1e-4 of a step, moments to a few ulp
+        assert np.abs(pd.cpu().numpy() - wp).max() <= 1e-4 * lr_t + 4e-7 * np.abs(wp).max()
+        # (atol: an element whose 0.9 m + 0.1 g nearly cancels carries the rounding of its terms, ~1e-8 * |g|)
+        close(md, wm, rtol=2e-6, atol=1e-8)
+        close(vd, wv, rtol=2e-6, atol=1e-15)
+    frozen = mask == 0
+    assert np.array_equal(pd.cpu().numpy()[frozen], p[frozen])                # frozen elements: bit for bit untouched
+
+
 def test_dropout_mask_is_reproducible(L):
     x = torch.ones(100000, device="cuda")
     y1, y2 = torch.empty_like(x), torch.empty_like(x)

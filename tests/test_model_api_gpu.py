@@ -209,9 +209,10 @@ def test_compound_head_model(tmp_path):
     # checkpoint round trips keep the head variant
     path = str(tmp_path / "full_model.h5")
     model.save(path)
+    now = model.predict(X.numpy(), batch_size=B)          # (the training forward above moved the BatchNorm statistics)
     again = M.load_model(path)
     assert again.compound and "SigmoidOutput/kernel" in again.state_dict()
-    np.testing.assert_array_equal(again.predict(X.numpy(), batch_size=B), got)
+    np.testing.assert_array_equal(again.predict(X.numpy(), batch_size=B), now)
     w = model.get_weights()
     again.set_weights([a * 0 for a in w])
     z = again.predict(X.numpy(), batch_size=B)
