@@ -347,22 +347,25 @@ def main():
     fence()
     t_host_idle = min(t_idle)
 
-    # Sustained leg: the same step for several seconds (reported separately; `value` stays the K timed steps).
+    if world > 1:                # every rank must agree on the timed region before anything is derived from it
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    # Sustained leg: the same step for several seconds (reported separately; `value` stays the K timed steps).  The
+    # step COUNT is fixed from the timed region's rate, identically on every rank (a time-based exit would let ranks
+    # leave the loop after different numbers of collectives).
     sustained = None
     if args.sustained_seconds > 0:
-        n_s = 0
+        n_s = max(20, int(args.sustained_seconds / (dt / args.steps) / 20 + 1) * 20)
         fence()
         t1 = time.perf_counter()
-        while True:
-            for _ in range(20):
-                step()
-            n_s += 20
-            if time.perf_counter() - t1 >= args.sustained_seconds:     # host time; the queue is at most ~4 steps deep
-                break
+        for _ in range(n_s):
+            step()
         fence()
         dts = time.perf_counter() - t1
         if world > 1:
-            tt = torch.tensor([dts, float(n_s)], dtype=torch.float64, device=dev)
+            tt = torch.tensor([dts], dtype=torch.float64, device=dev)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             dts = float(tt[0].item())
         sustained = {"seconds": round(dts, 2), "steps": n_s, "images_per_sec": round(BATCH * world * n_s / dts, 1),
@@ -382,11 +385,6 @@ def main():
         fence()
         eng.prof = None
         eng.wgrad_stream = None if args.no_overlap else side_stream
-
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
 
     result = None
     if rank == 0:
