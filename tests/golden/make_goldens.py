@@ -206,6 +206,31 @@ def main():
         G[f"aug_{tag}_changed_val"] = out.ravel()[changed]
         G[f"aug_{tag}_rng_after"] = np.float64(np.random.rand())   # pins total RNG consumption
 
+    # ---- zooniverse-style CSV of predictions (utils.show_pred_ellipses, utils.py:67-137): the image / drawing calls go
+    #      to the inert keras / cv2 stubs, the CSV text is the reference's own string formatting -----------------
+    import tempfile
+    rs = np.random.RandomState(21)
+    n_img = 5
+    Yt_csv = np.zeros((n_img, 576), np.float32)
+    Yp_csv = np.zeros((n_img, 576), np.float32)
+    for arr in (Yt_csv, Yp_csv):
+        arr[:, 0::8] = rs.uniform(20, 490, (n_img, 72))
+        arr[:, 1::8] = rs.uniform(20, 360, (n_img, 72))
+        arr[:, 2::8] = rs.uniform(-5, 140, (n_img, 72))
+        arr[:, 3::8] = rs.uniform(-5, 100, (n_img, 72))
+        arr[:, 4::8] = rs.uniform(-1, 1, (n_img, 72))
+        arr[:, 5::8] = rs.uniform(-1, 1, (n_img, 72))
+        arr[:, 6::8] = rs.uniform(-0.2, 1.2, (n_img, 72))
+        arr[:, 7::8] = rs.uniform(-1, 11, (n_img, 72))
+    Yp_csv[3, 6::8] = 0.9                      # an image without any predicted object -> the all-zeros row
+    names = ["steelpan_%07d.png" % (100 + i) for i in range(n_img)]
+    with tempfile.TemporaryDirectory() as td:
+        out_csv = os.path.join(td, "hawley_spnet.csv")
+        utils.show_pred_ellipses(Yt_csv, Yp_csv, [os.path.join(td, n) for n in names], num_draw=n_img, log_dir=td,
+                                 out_csv=out_csv, show_true=False)
+        G["csv_text"] = np.array(open(out_csv).read())
+    G["csv_Yt"], G["csv_Yp"], G["csv_names"] = Yt_csv, Yp_csv, np.array(names)
+
     # ---- flip metadata transform (pure python part of flip_image is not separable from cv2.flip,
     #      so only cleanup_angle is pinned above) -------------------------------------------
 

@@ -226,3 +226,21 @@ def test_gradient_allreduce_and_sharding_on_gloo(tmp_path, world):
     for r, (p, o) in enumerate(zip(procs, outs)):
         assert p.returncode == 0, o
         assert "rank %d ok" % r in o
+
+
+def test_prediction_csv_matches_reference_writer(golden, tmp_path):
+    """hawley_spnet.csv: byte-for-byte the text the reference's own show_pred_ellipses wrote for the same
+    de-normalised grids (utils.py:67-137; golden generated with the image / drawing calls stubbed out)."""
+    from PIL import Image
+    from spnet_amd import utils as U
+    names = [str(n) for n in golden["csv_names"]]
+    files = []
+    for n in names:
+        f = tmp_path / n
+        Image.new("L", (512, 384), 128).save(str(f))
+        files.append(str(f))
+    out_csv = str(tmp_path / "hawley_spnet.csv")
+    U.show_pred_ellipses(golden["csv_Yt"], golden["csv_Yp"], files, num_draw=len(files), log_dir=str(tmp_path),
+                         out_csv=out_csv, show_true=False)
+    assert open(out_csv).read() == str(golden["csv_text"])
+    assert all((tmp_path / ("steelpan_pred_%05d.png" % j)).exists() for j in range(len(files)))
