@@ -134,7 +134,7 @@ def secondary(args):
     from spnet_amd.engine import Engine
     h, w, b = args.height, args.width, args.batch
     dev = torch.device("cuda", 0)
-    eng = Engine(h, w, b, device="cuda:0", seed=0, train=(args.mode == "train"))
+    eng = Engine(h, w, b, device="cuda:0", seed=0, train=(args.mode == "train"), backbone=args.backbone)
     X = torch.rand(b, h, w, 1, device=dev) * 2 - 1
     Y = torch.rand(b, 576, device=dev)
 
@@ -152,10 +152,11 @@ def secondary(args):
         step()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    print(json.dumps({"metric": "%s images/sec, Xception backbone (secondary measurement)" % args.mode,
+    print(json.dumps({"metric": "%s images/sec, %s backbone (secondary measurement)" % (args.mode, args.backbone),
                       "value": round(b * args.steps / dt, 2), "unit": "images/sec", "n_gpus": 1, "steps": args.steps,
                       "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3), "dtype": "f32",
-                      "data": "synthetic (uniform noise)", "config": {"workload": "%s, %dx%d frames, batch %d" % (args.mode, w, h, b)}}))
+                      "data": "synthetic (uniform noise)",
+                      "config": {"workload": "%s, %s, %dx%d frames, batch %d" % (args.mode, args.backbone, w, h, b)}}))
 
 
 def predict_bench(args):
@@ -260,6 +261,8 @@ def main():
     ap.add_argument("--height", type=int, default=H)
     ap.add_argument("--width", type=int, default=W)
     ap.add_argument("--batch", type=int, default=BATCH)
+    ap.add_argument("--backbone", default="Xception", choices=["Xception", "MobileNet", "InceptionResNetV2"],
+                    help="secondary measurements only (the headline metric is Xception)")
     ap.add_argument("--no-overlap", action="store_true",
                     help="run the weight-gradient GEMMs on the main stream (the roofline leg always does)")
     args = ap.parse_args()
@@ -273,9 +276,10 @@ def main():
     from spnet_amd.engine import Engine, KernelTimer
     from spnet_amd import _lib as L
 
-    if args.mode == "predict" and (args.height, args.width) == (H, W) and args.batch in (BATCH, 128):
+    if args.mode == "predict" and (args.height, args.width) == (H, W) and args.batch in (BATCH, 128) \
+            and args.backbone == "Xception":
         return predict_bench(args)
-    if (args.height, args.width, args.batch, args.mode) != (H, W, BATCH, "train"):
+    if (args.height, args.width, args.batch, args.mode, args.backbone) != (H, W, BATCH, "train", "Xception"):
         return secondary(args)
     # ---- synthetic data first: the generator forks worker processes, which must happen before this process
     # initialises the GPU or joins the process group (rank-specific frames: weak scaling)

@@ -153,6 +153,23 @@ int spnet_maxpool3x3s2_bwd(const float* dy, const uint32_t* idx4, float* dx, int
 int spnet_avgpool2_fwd(const float* x, float* y, int B, int H, int W, int C, void* stream);
 int spnet_avgpool2_bwd(const float* dy, float* dx, int B, int H, int W, int C, void* stream);
 
+/* ---- keras InceptionResNetV2 (cf.basemodel = 'InceptionResNetV2', spnet/models.py:357-359) ------------------------ */
+/* MaxPooling2D(3, strides=2, 'valid') (stem, mixed_6a, mixed_7a); idx4 as above. */
+int spnet_maxpool3x3s2_valid_fwd(const float* x, float* y, uint32_t* idx4, int B, int H, int W, int C, void* stream);
+int spnet_maxpool3x3s2_valid_bwd(const float* dy, const uint32_t* idx4, float* dx, int B, int H, int W, int C, void* stream);
+/* AveragePooling2D(3, strides=1, 'same') (mixed_5b; TF averages over the in-image entries); backward = 1: in = dy, out = dx. */
+int spnet_avgpool3x3s1_same(const float* in, float* out, int B, int H, int W, int C, int backward, void* stream);
+/* Patch matrix of a KH x KW / stride s / 'same' | 'valid' convolution and its adjoint: backward = 0: out = col
+ * [B*OH*OW][KH*KW*C] from in = x; backward = 1: out = dx [B][H][W][C] from in = dcol.  The convolution itself is
+ * spnet_gemm_f32 on col and the flattened HWIO kernel (1x1 convs skip the patch matrix). */
+int spnet_patches(const float* in, float* out, int B, int H, int W, int C, int KH, int KW, int stride, int same, int backward,
+                  void* stream);
+/* inception_resnet_block: y = x + scale*up (+ ReLU); backward: dx = g*(y>0 if relu), dup = scale*dx. */
+int spnet_resadd(const float* x, const float* up, float* y, long n, float scale, int relu, void* stream);
+int spnet_resadd_bwd(const float* y, const float* g, float* dx, float* dup, long n, float scale, int relu, void* stream);
+/* dst[r*ldd + c] (+)= src[r*lds + c] for c < cols: Concatenate's channel blocks and gradient accumulation. */
+int spnet_copy_cols(const float* src, int lds, float* dst, int ldd, long rows, int cols, int accumulate, void* stream);
+
 /* ---- small-channel direct 3x3 convs: stem conv2d_1..3 (models.py:321,330,335), block1_conv1 ---- */
 /* op 0 fwd (a=x,b=w,out=y) | 1 bwd-data (a=dy,b=w,out=dx) | 2 bwd-weight (a=x,b=dy,out=dw).
  * (cin,cout,stride,same) in {(1,3,1,1), (3,3,1,1), (3,32,2,0)}; w is HWIO. */

@@ -230,6 +230,158 @@ def mobilenet_out_hw(H, W):
     return h, w
 
 
+# ------------------------------------------------------------------ Inception-ResNet-v2 (keras.applications 2.1.3)
+def irv2_layers():
+    """keras.applications.inception_resnet_v2.InceptionResNetV2(include_top=False) as a flat program.
+
+    Ops (executed in order; `src` / `dst` name tensors in a small register file):
+      ("conv", name, bn_name|None, src, dst, cin, cout, (kh, kw), stride, padding, relu, bias)
+      ("maxpool", src, dst)                       MaxPooling2D(3, strides=2, 'valid')
+      ("avgpool", src, dst)                       AveragePooling2D(3, strides=1, 'same')
+      ("concat", [srcs], dst, name)
+      ("resadd", x, up, dst, scale, relu)         x + scale * up, optional ReLU (the Lambda + Activation of a block)
+    conv2d_bn layers are auto-named by Keras in creation order: conv2d_4.. / batch_normalization_4.. behind the stem's
+    three; BatchNormalization(scale=False): no gamma."""
+    ops = []
+    ctr = [3]
+
+    def conv(src, dst, cin, cout, k, stride=1, padding="same", relu=True, name=None, bias=False):
+        kk = (k, k) if isinstance(k, int) else tuple(k)
+        if name is None:
+            ctr[0] += 1
+            cname, bname = "conv2d_%d" % ctr[0], "batch_normalization_%d" % ctr[0]
+        else:
+            cname, bname = name, name + "_bn"
+        ops.append(("conv", cname, None if bias else bname, src, dst, cin, cout, kk, stride, padding, relu, bias))
+        return cout
+
+    c = conv("in", "x", 3, 32, 3, 2, "valid")
+    c = conv("x", "x", c, 32, 3, 1, "valid")
+    c = conv("x", "x", c, 64, 3)
+    ops.append(("maxpool", "x", "x"))
+    c = conv("x", "x", c, 80, 1, 1, "valid")
+    c = conv("x", "x", c, 192, 3, 1, "valid")
+    ops.append(("maxpool", "x", "x"))
+    # mixed_5b
+    conv("x", "b0", 192, 96, 1)
+    conv("x", "b1", 192, 48, 1); conv("b1", "b1", 48, 64, 5)
+    conv("x", "b2", 192, 64, 1); conv("b2", "b2", 64, 96, 3); conv("b2", "b2", 96, 96, 3)
+    ops.append(("avgpool", "x", "bp")); conv("bp", "bp", 192, 64, 1)
+    ops.append(("concat", ["b0", "b1", "b2", "bp"], "x", "mixed_5b"))
+    c = 320
+
+    def block(kind, idx, c, scale, relu=True):
+        if kind == "block35":
+            conv("x", "b0", c, 32, 1)
+            conv("x", "b1", c, 32, 1); conv("b1", "b1", 32, 32, 3)
+            conv("x", "b2", c, 32, 1); conv("b2", "b2", 32, 48, 3); conv("b2", "b2", 48, 64, 3)
+            br, cm = ["b0", "b1", "b2"], 128
+        elif kind == "block17":
+            conv("x", "b0", c, 192, 1)
+            conv("x", "b1", c, 128, 1); conv("b1", "b1", 128, 160, (1, 7)); conv("b1", "b1", 160, 192, (7, 1))
+            br, cm = ["b0", "b1"], 384
+        else:
+            conv("x", "b0", c, 192, 1)
+            conv("x", "b1", c, 192, 1); conv("b1", "b1", 192, 224, (1, 3)); conv("b1", "b1", 224, 256, (3, 1))
+            br, cm = ["b0", "b1"], 448
+        name = "%s_%d" % (kind, idx)
+        ops.append(("concat", br, "m", name + "_mixed"))
+        conv("m", "up", cm, c, 1, relu=False, name=name + "_conv", bias=True)
+        ops.append(("resadd", "x", "up", "x", scale, relu))
+
+    for i in range(1, 11):
+        block("block35", i, 320, 0.17)
+    # mixed_6a
+    conv("x", "b0", 320, 384, 3, 2, "valid")
+    conv("x", "b1", 320, 256, 1); conv("b1", "b1", 256, 256, 3); conv("b1", "b1", 256, 384, 3, 2, "valid")
+    ops.append(("maxpool", "x", "bp"))
+    ops.append(("concat", ["b0", "b1", "bp"], "x", "mixed_6a"))
+    for i in range(1, 21):
+        block("block17", i, 1088, 0.1)
+    # mixed_7a
+    conv("x", "b0", 1088, 256, 1); conv("b0", "b0", 256, 384, 3, 2, "valid")
+    conv("x", "b1", 1088, 256, 1); conv("b1", "b1", 256, 288, 3, 2, "valid")
+    conv("x", "b2", 1088, 256, 1); conv("b2", "b2", 256, 288, 3); conv("b2", "b2", 288, 320, 3, 2, "valid")
+    ops.append(("maxpool", "x", "bp"))
+    ops.append(("concat", ["b0", "b1", "b2", "bp"], "x", "mixed_7a"))
+    for i in range(1, 10):
+        block("block8", i, 2080, 0.2)
+    block("block8", 10, 2080, 1.0, relu=False)
+    conv("x", "x", 2080, 1536, 1, name="conv_7b")
+    return ops
+
+
+def irv2_out_hw(H, W):
+    h, w = H // 2, W // 2                      # SPNet stem avgpool
+    v = lambda n, k, s: (n - k) // s + 1
+    h, w = v(h, 3, 2), v(w, 3, 2)
+    h, w = v(h, 3, 1), v(w, 3, 1)
+    h, w = v(h, 3, 2), v(w, 3, 2)
+    h, w = v(h, 3, 1), v(w, 3, 1)
+    h, w = v(h, 3, 2), v(w, 3, 2)              # 35x35 stage for a 299x299 network input
+    h, w = v(h, 3, 2), v(w, 3, 2)              # mixed_6a
+    h, w = v(h, 3, 2), v(w, 3, 2)              # mixed_7a
+    return h, w
+
+
+def maxpool3x3s2_valid(x, decisions=None):
+    B, H, W, C = x.shape
+    if decisions is None:
+        return _nhwc(F.max_pool2d(_nchw(x), 3, 2))
+    oh, ow = (H - 3) // 2 + 1, (W - 3) // 2 + 1
+    cols = F.unfold(_nchw(x), 3, stride=2).reshape(B, C, 9, oh, ow)
+    return _nhwc(cols.gather(2, decisions.pool_taps(cols)).squeeze(2))
+
+
+def avgpool3x3s1_same(x):
+    """AveragePooling2D(3, strides=1, padding='same'): TF averages over the VALID window entries only."""
+    return _nhwc(F.avg_pool2d(_nchw(x), 3, 1, 1, count_include_pad=False))
+
+
+def conv2d_general(x, w_hwio, stride, padding):
+    """Conv2D with a rectangular kernel, TF 'same' / 'valid' (conv2d above is the square-kernel case)."""
+    kh, kw = w_hwio.shape[0], w_hwio.shape[1]
+    xc = _nchw(x)
+    if padding == "same":
+        H, W = x.shape[1], x.shape[2]
+        oh, ow = -(-H // stride), -(-W // stride)
+        ph = max((oh - 1) * stride + kh - H, 0)
+        pw = max((ow - 1) * stride + kw - W, 0)
+        xc = F.pad(xc, (pw // 2, pw - pw // 2, ph // 2, ph - ph // 2))
+    return _nhwc(F.conv2d(xc, w_hwio.permute(3, 2, 0, 1), stride=stride))
+
+
+def backbone_irv2(P, x, training, taps=None, decisions=None):
+    reg = {"in": x}
+    for op in irv2_layers():
+        kind = op[0]
+        if kind == "conv":
+            _, cname, bname, src, dst, cin, cout, kk, stride, padding, relu, bias = op
+            t = conv2d_general(reg[src], P[cname + "/kernel"], stride, padding)
+            if bias:
+                t = t + P[cname + "/bias"]
+            else:
+                t = batchnorm(t, 1.0, P[bname + "/beta"], P[bname + "/moving_mean"], P[bname + "/moving_variance"], training)
+            if relu:
+                t = _act(t, 0.0, decisions)
+            reg[dst] = t
+        elif kind == "maxpool":
+            reg[op[2]] = maxpool3x3s2_valid(reg[op[1]], decisions)
+        elif kind == "avgpool":
+            reg[op[2]] = avgpool3x3s1_same(reg[op[1]])
+        elif kind == "concat":
+            reg[op[2]] = torch.cat([reg[s_] for s_ in op[1]], dim=-1)
+            if taps is not None:
+                taps[op[3]] = reg[op[2]]
+        elif kind == "resadd":
+            _, xs, up, dst, scale, relu = op
+            t = reg[xs] + scale * reg[up]
+            reg[dst] = _act(t, 0.0, decisions) if relu else t
+    if taps is not None:
+        taps["backbone"] = reg["x"]
+    return reg["x"]
+
+
 def backbone_out_hw(H, W):
     h, w = H // 2, W // 2                      # stem avgpool
     h, w = (h - 3) // 2 + 1, (w - 3) // 2 + 1  # block1_conv1 3x3/s2 valid
@@ -267,6 +419,23 @@ def init_params(H, W, n_out=576, seed=0, dtype=torch.float32, basemodel="Xceptio
     bn("batch_normalization_2", 3)
     conv("conv2d_3", 3, 3, 3)
     bn("batch_normalization_3", 3)
+    if basemodel == "InceptionResNetV2":
+        for op in irv2_layers():
+            if op[0] != "conv":
+                continue
+            _, cname, bname, src, dst, cin, cout, kk, stride, padding, relu, bias = op
+            P[cname + "/kernel"] = _glorot((kk[0], kk[1], cin, cout), cin * kk[0] * kk[1], cout * kk[0] * kk[1], g, dtype)
+            if bias:
+                P[cname + "/bias"] = torch.zeros(cout, dtype=dtype)
+            else:                                  # BatchNormalization(scale=False): beta + moving statistics only
+                P[bname + "/beta"] = torch.zeros(cout, dtype=dtype)
+                P[bname + "/moving_mean"] = torch.zeros(cout, dtype=dtype)
+                P[bname + "/moving_variance"] = torch.ones(cout, dtype=dtype)
+        h, w = irv2_out_hw(H, W)
+        nin = h * w * 1536
+        P["FinalOutput/kernel"] = _glorot((nin, n_out), nin, n_out, g, dtype)
+        P["FinalOutput/bias"] = torch.zeros(n_out, dtype=dtype)
+        return P
     if basemodel == "MobileNet":
         conv("conv1", 3, 3, 32)
         bn("conv1_bn", 32)
@@ -394,7 +563,8 @@ def forward(P, X, training=False, drop_mask=None, taps=None, decisions=None, sig
     sigmoid_cols=(start, step): the 'compound' head (spnet/models.py:379-386) -- Dense(n_preds, sigmoid) and
     Dense(rest) re-ordered by InterleaveColumns == one dense layer whose columns start::step pass through a sigmoid."""
     x = stem(P, X, training, drop_mask, taps, decisions)
-    x = (backbone_mobilenet if "conv1/kernel" in P else backbone)(P, x, training, taps, decisions)
+    net = backbone_mobilenet if "conv1/kernel" in P else (backbone_irv2 if "conv_7b/kernel" in P else backbone)
+    x = net(P, x, training, taps, decisions)
     flat = x.reshape(x.shape[0], -1)          # NHWC flatten order (Keras Flatten on channels_last)
     y = flat @ P["FinalOutput/kernel"] + P["FinalOutput/bias"]
     if sigmoid_cols is not None:
@@ -423,6 +593,8 @@ def custom_loss(y_true, y_pred, loss_type="same"):
 
 
 def l2_penalty(P):
+    if "conv_7b/kernel" in P:      # Inception-ResNet-v2: every Conv2D / Dense kernel (all are plain Conv2D layers)
+        return sum(L2 * (v ** 2).sum() for k, v in P.items() if k.endswith("/kernel"))
     names = L2_KERNELS_MOBILENET if "conv1/kernel" in P else L2_KERNELS
     return sum(L2 * (P[n + "/kernel"] ** 2).sum() for n in names)
 

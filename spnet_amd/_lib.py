@@ -57,6 +57,13 @@ _SIGS = {
     "spnet_bn_bwd": (c_int, [P, P, c_long, c_int, P, P, P, P, c_int, P, P, P, P, P, P]),
     "spnet_maxpool3x3s2_add_fwd": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, P, P, P]),
     "spnet_maxpool3x3s2_bwd": (c_int, [P, P, P, c_int, c_int, c_int, c_int, P]),
+    "spnet_maxpool3x3s2_valid_fwd": (c_int, [P, P, P, c_int, c_int, c_int, c_int, P]),
+    "spnet_maxpool3x3s2_valid_bwd": (c_int, [P, P, P, c_int, c_int, c_int, c_int, P]),
+    "spnet_avgpool3x3s1_same": (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, P]),
+    "spnet_patches": (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P]),
+    "spnet_resadd": (c_int, [P, P, P, c_long, c_float, c_int, P]),
+    "spnet_resadd_bwd": (c_int, [P, P, P, P, c_long, c_float, c_int, P]),
+    "spnet_copy_cols": (c_int, [P, c_int, P, c_int, c_long, c_int, c_int, P]),
     "spnet_avgpool2_fwd": (c_int, [P, P, c_int, c_int, c_int, c_int, P]),
     "spnet_avgpool2_bwd": (c_int, [P, P, c_int, c_int, c_int, c_int, P]),
     "spnet_conv3x3_small": (c_int, [c_int, c_int, c_int, c_int, c_int, P, P, P, c_int, c_int, c_int, P, c_long, P]),

@@ -1,0 +1,161 @@
+// General k_h x k_w convolutions of keras InceptionResNetV2 (3x3, 5x5, 1x7, 7x1, 1x3, 3x1; strides 1 | 2; 'same' |
+// 'valid'; call site spnet/models.py:357-359 with cf.basemodel = 'InceptionResNetV2') as patch gather + the fp32 MFMA
+// GEMM of gemm.hip, and the block glue of inception_resnet_block: x + scale*up (+ ReLU) and gradient accumulation.
+// All tensors NHWC fp32 with C % 4 == 0 (the one 3-channel conv of the network is block1_conv1's shape and runs the
+// direct kernel of stem.hip); K index of a patch row = (kh*KW + kw)*C + c, i.e. the flattened HWIO kernel is the GEMM's
+// B operand as it stands.
+#include "common.h"
+
+// col[(b,oh,ow)][(kh,kw,c)] = x[b, oh*s - pt + kh, ow*s - pl + kw, c]  (zero outside the image)
+__global__ __launch_bounds__(256) void im2col_kernel(const float* __restrict__ x, float* __restrict__ col, int Bn, int H,
+                                                     int W, int C, int KH, int KW, int s, int pt, int pl, int OH, int OW) {
+  const int c4n = C >> 2;
+  const long total = (long)Bn * OH * OW * KH * KW * c4n;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int c4 = (int)(i % c4n);
+    long t = i / c4n;
+    const int kw = (int)(t % KW);
+    t /= KW;
+    const int kh = (int)(t % KH);
+    t /= KH;
+    const int ow = (int)(t % OW);
+    t /= OW;
+    const int oh = (int)(t % OH);
+    const int b = (int)(t / OH);
+    const int h = oh * s - pt + kh, w = ow * s - pl + kw;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (h >= 0 && h < H && w >= 0 && w < W) v = *reinterpret_cast<const float4*>(x + (((long)b * H + h) * W + w) * C + c4 * 4);
+    *reinterpret_cast<float4*>(col + i * 4) = v;
+  }
+}
+
+// dx[b,h,w,c] = sum over the patches (oh,ow) and taps (kh,kw) that read (h,w) of dcol  (gather form: no atomics)
+__global__ __launch_bounds__(256) void col2im_kernel(const float* __restrict__ dcol, float* __restrict__ dx, int Bn, int H,
+                                                     int W, int C, int KH, int KW, int s, int pt, int pl, int OH, int OW) {
+  const int c4n = C >> 2;
+  const long total = (long)Bn * H * W * c4n;
+  const long K = (long)KH * KW * C;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int c4 = (int)(i % c4n);
+    long t = i / c4n;
+    const int w = (int)(t % W);
+    t /= W;
+    const int h = (int)(t % H);
+    const int b = (int)(t / H);
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int kh = 0; kh < KH; ++kh) {
+      const int hh = h + pt - kh;
+      if (hh < 0 || hh % s) continue;
+      const int oh = hh / s;
+      if (oh >= OH) continue;
+      for (int kw = 0; kw < KW; ++kw) {
+        const int ww = w + pl - kw;
+        if (ww < 0 || ww % s) continue;
+        const int ow = ww / s;
+        if (ow >= OW) continue;
+        const float4 v = *reinterpret_cast<const float4*>(dcol + (((long)b * OH + oh) * OW + ow) * K + ((long)kh * KW + kw) * C + c4 * 4);
+        acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+      }
+    }
+    *reinterpret_cast<float4*>(dx + i * 4) = acc;
+  }
+}
+
+static void conv_geom(int in, int k, int s, int same, int* out, int* before) {
+  if (same) {
+    *out = (in + s - 1) / s;
+    int total = (*out - 1) * s + k - in;
+    if (total < 0) total = 0;
+    *before = total / 2;
+  } else {
+    *out = (in - k) / s + 1;
+    *before = 0;
+  }
+}
+
+// backward == 0: col [B*OH*OW][KH*KW*C] from x;  backward == 1: dx [B][H][W][C] from dcol (x = dcol, out = dx).
+extern "C" int spnet_patches(const float* in, float* out, int B, int H, int W, int C, int KH, int KW, int stride, int same,
+                             int backward, void* stream) {
+  if ((C & 3) || KH < 1 || KW < 1 || (stride != 1 && stride != 2)) return (int)hipErrorInvalidValue;
+  int OH, OW, pt, pl;
+  conv_geom(H, KH, stride, same, &OH, &pt);
+  conv_geom(W, KW, stride, same, &OW, &pl);
+  if (OH < 1 || OW < 1) return (int)hipErrorInvalidValue;
+  if (!backward) {
+    const long total = (long)B * OH * OW * KH * KW * (C / 4);
+    hipLaunchKernelGGL(im2col_kernel, dim3(spnet_ew_grid(total, 256)), dim3(256), 0, (hipStream_t)stream, in, out, B, H, W,
+                       C, KH, KW, stride, pt, pl, OH, OW);
+  } else {
+    const long total = (long)B * H * W * (C / 4);
+    hipLaunchKernelGGL(col2im_kernel, dim3(spnet_ew_grid(total, 256)), dim3(256), 0, (hipStream_t)stream, in, out, B, H, W,
+                       C, KH, KW, stride, pt, pl, OH, OW);
+  }
+  SPNET_RETURN_LAUNCH_STATUS();
+}
+
+// inception_resnet_block's Lambda + Activation: y = x + scale*up, ReLU if relu.
+// backward (y = the forward OUTPUT, g = dL/dy): gm = g * (y > 0 if relu); dup = scale * gm; dx = gm (written only when
+// dx != g: with dx == g and no ReLU the incoming buffer already is the x-branch gradient).
+__global__ __launch_bounds__(256) void resadd_kernel(const float* __restrict__ x, const float* __restrict__ up,
+                                                     float* __restrict__ y, long n4, float scale, int relu) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+    const float4 a = *reinterpret_cast<const float4*>(x + i * 4), u = *reinterpret_cast<const float4*>(up + i * 4);
+    float4 o = make_float4(fmaf(scale, u.x, a.x), fmaf(scale, u.y, a.y), fmaf(scale, u.z, a.z), fmaf(scale, u.w, a.w));
+    if (relu) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
+    *reinterpret_cast<float4*>(y + i * 4) = o;
+  }
+}
+__global__ __launch_bounds__(256) void resadd_bwd_kernel(const float* __restrict__ y, const float* __restrict__ g,
+                                                         float* __restrict__ dx, float* __restrict__ dup, long n4,
+                                                         float scale, int relu) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+    float4 v = *reinterpret_cast<const float4*>(g + i * 4);
+    if (relu) {
+      const float4 o = *reinterpret_cast<const float4*>(y + i * 4);
+      v.x = o.x > 0.f ? v.x : 0.f; v.y = o.y > 0.f ? v.y : 0.f; v.z = o.z > 0.f ? v.z : 0.f; v.w = o.w > 0.f ? v.w : 0.f;
+    }
+    *reinterpret_cast<float4*>(dx + i * 4) = v;
+    *reinterpret_cast<float4*>(dup + i * 4) = make_float4(scale * v.x, scale * v.y, scale * v.z, scale * v.w);
+  }
+}
+
+extern "C" int spnet_resadd(const float* x, const float* up, float* y, long n, float scale, int relu, void* stream) {
+  if (n & 3) return (int)hipErrorInvalidValue;
+  hipLaunchKernelGGL(resadd_kernel, dim3(spnet_ew_grid(n / 4, 256)), dim3(256), 0, (hipStream_t)stream, x, up, y, n / 4, scale,
+                     relu);
+  SPNET_RETURN_LAUNCH_STATUS();
+}
+extern "C" int spnet_resadd_bwd(const float* y, const float* g, float* dx, float* dup, long n, float scale, int relu,
+                                void* stream) {
+  if (n & 3) return (int)hipErrorInvalidValue;
+  hipLaunchKernelGGL(resadd_bwd_kernel, dim3(spnet_ew_grid(n / 4, 256)), dim3(256), 0, (hipStream_t)stream, y, g, dx, dup,
+                     n / 4, scale, relu);
+  SPNET_RETURN_LAUNCH_STATUS();
+}
+
+// Gradient accumulation where a tensor feeds several branches, and channel-block copies for Concatenate:
+// dst[r*ldd + c] (+)= src[r*lds + c], c < cols (cols, ldd, lds multiples of 4).
+__global__ __launch_bounds__(256) void copy_cols_kernel(const float* __restrict__ src, int lds, float* __restrict__ dst,
+                                                        int ldd, long rows, int cols, int accumulate) {
+  const int c4n = cols >> 2;
+  const long total = rows * c4n;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long r = i / c4n;
+    const int c = (int)(i % c4n) * 4;
+    float4 v = *reinterpret_cast<const float4*>(src + r * lds + c);
+    float4* d = reinterpret_cast<float4*>(dst + r * ldd + c);
+    if (accumulate) {
+      const float4 o = *d;
+      v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
+    }
+    *d = v;
+  }
+}
+
+extern "C" int spnet_copy_cols(const float* src, int lds, float* dst, int ldd, long rows, int cols, int accumulate,
+                               void* stream) {
+  if ((cols & 3) || (lds & 3) || (ldd & 3) || rows < 1) return (int)hipErrorInvalidValue;
+  hipLaunchKernelGGL(copy_cols_kernel, dim3(spnet_ew_grid(rows * (cols / 4), 256)), dim3(256), 0, (hipStream_t)stream, src,
+                     lds, dst, ldd, rows, cols, accumulate ? 1 : 0);
+  SPNET_RETURN_LAUNCH_STATUS();
+}

@@ -185,3 +185,76 @@ extern "C" int spnet_avgpool2_bwd(const float* dy, float* dx, int B, int H, int 
                      (hipStream_t)stream, dy, dx, B, H, W, C, OH, OW);
   SPNET_RETURN_LAUNCH_STATUS();
 }
+
+// ---------------------------------------------------------------- Inception-ResNet-v2 pooling layers
+// MaxPooling2D(3, strides=2, padding='valid') (stem, mixed_6a, mixed_7a of keras InceptionResNetV2; call site
+// spnet/models.py:357-359): the same kernels with no padding, no residual and OH = (H-3)/2+1.
+extern "C" int spnet_maxpool3x3s2_valid_fwd(const float* x, float* y, uint32_t* idx4, int B, int H, int W, int C,
+                                            void* stream) {
+  if ((C & 3) || H < 3 || W < 3) return (int)hipErrorInvalidValue;
+  const int OH = (H - 3) / 2 + 1, OW = (W - 3) / 2 + 1;
+  const long total = (long)B * OH * OW * (C / 4);
+  hipLaunchKernelGGL(maxpool_add_fwd_kernel, dim3(spnet_ew_grid(total, 256)), dim3(256), 0, (hipStream_t)stream, x,
+                     (const float*)nullptr, y, idx4, B, H, W, C, OH, OW, 0, 0, (const float*)nullptr, (const float*)nullptr);
+  SPNET_RETURN_LAUNCH_STATUS();
+}
+
+extern "C" int spnet_maxpool3x3s2_valid_bwd(const float* dy, const uint32_t* idx4, float* dx, int B, int H, int W, int C,
+                                            void* stream) {
+  if ((C & 3) || H < 3 || W < 3) return (int)hipErrorInvalidValue;
+  const int OH = (H - 3) / 2 + 1, OW = (W - 3) / 2 + 1;
+  const long total = (long)B * H * W * (C / 4);
+  hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(spnet_ew_grid(total, 256)), dim3(256), 0, (hipStream_t)stream, dy, idx4, dx,
+                     B, H, W, C, OH, OW, 0, 0);
+  SPNET_RETURN_LAUNCH_STATUS();
+}
+
+// AveragePooling2D(3, strides=1, padding='same') (mixed_5b): TensorFlow averages over the window entries that lie
+// inside the image only.  bwd = 1: dx[p] = sum over the windows q containing p of dy[q] / count(q).
+__global__ __launch_bounds__(256) void avgpool3x3s1_kernel(const float* __restrict__ in, float* __restrict__ out, int Bn,
+                                                           int H, int W, int C, int bwd) {
+  const int c4n = C >> 2;
+  const long total = (long)Bn * H * W * c4n;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int c4 = (int)(i % c4n);
+    long t = i / c4n;
+    const int w = (int)(t % W);
+    t /= W;
+    const int h = (int)(t % H);
+    const int b = (int)(t / H);
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    int n = 0;
+#pragma unroll
+    for (int dh = -1; dh <= 1; ++dh) {
+      const int hh = h + dh;
+      if (hh < 0 || hh >= H) continue;
+#pragma unroll
+      for (int dw = -1; dw <= 1; ++dw) {
+        const int ww = w + dw;
+        if (ww < 0 || ww >= W) continue;
+        const float4 v = *reinterpret_cast<const float4*>(in + (((long)b * H + hh) * W + ww) * C + c4 * 4);
+        float k = 1.f;
+        if (bwd) {   // weight of window (hh, ww): 1 / number of its entries inside the image
+          const int nh = min(hh + 1, H - 1) - max(hh - 1, 0) + 1, nw = min(ww + 1, W - 1) - max(ww - 1, 0) + 1;
+          k = 1.f / (float)(nh * nw);
+        }
+        s.x = fmaf(v.x, k, s.x); s.y = fmaf(v.y, k, s.y); s.z = fmaf(v.z, k, s.z); s.w = fmaf(v.w, k, s.w);
+        ++n;
+      }
+    }
+    if (!bwd) {
+      const float k = 1.f / (float)n;
+      s.x *= k; s.y *= k; s.z *= k; s.w *= k;
+    }
+    *reinterpret_cast<float4*>(out + i * 4) = s;
+  }
+}
+
+extern "C" int spnet_avgpool3x3s1_same(const float* in, float* out, int B, int H, int W, int C, int backward,
+                                       void* stream) {
+  if (C & 3) return (int)hipErrorInvalidValue;
+  const long total = (long)B * H * W * (C / 4);
+  hipLaunchKernelGGL(avgpool3x3s1_kernel, dim3(spnet_ew_grid(total, 256)), dim3(256), 0, (hipStream_t)stream, in, out, B, H,
+                     W, C, backward ? 1 : 0);
+  SPNET_RETURN_LAUNCH_STATUS();
+}

@@ -95,6 +95,104 @@ def backbone_out_hw(H, W):
     return h, w
 
 
+def irv2_program():
+    """keras.applications.inception_resnet_v2.InceptionResNetV2(include_top=False) (Keras 2.1.3; call site
+    spnet/models.py:357-359 with cf.basemodel = 'InceptionResNetV2') as a flat list of operations over named tensors:
+      ("conv", conv_name, bn_name | None, src, dst, cin, cout, (kh, kw), stride, same, relu, bias)
+      ("maxpool", src, dst) | ("avgpool", src, dst) | ("concat", [srcs], dst, name) | ("resadd", x, up, dst, scale, relu)
+    Unnamed conv2d_bn layers get Keras' creation-order names conv2d_4.. / batch_normalization_4.. (the stem owns 1-3);
+    their BatchNormalization has scale=False (no gamma)."""
+    ops, ctr = [], [3]
+
+    def conv(src, dst, cin, cout, k, stride=1, same=True, relu=True, name=None, bias=False):
+        kk = (k, k) if isinstance(k, int) else tuple(k)
+        if name is None:
+            ctr[0] += 1
+            cname, bname = "conv2d_%d" % ctr[0], "batch_normalization_%d" % ctr[0]
+        else:
+            cname, bname = name, name + "_bn"
+        ops.append(("conv", cname, None if bias else bname, src, dst, cin, cout, kk, stride, same, relu, bias))
+
+    # stem
+    conv("in", "x", 3, 32, 3, 2, False)
+    conv("x", "x", 32, 32, 3, 1, False)
+    conv("x", "x", 32, 64, 3)
+    ops.append(("maxpool", "x", "x"))
+    conv("x", "x", 64, 80, 1, 1, False)
+    conv("x", "x", 80, 192, 3, 1, False)
+    ops.append(("maxpool", "x", "x"))
+    # mixed_5b (Inception-A)
+    conv("x", "b0", 192, 96, 1)
+    conv("x", "b1", 192, 48, 1)
+    conv("b1", "b1", 48, 64, 5)
+    conv("x", "b2", 192, 64, 1)
+    conv("b2", "b2", 64, 96, 3)
+    conv("b2", "b2", 96, 96, 3)
+    ops.append(("avgpool", "x", "bp"))
+    conv("bp", "bp", 192, 64, 1)
+    ops.append(("concat", ["b0", "b1", "b2", "bp"], "x", "mixed_5b"))
+
+    def block(kind, idx, c, scale, relu=True):
+        if kind == "block35":
+            conv("x", "b0", c, 32, 1)
+            conv("x", "b1", c, 32, 1)
+            conv("b1", "b1", 32, 32, 3)
+            conv("x", "b2", c, 32, 1)
+            conv("b2", "b2", 32, 48, 3)
+            conv("b2", "b2", 48, 64, 3)
+            br, cm = ["b0", "b1", "b2"], 128
+        elif kind == "block17":
+            conv("x", "b0", c, 192, 1)
+            conv("x", "b1", c, 128, 1)
+            conv("b1", "b1", 128, 160, (1, 7))
+            conv("b1", "b1", 160, 192, (7, 1))
+            br, cm = ["b0", "b1"], 384
+        else:
+            conv("x", "b0", c, 192, 1)
+            conv("x", "b1", c, 192, 1)
+            conv("b1", "b1", 192, 224, (1, 3))
+            conv("b1", "b1", 224, 256, (3, 1))
+            br, cm = ["b0", "b1"], 448
+        name = "%s_%d" % (kind, idx)
+        ops.append(("concat", br, "m", name + "_mixed"))
+        conv("m", "up", cm, c, 1, relu=False, name=name + "_conv", bias=True)
+        ops.append(("resadd", "x", "up", "x", scale, relu))
+
+    for i in range(1, 11):
+        block("block35", i, 320, 0.17)
+    # mixed_6a (Reduction-A)
+    conv("x", "b0", 320, 384, 3, 2, False)
+    conv("x", "b1", 320, 256, 1)
+    conv("b1", "b1", 256, 256, 3)
+    conv("b1", "b1", 256, 384, 3, 2, False)
+    ops.append(("maxpool", "x", "bp"))
+    ops.append(("concat", ["b0", "b1", "bp"], "x", "mixed_6a"))
+    for i in range(1, 21):
+        block("block17", i, 1088, 0.1)
+    # mixed_7a (Reduction-B)
+    conv("x", "b0", 1088, 256, 1)
+    conv("b0", "b0", 256, 384, 3, 2, False)
+    conv("x", "b1", 1088, 256, 1)
+    conv("b1", "b1", 256, 288, 3, 2, False)
+    conv("x", "b2", 1088, 256, 1)
+    conv("b2", "b2", 256, 288, 3)
+    conv("b2", "b2", 288, 320, 3, 2, False)
+    ops.append(("maxpool", "x", "bp"))
+    ops.append(("concat", ["b0", "b1", "b2", "bp"], "x", "mixed_7a"))
+    for i in range(1, 10):
+        block("block8", i, 2080, 0.2)
+    block("block8", 10, 2080, 1.0, relu=False)
+    conv("x", "x", 2080, 1536, 1, name="conv_7b")
+    return ops
+
+
+def irv2_out_hw(H, W):
+    h, w = H // 2, W // 2
+    for k, s_ in ((3, 2), (3, 1), (3, 2), (3, 1), (3, 2), (3, 2), (3, 2)):     # valid convs / pools that shrink the plane
+        h, w = (h - k) // s_ + 1, (w - k) // s_ + 1
+    return h, w
+
+
 def mobilenet_out_hw(H, W):
     h, w = H // 2, W // 2
     h, w = (h + 1) // 2, (w + 1) // 2
@@ -122,6 +220,24 @@ def param_specs(H, W, n_out=576, backbone="Xception"):
     bn("batch_normalization_2", 3)
     specs.append(("conv2d_3/kernel", (3, 3, 3, 3), True, True))
     bn("batch_normalization_3", 3)
+    if backbone == "InceptionResNetV2":
+        for op in irv2_program():
+            if op[0] != "conv":
+                continue
+            _, cname, bname, _, _, cin, cout, kk, _, _, _, bias = op
+            specs.append((cname + "/kernel", (kk[0], kk[1], cin, cout), True, True))
+            if bias:
+                specs.append((cname + "/bias", (cout,), True, False))
+            else:                  # BatchNormalization(scale=False)
+                specs.append((bname + "/beta", (cout,), True, False))
+                specs.append((bname + "/moving_mean", (cout,), False, False))
+                specs.append((bname + "/moving_variance", (cout,), False, False))
+        h, w = irv2_out_hw(H, W)
+        if h < 1 or w < 1:
+            raise ValueError("frames of %dx%d are too small for InceptionResNetV2 (needs >= 150x150)" % (H, W))
+        specs.append(("FinalOutput/kernel", (h * w * 1536, n_out), True, True))
+        specs.append(("FinalOutput/bias", (n_out,), True, False))
+        return specs
     if backbone == "MobileNet":
         specs.append(("conv1/kernel", (3, 3, 3, 32), True, True))
         bn("conv1_bn", 32)
@@ -184,8 +300,9 @@ class Engine:
         # (start, step) of the output columns that pass through a sigmoid: the 'compound' head of the reference
         # (models.py:379-386) = one dense layer with sigmoid 'noobj' columns once InterleaveColumns has re-ordered them
         self.sigmoid_cols = sigmoid_cols
-        if backbone not in ("Xception", "MobileNet"):
-            raise NotImplementedError("backbone %r: this build implements Xception and MobileNet" % (backbone,))
+        if backbone not in ("Xception", "MobileNet", "InceptionResNetV2"):
+            raise NotImplementedError("backbone %r: this build implements Xception, MobileNet and InceptionResNetV2"
+                                      % (backbone,))
         self.backbone = backbone
         self.dev = torch.device(device)
         self.loss_type = loss_type
@@ -272,6 +389,8 @@ class Engine:
                 self.l2_n = off          # prefix (incl. alignment padding, which stays zero)
             if name.endswith("depthwise_kernel"):
                 self.rest_lo = off       # first offset behind the depthwise kernels
+        if not any(n.endswith("depthwise_kernel") for n, _, _, _ in order):
+            self.rest_lo = self.l2_n     # no depthwise kernels (InceptionResNetV2): the rest starts behind the l2 prefix
         self.n_theta = off
         s_off = 0
         self.s_off = OrderedDict()
@@ -385,6 +504,10 @@ class Engine:
         self.stem_out = d.y
         if self.backbone == "MobileNet":
             return self._build_mobilenet(d.y)
+        if self.backbone == "InceptionResNetV2":
+            net = IRv2Backbone(self, d.y); n.append(net)
+            self.backbone_out = net.y
+            return self._build_head(net.y)
         # ---- Xception entry flow, block 1
         e1 = SmallConv(self, d.y, 3, 32, 2, False, "block1_conv1"); n.append(e1)
         b1 = BatchNorm(self, e1.y, 32, "block1_conv1_bn", ACT_RELU); n.append(b1)
@@ -1350,6 +1473,248 @@ class ExitBlock(Node):
 
     def bwd(self, g):
         return self.u1.bwd(self.u2.bwd(g))
+
+
+class _T:
+    """A tensor of the Inception-ResNet-v2 program: forward buffer + the gradient accumulated from its consumers."""
+
+    def __init__(self, buf):
+        self.buf, self.g = buf, None
+
+
+class IRv2Backbone(Node):
+    """keras InceptionResNetV2(include_top=False) behind the stem (spnet/models.py:357-359, cf.basemodel =
+    'InceptionResNetV2'): irv2_program() executed op by op.  Convolutions = [patch gather +] fp32 MFMA GEMM
+    (spnet_patches + spnet_gemm_f32; 1x1 convs multiply the activation matrix directly; the 3-channel first conv runs
+    the direct kernel), BatchNormalization(scale=False) + ReLU through the stand-alone BN kernels, Concatenate and
+    the branch fan-out as channel-block copies / gradient accumulation (spnet_copy_cols), x + scale*up through
+    spnet_resadd.  Backward walks the program in reverse; a tensor's gradient is complete when its producer is reached."""
+
+    def __init__(self, eng, x):
+        self.e = eng
+        self.ops = []
+        self.pnames = []
+        cur = {"in": _T(x)}
+        self.t_in = cur["in"]
+        B = eng.B
+        self.ones = {}
+        max_dcol = 0
+        for op in irv2_program():
+            kind = op[0]
+            if kind == "conv":
+                _, cname, bname, src, dst, cin, cout, kk, stride, same, relu, bias = op
+                o = _IRConv(eng, self, cur[src], cname, bname, cin, cout, kk, stride, same, relu, bias)
+                max_dcol = max(max_dcol, o.col_floats)
+                self.pnames += [cname] + ([bname] if bname else [])
+                cur[dst] = o.out
+            elif kind in ("maxpool", "avgpool"):
+                o = _IRPool(eng, cur[op[1]], kind)
+                cur[op[2]] = o.out
+            elif kind == "concat":
+                o = _IRConcat(eng, [cur[s_] for s_ in op[1]])
+                cur[op[2]] = o.out
+            else:
+                _, xs, up, dst, scale, relu = op
+                o = _IRResAdd(eng, cur[xs], cur[up], scale, relu)
+                cur[dst] = o.out
+            self.ops.append(o)
+        self.y = cur["x"].buf
+        self.t_out = cur["x"]
+        # one scratch for every conv's patch-matrix gradient (used and consumed on the main stream, op by op)
+        self.dcol = eng.new(max_dcol) if (eng.train_capable and max_dcol) else None
+
+    def const_ones(self, C):
+        if C not in self.ones:
+            self.ones[C] = (torch.ones(C, device=self.e.dev, dtype=torch.float32), self.e.new(C))
+        return self.ones[C]
+
+    def fwd(self, training):
+        for o in self.ops:
+            o.fwd(training)
+
+    def bwd(self, g):
+        for o in self.ops:
+            o.out.g = None
+        self.t_in.g = None
+        self.t_out.g = g
+        for o in reversed(self.ops):
+            o.bwd(self)
+        return self.t_in.g
+
+
+def _ir_acc(t, gbuf, eng):
+    """Add an op's input gradient to the tensor's accumulator (the first contribution becomes the accumulator)."""
+    if t.g is None:
+        t.g = gbuf
+    else:
+        C = gbuf.shape[-1]
+        L.spnet_copy_cols(L.ptr(gbuf), C, L.ptr(t.g), C, gbuf.numel() // C, C, 1, _stream())
+
+
+class _IRConv:
+    def __init__(self, eng, net, src, cname, bname, cin, cout, kk, stride, same, relu, bias):
+        self.e, self.src, self.cin, self.cout = eng, src, cin, cout
+        self.kh, self.kw, self.stride, self.same, self.relu, self.bias = kk[0], kk[1], stride, int(same), relu, bias
+        B, H, W, _ = src.buf.shape
+        self.H, self.W = H, W
+        if same:
+            OH, OW = (H + stride - 1) // stride, (W + stride - 1) // stride
+        else:
+            OH, OW = (H - self.kh) // stride + 1, (W - self.kw) // stride + 1
+        self.M, self.K = B * OH * OW, self.kh * self.kw * cin
+        self.direct = (self.kh == 1 and self.kw == 1 and stride == 1)
+        self.small = (cin == 3)                      # the first conv: 3 -> 32, 3x3 / stride 2 / valid (stem.hip)
+        self.w = eng.P(cname + "/kernel")
+        self.col = None if (self.direct or self.small) else eng.new(self.M, self.K)
+        self.col_floats = 0 if (self.direct or self.small) else self.M * self.K
+        self.out = _T(eng.new(B, OH, OW, cout))
+        tr = eng.train_capable
+        if bias:
+            self.b = eng.P(cname + "/bias")
+            self.gb = eng.G(cname + "/bias") if tr else None
+        else:
+            self.yp = eng.new(B, OH, OW, cout)
+            self.ones, self.gscr = net.const_ones(cout)
+            self.beta = eng.P(bname + "/beta")
+            self.mm, self.mv = eng.S(bname + "/moving_mean"), eng.S(bname + "/moving_variance")
+            self.ss = eng.new(2 * cout)
+            if tr:
+                self.gbeta = eng.G(bname + "/beta")
+                self.save = eng.new(2 * cout)
+        if tr:
+            self.gw = eng.G(cname + "/kernel")
+            self.dx = eng.new(*src.buf.shape)
+
+    def _A(self):
+        return self.src.buf if self.direct else self.col
+
+    def fwd(self, training):
+        e, C = self.e, self.cout
+        y = self.out.buf
+        dst = y if self.bias else self.yp
+        if self.small:
+            L.spnet_conv3x3_small(0, 3, C, self.stride, 0, L.ptr(self.src.buf), L.ptr(self.w), L.ptr(dst), e.B, self.H,
+                                  self.W, e.ws_ptr(WS_MISC), WS_MISC[1], _stream())
+        else:
+            if not self.direct:
+                L.spnet_patches(L.ptr(self.src.buf), L.ptr(self.col), e.B, self.H, self.W, self.cin, self.kh, self.kw,
+                                self.stride, self.same, 0, _stream())
+            _gemm(self._A(), K_MAJOR, self.K, self.w, OUT_MAJOR, C, dst, C, self.M, C, self.K, e,
+                  bias=self.b if self.bias else None)
+        if self.bias:
+            return
+        act = ACT_RELU if self.relu else ACT_NONE
+        if training:
+            L.spnet_bn_fwd_train(L.ptr(self.yp), self.M, C, L.ptr(self.ones), L.ptr(self.beta), L.ptr(self.mm), L.ptr(self.mv),
+                                 L.ptr(self.save), self.save[C:].data_ptr(), L.ptr(self.ss), act, None, 0, L.ptr(y), BN_EPS,
+                                 BN_MOMENTUM, e.ws_ptr(WS_MISC), _stream())
+        else:
+            L.spnet_bn_fwd_infer(L.ptr(self.yp), self.M, C, L.ptr(self.ones), L.ptr(self.beta), L.ptr(self.mm),
+                                 L.ptr(self.mv), L.ptr(self.ss), act, None, 0, L.ptr(y), BN_EPS, _stream())
+
+    def bwd(self, net):
+        e, C, g = self.e, self.cout, self.out.g
+        if self.bias:
+            L.spnet_reduce_rows(L.ptr(g), self.M, C, L.ptr(self.gb), _stream())
+        else:       # BatchNorm (+ReLU) backward in place on the accumulated gradient; gamma is the constant 1
+            L.spnet_bn_bwd(L.ptr(self.yp), L.ptr(g), self.M, C, L.ptr(self.ones), L.ptr(self.beta), L.ptr(self.save),
+                           self.save[C:].data_ptr(), ACT_RELU if self.relu else ACT_NONE, L.ptr(g), L.ptr(self.gscr),
+                           L.ptr(self.gbeta), L.ptr(e.small[:3 * C]), e.ws_ptr(WS_MISC), _stream())
+        side = e.wgrad_stream
+        if self.small:
+            def wgrad(region):
+                L.spnet_conv3x3_small(2, 3, C, self.stride, 0, L.ptr(self.src.buf), L.ptr(g), L.ptr(self.gw), e.B, self.H,
+                                      self.W, e.ws_ptr(region), region[1], _stream())
+        else:
+            def wgrad(region):
+                _gemm(self._A(), OUT_MAJOR, self.K, g, OUT_MAJOR, C, self.gw, C, self.K, C, self.M, e, region=region)
+        if side is None:
+            wgrad(WS_GEMM)
+        else:           # weight gradient off the data-gradient chain (see Pointwise.bwd)
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                wgrad(WS_GEMM2)
+        if self.small:
+            L.spnet_conv3x3_small(1, 3, C, self.stride, 0, L.ptr(g), L.ptr(self.w), L.ptr(self.dx), e.B, self.H, self.W,
+                                  e.ws_ptr(WS_MISC), WS_MISC[1], _stream())
+        elif self.direct:
+            _gemm(g, K_MAJOR, C, self.w, K_MAJOR, C, self.dx, self.K, self.M, self.K, C, e)
+        else:
+            _gemm(g, K_MAJOR, C, self.w, K_MAJOR, C, net.dcol, self.K, self.M, self.K, C, e)
+            L.spnet_patches(L.ptr(net.dcol), L.ptr(self.dx), e.B, self.H, self.W, self.cin, self.kh, self.kw, self.stride,
+                            self.same, 1, _stream())
+        _ir_acc(self.src, self.dx, e)
+
+
+class _IRPool:
+    def __init__(self, eng, src, kind):
+        self.e, self.src, self.kind = eng, src, kind
+        B, H, W, C = src.buf.shape
+        self.H, self.W, self.C = H, W, C
+        if kind == "maxpool":
+            OH, OW = (H - 3) // 2 + 1, (W - 3) // 2 + 1
+            self.idx = torch.empty(B * OH * OW * (C // 4), device=eng.dev, dtype=torch.int32) if eng.train_capable else None
+        else:
+            OH, OW = H, W
+        self.out = _T(eng.new(B, OH, OW, C))
+        self.dx = eng.new(B, H, W, C) if eng.train_capable else None
+
+    def fwd(self, training):
+        e = self.e
+        if self.kind == "maxpool":
+            L.spnet_maxpool3x3s2_valid_fwd(L.ptr(self.src.buf), L.ptr(self.out.buf), L.ptr(self.idx) if training else None,
+                                           e.B, self.H, self.W, self.C, _stream())
+        else:
+            L.spnet_avgpool3x3s1_same(L.ptr(self.src.buf), L.ptr(self.out.buf), e.B, self.H, self.W, self.C, 0, _stream())
+
+    def bwd(self, net):
+        e, g = self.e, self.out.g
+        if self.kind == "maxpool":
+            L.spnet_maxpool3x3s2_valid_bwd(L.ptr(g), L.ptr(self.idx), L.ptr(self.dx), e.B, self.H, self.W, self.C, _stream())
+        else:
+            L.spnet_avgpool3x3s1_same(L.ptr(g), L.ptr(self.dx), e.B, self.H, self.W, self.C, 1, _stream())
+        _ir_acc(self.src, self.dx, e)
+
+
+class _IRConcat:
+    def __init__(self, eng, srcs):
+        self.e, self.srcs = eng, srcs
+        B, H, W, _ = srcs[0].buf.shape
+        self.cs = [t.buf.shape[-1] for t in srcs]
+        self.rows = B * H * W
+        self.out = _T(eng.new(B, H, W, sum(self.cs)))
+        self.dparts = [eng.new(*t.buf.shape) for t in srcs] if eng.train_capable else None
+
+    def fwd(self, training):
+        ct, off = sum(self.cs), 0
+        for t, c in zip(self.srcs, self.cs):
+            L.spnet_copy_cols(L.ptr(t.buf), c, self.out.buf.data_ptr() + 4 * off, ct, self.rows, c, 0, _stream())
+            off += c
+
+    def bwd(self, net):
+        ct, off, g = sum(self.cs), 0, self.out.g
+        for t, c, d in zip(self.srcs, self.cs, self.dparts):
+            L.spnet_copy_cols(g.data_ptr() + 4 * off, ct, L.ptr(d), c, self.rows, c, 0, _stream())
+            _ir_acc(t, d, self.e)
+            off += c
+
+
+class _IRResAdd:
+    def __init__(self, eng, x, up, scale, relu):
+        self.e, self.x, self.up, self.scale, self.relu = eng, x, up, float(scale), int(bool(relu))
+        self.out = _T(eng.new(*x.buf.shape))
+        if eng.train_capable:
+            self.dx, self.dup = eng.new(*x.buf.shape), eng.new(*x.buf.shape)
+
+    def fwd(self, training):
+        L.spnet_resadd(L.ptr(self.x.buf), L.ptr(self.up.buf), L.ptr(self.out.buf), self.out.buf.numel(), self.scale,
+                       self.relu, _stream())
+
+    def bwd(self, net):
+        L.spnet_resadd_bwd(L.ptr(self.out.buf), L.ptr(self.out.g), L.ptr(self.dx), L.ptr(self.dup), self.out.buf.numel(),
+                           self.scale, self.relu, _stream())
+        _ir_acc(self.x, self.dx, self.e)
+        _ir_acc(self.up, self.dup, self.e)
 
 
 class PadSame(Node):

@@ -136,12 +136,25 @@ def keras_layer_table(basemodel=None):
     """Ordered (layer_name, [weight-name prefixes]) list approximating base_model.layers of the
     reference (144 entries: 13 stem layers incl. the input + 131 Xception layers; run log
     'Freezing 0 / 144 layers').  Used only to translate freeze_fac into a set of frozen tensors."""
-    from .engine import MOBILENET_BLOCKS, xception_plan
+    from .engine import MOBILENET_BLOCKS, irv2_program, xception_plan
     t = [("input_1", []), ("conv2d_1", ["conv2d_1"]), ("average_pooling2d_1", []),
          ("batch_normalization_1", ["batch_normalization_1"]), ("leaky_re_lu_1", []), ("conv2d_2", ["conv2d_2"]),
          ("batch_normalization_2", ["batch_normalization_2"]), ("leaky_re_lu_2", []), ("conv2d_3", ["conv2d_3"]),
          ("batch_normalization_3", ["batch_normalization_3"]), ("average_pooling2d_2", []), ("add_1", []),
          ("dropout_1", [])]
+    if (basemodel or cf.basemodel) == 'InceptionResNetV2':     # conv / bn / activation triples, pools, concats, lambdas
+        for op in irv2_program():
+            if op[0] == "conv":
+                t.append((op[1], [op[1]]))
+                if op[2]:
+                    t.append((op[2], [op[2]]))
+                if op[10]:
+                    t.append((op[1] + "_ac", []))
+            elif op[0] == "resadd":
+                t += [("block_lambda", [])] + ([("block_ac", [])] if op[5] else [])
+            else:
+                t.append((op[0], []))
+        return t
     if (basemodel or cf.basemodel) == 'MobileNet':       # keras.applications.mobilenet layer order
         t += [("conv1", ["conv1"]), ("conv1_bn", ["conv1_bn"]), ("conv1_relu", [])]
         for i in range(1, len(MOBILENET_BLOCKS) + 1):
@@ -182,9 +195,9 @@ class Model:
         # Select this rank's GPU (and join the torchrun process group) BEFORE anything is allocated: every plan,
         # callback buffer and kernel launch of this process then lives on cuda:LOCAL_RANK.
         self.rank, _, self.world = parallel.init_distributed()
-        if cf.basemodel not in ('Xception', 'MobileNet'):
-            raise NotImplementedError("this build implements the Xception and MobileNet backbones (cf.basemodel=%r)"
-                                      % cf.basemodel)
+        if cf.basemodel not in ('Xception', 'MobileNet', 'InceptionResNetV2'):
+            raise NotImplementedError("this build implements the Xception, MobileNet and InceptionResNetV2 backbones "
+                                      "(cf.basemodel=%r)" % cf.basemodel)
         self.basemodel = cf.basemodel
         self.input_shape = tuple(int(v) for v in input_shape)
         H, W = self.input_shape[0], self.input_shape[1]
@@ -550,7 +563,7 @@ def load_model(path, custom_objects=None):
     try:                                   # head variant and backbone are part of the saved model, not of the caller's config
         if saved_type in ("compound", "monolithic", "big"):
             cf.model_type = saved_type
-        if meta.get("basemodel") in ("Xception", "MobileNet"):
+        if meta.get("basemodel") in ("Xception", "MobileNet", "InceptionResNetV2"):
             cf.basemodel = meta["basemodel"]
         model = Model(shape, Y0size=int(meta.get("Y0size", 576)), freeze_fac=0.0)
     finally:

@@ -88,6 +88,14 @@ def device_decisions(eng):
             relu.append(state6(node.y))
         elif isinstance(node, E.MobileBlock):
             relu += [state6(node.bn_dw.y), state6(node.y)]
+        elif isinstance(node, E.IRv2Backbone):
+            for o in node.ops:
+                if getattr(o, "relu", False):                       # conv + BN + ReLU, or a block's closing ReLU
+                    relu.append(cpu(o.out.buf) > 0)
+                elif getattr(o, "kind", None) == "maxpool":
+                    B, OH, OW, C = o.out.buf.shape
+                    taps = cpu(o.idx).view(torch.uint8).reshape(B, OH, OW, C).long()
+                    pool.append(taps.permute(0, 3, 1, 2).unsqueeze(2))
         elif isinstance(node, E.BatchNorm) and node.act != E.ACT_NONE:
             relu.append(cpu(node.y) > 0)
         elif isinstance(node, E.StridedBlock):
@@ -116,6 +124,14 @@ def assert_gradients_match(eng, P, X, Y, mask, tol=5e-3, tie=1e-4, loss_type="sa
     far = [f for f in dec.flips if f[2] > tie]
     assert not far, "device decisions differ from the oracle's away from ties: %s" % far[:8]
     gd = eng.grad_dict()
-    bad = {k: e for k, e in ((k, rel_err(gd[k].numpy(), g64[k].numpy())) for k in g64) if e > tol}
+    # a tensor whose true gradient vanishes identically (a bias in front of a training-mode BatchNorm: Inception-
+    # ResNet's block8_10_conv/bias, 1e-17 in fp64) is measured against 1e-6 of the model's largest gradient entry
+    floor = 1e-6 * max(float(np.abs(v.numpy()).max()) for v in g64.values())
+    bad = {}
+    for k in g64:
+        ref = g64[k].numpy()
+        e = float(np.abs(gd[k].numpy().astype(np.float64) - ref).max()) / max(float(np.abs(ref).max()), floor)
+        if e > tol:
+            bad[k] = e
     assert not bad, sorted(bad.items(), key=lambda kv: -kv[1])[:8]
     return data64, yp64, P64, dec

@@ -1,0 +1,182 @@
+"""Inception-ResNet-v2 backbone (BASELINE configs[3]; cf.basemodel = 'InceptionResNetV2', spnet/models.py:357-359):
+structure known-answers, the general-convolution building blocks, whole-network parity with the oracle."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import torch_ref as T
+from tests.parity_util import assert_gradients_match, make_case, rel_err
+
+
+def _need_gpu():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+
+
+def test_structure_matches_keras_inception_resnet_v2():
+    _need_gpu()
+    from spnet_amd.engine import irv2_out_hw, irv2_program, param_specs
+    # the product's program and the oracle's restatement are written independently: same ops, names and shapes
+    got = [o[:9] + ("same" if o[9] else "valid",) + o[10:] if o[0] == "conv" else o for o in irv2_program()]
+    assert got == T.irv2_layers()
+    specs = param_specs(598, 598, backbone="InceptionResNetV2")
+    body = [s for s in specs if not s[0].startswith(("conv2d_1/", "conv2d_2/", "conv2d_3/", "batch_normalization_1/",
+                                                     "batch_normalization_2/", "batch_normalization_3/", "FinalOutput"))]
+    total = sum(int(np.prod(s[1])) for s in body)
+    trainable = sum(int(np.prod(s[1])) for s in body if s[2])
+    # keras.applications.InceptionResNetV2(include_top=False): 54,336,736 parameters, 54,276,192 trainable
+    assert (total, trainable, total - trainable) == (54336736, 54276192, 60544)
+    assert irv2_out_hw(598, 598) == (8, 8)                # 299x299 behind the stem -> the canonical 8x8x1536
+    assert sum(1 for o in irv2_program() if o[0] == "conv") == 244
+
+
+@pytest.mark.parametrize("B,H,W,C,kh,kw,stride,same", [(2, 9, 11, 32, 3, 3, 1, 1), (2, 10, 14, 128, 1, 7, 1, 1),
+                                                       (2, 10, 14, 160, 7, 1, 1, 1), (1, 21, 29, 48, 5, 5, 1, 1),
+                                                       (2, 21, 29, 320, 3, 3, 2, 0), (3, 13, 12, 64, 3, 3, 1, 0),
+                                                       (2, 6, 4, 192, 1, 3, 1, 1), (2, 6, 4, 224, 3, 1, 1, 1)])
+def test_general_convolution_through_patches_and_gemm(B, H, W, C, kh, kw, stride, same):
+    _need_gpu()
+    from spnet_amd import _lib as L
+    st = torch.cuda.current_stream().cuda_stream
+    rs = np.random.RandomState(C + kh * 7 + kw)
+    cout = 64
+    x = torch.tensor(rs.randn(B, H, W, C), dtype=torch.float64, requires_grad=True)
+    w = torch.tensor(rs.randn(kh, kw, C, cout) / np.sqrt(kh * kw * C), dtype=torch.float64, requires_grad=True)
+    y = T.conv2d_general(x, w, stride, "same" if same else "valid")
+    dy = torch.tensor(rs.randn(*y.shape), dtype=torch.float64)
+    y.backward(dy)
+    M, K = y.shape[0] * y.shape[1] * y.shape[2], kh * kw * C
+    xd, wd, dyd = x.detach().float().cuda(), w.detach().float().cuda(), dy.float().cuda().contiguous()
+    col = torch.full((M, K), float("nan"), device="cuda")
+    L.spnet_patches(xd.data_ptr(), col.data_ptr(), B, H, W, C, kh, kw, stride, same, 0, st)
+    ws = torch.empty(1 << 22, device="cuda")
+    yd = torch.empty(M, cout, device="cuda")
+    L.spnet_gemm_f32(col.data_ptr(), 0, K, wd.data_ptr(), 1, cout, yd.data_ptr(), cout, M, cout, K, 0, ws.data_ptr(),
+                     ws.numel(), None, 0, st)
+    np.testing.assert_allclose(yd.cpu().numpy().reshape(y.shape), y.detach().numpy(), rtol=1e-4, atol=1e-4)
+    dcol = torch.empty(M, K, device="cuda")
+    L.spnet_gemm_f32(dyd.data_ptr(), 0, cout, wd.data_ptr(), 0, cout, dcol.data_ptr(), K, M, K, cout, 0, ws.data_ptr(),
+                     ws.numel(), None, 0, st)
+    dx = torch.full((B, H, W, C), float("nan"), device="cuda")
+    L.spnet_patches(dcol.data_ptr(), dx.data_ptr(), B, H, W, C, kh, kw, stride, same, 1, st)
+    np.testing.assert_allclose(dx.cpu().numpy(), x.grad.numpy(), rtol=1e-4, atol=1e-4)
+    gw = torch.empty(K, cout, device="cuda")
+    L.spnet_gemm_f32(col.data_ptr(), 1, K, dyd.data_ptr(), 1, cout, gw.data_ptr(), cout, K, cout, M, 0, ws.data_ptr(),
+                     ws.numel(), None, 0, st)
+    np.testing.assert_allclose(gw.cpu().numpy().reshape(w.shape), w.grad.numpy(), rtol=1e-4, atol=1e-4 * np.sqrt(M))
+
+
+def test_irv2_pools_and_block_glue():
+    _need_gpu()
+    from spnet_amd import _lib as L
+    st = torch.cuda.current_stream().cuda_stream
+    rs = np.random.RandomState(4)
+    B, H, W, C = 2, 21, 29, 64
+    x = torch.tensor(rs.randn(B, H, W, C), dtype=torch.float64, requires_grad=True)
+    for name, fn in (("max", T.maxpool3x3s2_valid), ("avg", T.avgpool3x3s1_same)):
+        x.grad = None
+        y = fn(x)
+        dy = torch.tensor(rs.randn(*y.shape), dtype=torch.float64)
+        y.backward(dy)
+        xd, dyd = x.detach().float().cuda(), dy.float().cuda()
+        yd, dxd = torch.empty(tuple(y.shape), device="cuda"), torch.empty(B, H, W, C, device="cuda")
+        if name == "max":
+            idx = torch.empty(y.numel() // 4, dtype=torch.int32, device="cuda")
+            L.spnet_maxpool3x3s2_valid_fwd(xd.data_ptr(), yd.data_ptr(), idx.data_ptr(), B, H, W, C, st)
+            L.spnet_maxpool3x3s2_valid_bwd(dyd.data_ptr(), idx.data_ptr(), dxd.data_ptr(), B, H, W, C, st)
+        else:
+            L.spnet_avgpool3x3s1_same(xd.data_ptr(), yd.data_ptr(), B, H, W, C, 0, st)
+            L.spnet_avgpool3x3s1_same(dyd.data_ptr(), dxd.data_ptr(), B, H, W, C, 1, st)
+        np.testing.assert_allclose(yd.cpu().numpy(), y.detach().numpy(), rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(dxd.cpu().numpy(), x.grad.numpy(), rtol=1e-5, atol=1e-6)
+    # x + scale*up (+ReLU) and its gradient; channel-block copies with accumulation
+    a, u, g = (torch.tensor(rs.randn(B, H, W, C), dtype=torch.float32).cuda() for _ in range(3))
+    y = torch.empty_like(a)
+    L.spnet_resadd(a.data_ptr(), u.data_ptr(), y.data_ptr(), a.numel(), 0.17, 1, st)
+    want = torch.relu(a.double() + 0.17 * u.double())
+    np.testing.assert_allclose(y.cpu().numpy(), want.cpu().numpy(), rtol=1e-6, atol=1e-6)
+    dx, du = torch.empty_like(a), torch.empty_like(a)
+    L.spnet_resadd_bwd(y.data_ptr(), g.data_ptr(), dx.data_ptr(), du.data_ptr(), a.numel(), 0.17, 1, st)
+    gm = g * (y > 0)
+    assert torch.equal(dx, gm) and torch.allclose(du, 0.17 * gm)
+    cat = torch.zeros(B * H * W, 96, device="cuda")
+    part = torch.tensor(rs.randn(B * H * W, 32), dtype=torch.float32).cuda()
+    L.spnet_copy_cols(part.data_ptr(), 32, cat.data_ptr() + 4 * 64, 96, B * H * W, 32, 0, st)
+    L.spnet_copy_cols(part.data_ptr(), 32, cat.data_ptr() + 4 * 64, 96, B * H * W, 32, 1, st)
+    assert torch.equal(cat[:, 64:], 2 * part) and float(cat[:, :64].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("H,W,B,seed", [(288, 224, 2, 0), (235, 301, 3, 1)])
+def test_irv2_forward_and_gradients(H, W, B, seed):
+    """(Frames big enough that the last stage still has a dozen samples per channel: at 160x192 / batch 2 the 8x8-stage
+    BatchNorms normalise over TWO samples, xhat = +-1 whatever the data, and nothing meaningful is left to compare.)"""
+    _need_gpu()
+    from spnet_amd.engine import Engine
+    P, X, Y, mask, dseed = make_case(H, W, B, seed, basemodel="InceptionResNetV2")
+    eng = Engine(H, W, B, device="cuda:0", seed=1, backbone="InceptionResNetV2")
+    assert list(eng.state_dict().keys()) == list(P.keys())
+    eng.load_state_dict(P)
+    want = T.forward(P, X, training=False)
+    got = eng.forward(X.cuda(), training=False).cpu()
+    assert float(((got - want) ** 2).mean()) <= 1e-8 * max(float((want ** 2).mean()), 1.0)
+    eng.set_drop_seed(dseed)
+    out = eng.forward(X.cuda(), training=True)
+    loss = eng.loss(Y.cuda())
+    eng.backward()
+    torch.cuda.synchronize()
+    data64, yp64, P64, _ = assert_gradients_match(eng, P, X, Y, mask, tol=5e-3)
+    assert rel_err(out.cpu().numpy(), yp64.numpy()) <= 5e-4
+    np.testing.assert_allclose(float(loss[5]), data64, rtol=1e-4)
+    sd = eng.state_dict()
+    for k in P:
+        if k.endswith("moving_mean") or k.endswith("moving_variance"):
+            np.testing.assert_allclose(sd[k].numpy(), P64[k].numpy(), rtol=1e-4, atol=1e-5, err_msg=k)
+
+
+def test_irv2_trains_through_the_model_api():
+    """BASELINE configs[3] plumbing: cf.basemodel = 'InceptionResNetV2', batch 16 -- a few optimizer steps through
+    Model.fit reduce the loss; predict is deterministic."""
+    _need_gpu()
+    from spnet_amd import config as cf
+    from spnet_amd import models as M
+    rs = np.random.RandomState(3)
+    X = (rs.rand(16, 160, 192, 1).astype(np.float32) * 2 - 1)
+    Y = rs.rand(16, 576).astype(np.float32)
+    Y[:, 6::8] = (Y[:, 6::8] > 0.5)
+    old = cf.basemodel
+    try:
+        cf.basemodel = 'InceptionResNetV2'
+        model = M.create_model_functional(X, Y0size=576, freeze_fac=0.0)
+    finally:
+        cf.basemodel = old
+    assert model.basemodel == 'InceptionResNetV2'
+    model.optimizer.lr = 3e-4
+    h = model.fit(X, Y, batch_size=16, epochs=6, shuffle=False, verbose=0)
+    assert np.all(np.isfinite(h["loss"])) and h["loss"][-1] < h["loss"][0]
+    p1, p2 = model.predict(X, batch_size=16), model.predict(X, batch_size=16)
+    assert p1.shape == (16, 576) and np.array_equal(p1, p2)
+
+
+def test_config3_plumbing_run_with_inception_resnet_v2(tmp_path):
+    """BASELINE configs[3]: Inception-ResNetV2 backbone, batch 16, through train_spnet.py (331x331 'monolithic' frames)."""
+    import os
+    import subprocess
+    import sys
+    _need_gpu()
+    from spnet_amd import fake_espi as F
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    data = tmp_path / "data"
+    F.write_dataset(str(data / "Train"), 32, seed=1)
+    F.write_dataset(str(data / "Val"), 16, seed=2)
+    work = tmp_path / "work"
+    work.mkdir()
+    r = subprocess.run([sys.executable, os.path.join(root, "train_spnet.py"), "-d", str(data), "-b", "16", "-e", "2",
+                        "--name", "ir", "--backbone", "InceptionResNetV2"], cwd=str(work), env=dict(os.environ, PYTHONPATH=root),
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + "\n" + r.stderr[-3000:]
+    assert "cf.basemodel = InceptionResNetV2" in r.stdout and "SPNet execution completed." in r.stdout
+    logs = [d for d in os.listdir(work / "logs") if d.startswith("ir_")]
+    rows = [l for l in open(work / "logs" / logs[0] / "losses.dat") if not l.startswith("#")]
+    assert len(rows) == 2 and all(np.isfinite(float(x.split()[1])) for x in rows)
