@@ -67,6 +67,26 @@ def test_full_config_is_deterministic_and_learns(full):
     np.testing.assert_allclose(parts, data, rtol=1e-5)              # five terms add up to custom_loss
 
 
+def test_host_running_ahead_equals_synchronous_stepping(full):
+    """Per-step scalars (Adam's bias-corrected step size, the dropout seed) reach the device through a ring of pinned
+    slots copied in stream order: six steps enqueued back to back (the host runs several steps ahead of the GPU, every
+    step with another learning rate) must leave exactly the weights of six steps with a device sync after each."""
+    eng, X, Y = full
+    lrs = [1e-4, 3e-4, 5e-5, 2e-4, 7e-5, 1e-4]
+    finals = []
+    for sync in (False, True):
+        eng.init_weights(0)
+        eng.drop_seed = 11
+        for lr in lrs:
+            out = eng.train_step(X, Y, lr)
+            if sync:
+                torch.cuda.synchronize()
+        torch.cuda.synchronize()
+        finals.append((eng.theta.clone(), out.clone(), eng.t))
+    assert finals[0][2] == finals[1][2] == 6
+    assert torch.equal(finals[0][0], finals[1][0]) and torch.equal(finals[0][1], finals[1][1])
+
+
 def test_full_size_linearity_of_gemm_and_depthwise(full):
     eng, X, Y = full
     from spnet_amd import _lib as L

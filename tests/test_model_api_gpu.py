@@ -60,6 +60,25 @@ def test_frozen_layers_stay_put_and_unfreeze_trains_them(data):
     assert len(moved) >= 0.9 * sum(trainable(k) for k in fro_f)
 
 
+def test_optimizer_state_is_shared_by_all_plans(data, tmp_path):
+    """Adam's iteration count and the dropout seed sequence belong to the weights, not to a (batch size) launch plan: a
+    second fit() with another batch size continues both, and the whole-model file records the real iteration count."""
+    from safetensors import safe_open
+    from spnet_amd import models as M
+    X, Y = data
+    model = M.build_model(X, Y0size=576, freeze_fac=0.0)
+    model.fit(X, Y, batch_size=8, epochs=1, shuffle=False, verbose=0)           # 2 iterations
+    seed_after_first = model._root.drop_seed
+    assert model._root.t == 2
+    model.fit(X, Y, batch_size=4, epochs=1, shuffle=False, verbose=0)           # 4 more, on another plan
+    assert model._root.t == 6 and model._engine(4, True).t == 6 and model._engine(8, True).t == 6
+    assert model._root.drop_seed != seed_after_first
+    path = str(tmp_path / "m.h5")
+    model.save(path)
+    with safe_open(path, framework="pt") as f:
+        assert f.metadata()["optimizer_iterations"] == "6"
+
+
 def test_weights_round_trip_and_predict_is_deterministic(data, tmp_path):
     from spnet_amd import models as M
     X, Y = data
