@@ -319,12 +319,13 @@ class Engine:
         self._wgrad_table = None
         self._first_middle = None
         self.defer_mid_wgrad = os.environ.get("SPNET_DEFER_WGRAD", "1") != "0"
-        self.overlap_wgrad = True       # pointwise weight gradients on a side stream (joined before Adam)
+        # pointwise weight gradients on a side stream (joined before Adam); SPNET_OVERLAP_WGRAD=0: one stream
+        self.overlap_wgrad = os.environ.get("SPNET_OVERLAP_WGRAD", "1") != "0"
         # Optional: capture the single-GPU train step as a hipGraph after one eager step.  Off by default:
         # measured on MI355X / ROCm 7.2 the replay of this ~400-node two-stream graph takes 13.8 ms against
         # 13.4 ms for the eager launches (single stream: 13.5 either way) -- the host enqueues a step in
         # 4.3 ms and runs ahead of the GPU, so launch overhead is not what limits the step.
-        self.use_graph = False
+        self.use_graph = os.environ.get("SPNET_TRAIN_GRAPH", "0") == "1"
         torch.cuda.set_device(self.dev)
         # Inference coefficients (scale|shift from the moving statistics, one tiny kernel per BatchNorm) are
         # recomputed only when the weights or statistics changed since this plan last did: [version] is shared
