@@ -52,17 +52,20 @@ def conv2d(x, w_hwio, stride=1, padding="valid"):
 
 def dwconv3x3(x, w_33c, stride=1):
     """Depthwise 3x3, SAME, no bias (tf.nn.depthwise_conv2d inside SeparableConv2D / MobileNet's DepthwiseConv2D);
-    stride 2 pads the TF way (extra row / column at the bottom / right)."""
-    C = x.shape[3]
-    w = w_33c.permute(2, 0, 1).reshape(C, 1, 3, 3)
-    if stride == 1:
-        return _nhwc(F.conv2d(_nchw(x), w, padding=1, groups=C))
+    stride 2 pads the TF way (extra row / column at the bottom / right).  Written as nine shifted multiply-adds on the
+    NHWC tensor (y[b,i,j,c] = sum_{kh,kw} xpad[b, i*s+kh, j*s+kw, c] * w[kh,kw,c]): identical to a grouped conv2d, but
+    it stays fast in float64, where grouped convolutions have no optimised CPU path."""
     H, W = x.shape[1], x.shape[2]
     oh, ow = -(-H // stride), -(-W // stride)
     ph = max((oh - 1) * stride + 3 - H, 0)
     pw = max((ow - 1) * stride + 3 - W, 0)
-    xc = F.pad(_nchw(x), (pw // 2, pw - pw // 2, ph // 2, ph - ph // 2))
-    return _nhwc(F.conv2d(xc, w, stride=stride, groups=C))
+    xp = F.pad(x, (0, 0, pw // 2, pw - pw // 2, ph // 2, ph - ph // 2))
+    y = None
+    for kh in range(3):
+        for kw in range(3):
+            t = xp[:, kh:kh + (oh - 1) * stride + 1:stride, kw:kw + (ow - 1) * stride + 1:stride, :] * w_33c[kh, kw]
+            y = t if y is None else y + t
+    return y
 
 
 def pwconv(x, w_io):

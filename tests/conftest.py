@@ -11,6 +11,10 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # The CPU oracle runs in this process: keep torch's thread pool at the share of cores a test box really has (a
+    # 1-GPU box exposes 100+ logical CPUs but grants ~16; 128 oversubscribed threads make the fp64 oracle 20x slower).
+    import torch
+    torch.set_num_threads(max(1, min(16, os.cpu_count() or 1)))
 
 
 @pytest.fixture(scope="session")
