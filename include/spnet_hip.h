@@ -93,6 +93,15 @@ int spnet_dwconv3x3_strided(int op, const float* a, const float* b, float* out, 
  * pass over x and dy).  workspace: spnet_dwconv3x3_tiled_bwd_ws(B,H,W,C) floats. */
 int spnet_dwconv3x3_tiled_fwd(const float* x, const float* w, float* y, int B, int H, int W, int C,
                               int relu_in, const float* in_scale, const float* in_shift, void* stream);
+/* The same with the PRODUCER BatchNorm's training-forward finalize folded into the prologue (one dependent launch less
+ * per SeparableConv2D -> BatchNormalization -> SeparableConv2D chain inside keras Xception; spnet/models.py:357-359):
+ * partial [rows][2][C] = column sums of x left by spnet_gemm_f32_colstats (rows <= 128), M = pixels they were taken
+ * over; the kernel applies relu?(x*scale + shift) with the coefficients it derives (bit-identical to
+ * spnet_bn_finalize_fwd), writes save_mean / save_invstd / scale_shift[2C] and updates the moving statistics. */
+int spnet_dwconv3x3_tiled_fwd_bnfin(const float* x, const float* w, float* y, int B, int H, int W, int C, int relu_in,
+                                    const float* partial, int rows, long M, const float* gamma, const float* beta,
+                                    float* moving_mean, float* moving_var, float* save_mean, float* save_invstd,
+                                    float* scale_shift, float eps, float momentum, void* stream);
 long spnet_dwconv3x3_tiled_bwd_ws(int B, int H, int W, int C);
 long spnet_dwconv3x3_tiled_rows(int B, int H, int W, int C);
 /* in_scale/in_shift (or NULL): the producer BatchNorm's affine applied on load (x_fwd is then the PRE-BN
@@ -128,6 +137,12 @@ int spnet_bn_infer_coeffs(int C, const float* gamma, const float* beta, const fl
                           const float* moving_var, float* scale_shift, float eps, void* stream);
 int spnet_bn_apply(const float* x, long M, int C, const float* scale_shift, int act, const float* residual,
                    int res_bcast, float* y, void* stream);
+/* spnet_bn_finalize_fwd + spnet_bn_apply (no broadcast residual) as ONE launch while P <= 128 partial rows -- the closing
+ * BatchNormalization + Add of a keras Xception middle block in training (spnet/models.py:357-359); results identical. */
+int spnet_bn_finalize_apply(const float* partial, int P, const float* x, long M, int C, const float* gamma,
+                            const float* beta, float* moving_mean, float* moving_var, float* save_mean,
+                            float* save_invstd, float* scale_shift, int act, const float* residual, float* y, float eps,
+                            float momentum, void* stream);
 int spnet_bn_bwd_from_partials(const float* x, const float* dy, long M, int C, const float* gamma,
                                const float* beta, const float* save_mean, const float* save_invstd, int P,
                                const float* partial, float* dx, float* dgamma, float* dbeta, float* coeffs,

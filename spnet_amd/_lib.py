@@ -39,12 +39,15 @@ _SIGS = {
     "spnet_reduce_rows": (c_int, [P, c_int, c_int, P, P]),
     "spnet_reduce_rows_batched": (c_int, [P, c_int, c_int, P]),
     "spnet_dwconv3x3_tiled_fwd": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, P, P, P]),
+    "spnet_dwconv3x3_tiled_fwd_bnfin": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, P, c_int, c_long, P, P, P, P, P, P, P,
+                                                c_float, c_float, P]),
     "spnet_dwconv3x3_tiled_bwd_ws": (c_long, [c_int, c_int, c_int, c_int]),
     "spnet_dwconv3x3_tiled_rows": (c_long, [c_int, c_int, c_int, c_int]),
     "spnet_dwconv3x3_tiled_bwd": (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, P, P, P, P, P, P, P, P, P]),
     "spnet_bn_finalize_fwd": (c_int, [P, c_int, c_long, c_int, P, P, P, P, P, P, P, c_float, c_float, P]),
     "spnet_bn_infer_coeffs": (c_int, [c_int, P, P, P, P, P, c_float, P]),
     "spnet_bn_apply": (c_int, [P, c_long, c_int, P, c_int, P, c_int, P, P]),
+    "spnet_bn_finalize_apply": (c_int, [P, c_int, P, c_long, c_int, P, P, P, P, P, P, P, c_int, P, P, c_float, c_float, P]),
     "spnet_bn_bwd_from_partials": (c_int, [P, P, c_long, c_int, P, P, P, P, c_int, P, P, P, P, P, P]),
     "spnet_gemm_f32_colstats": (c_int, [P, c_int, c_int, P, c_int, c_int, P, c_int, c_int, c_int, c_int, c_int, P, P, P]),
     "spnet_gemm_f32_bnblend": (c_int, [P, P, P, c_int, c_int, P, c_int, P, c_int, c_int, c_int, c_int, c_int, P, P]),

@@ -223,18 +223,13 @@ __global__ __launch_bounds__(256) void bn_fwd_finalize_kernel(
   double s, q;
   const int c = combine_partials(partial, P, C, &s, &q);
   if (c < 0) return;
-  const double mean = s / (double)M;
-  double var = q / (double)M - mean * mean;
-  if (var < 0.0) var = 0.0;
-  const float invstd = (float)(1.0 / sqrt(var + (double)eps));
-  const float sc = gamma[c] * invstd;
-  save_mean[c] = (float)mean;
-  save_invstd[c] = invstd;
-  scale[c] = sc;
-  shift[c] = beta[c] - (float)mean * sc;
-  const double unbiased = (M > 1) ? var * ((double)M / (double)(M - 1)) : var;
-  moving_mean[c] = momentum * moving_mean[c] + (1.f - momentum) * (float)mean;
-  moving_var[c] = momentum * moving_var[c] + (1.f - momentum) * (float)unbiased;
+  const BnChannelStats st = bn_channel_stats(s, q, M, gamma[c], beta[c], eps);
+  save_mean[c] = st.mean;
+  save_invstd[c] = st.invstd;
+  scale[c] = st.scale;
+  shift[c] = st.shift;
+  moving_mean[c] = bn_moving_update(moving_mean[c], momentum, st.mean);
+  moving_var[c] = bn_moving_update(moving_var[c], momentum, st.unbiased_var);
 }
 
 // Inference: affine from the moving statistics.
@@ -369,6 +364,153 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_scalar_kernel(
     const float g = dy[i] * act_grad(fmaf(xh, gamma[c], beta[c]), act);
     dx[i] = fmaf(k1[c], g, fmaf(k2[c], xh, k3[c]));
   }
+}
+
+// ---------------------------------------------------------------- finalize folded into the apply pass
+// Where a BatchNorm's statistics arrive as FEW partial rows (the 728-channel middle flow, the exit flow: P <= 128),
+// the finalize kernel is a dependent 5-7 us launch in front of an elementwise pass that takes 10-13 us.  These kernels
+// do both: a workgroup owns 32 channels x a slab of rows, first combines the partial rows of ITS channels -- the
+// arithmetic of combine_partials() in the same order, so every workgroup of a channel chunk holds the coefficients the
+// finalize kernel would have written, bit for bit -- then streams its slab.  The workgroups of slab 0 publish the
+// per-channel results (dgamma / dbeta, or mean / invstd / scale / shift + the moving-statistics update).
+// blockDim = 256 = 8 channel quads x 32 rows; grid = (ceil(C/32), slabs).
+#define BN_FUSE_CH 32
+__device__ __forceinline__ bool chunk_sums(const float* __restrict__ partial, int P, int C, int c0, double* dred,
+                                           double* s_out, double* q_out) {
+  const int tid = threadIdx.x;
+  const int ch = tid % BN_FUSE_CH, grp = tid / BN_FUSE_CH;      // 8 thread groups, two of the 16 row groups each
+  const int c = c0 + ch;
+  for (int g = grp; g < 16; g += 256 / BN_FUSE_CH) {
+    double s = 0.0, q = 0.0;
+    if (c < C) {
+#pragma unroll 4
+      for (int p = g; p < P; p += 16) {
+        s += (double)partial[((long)p * 2 + 0) * C + c];
+        q += (double)partial[((long)p * 2 + 1) * C + c];
+      }
+    }
+    dred[(0 * 16 + g) * BN_FUSE_CH + ch] = s;
+    dred[(1 * 16 + g) * BN_FUSE_CH + ch] = q;
+  }
+  __syncthreads();
+  if (tid >= BN_FUSE_CH || c >= C) return false;
+  double ss = 0.0, qq = 0.0;
+#pragma unroll
+  for (int k = 0; k < 16; ++k) { ss += dred[(0 * 16 + k) * BN_FUSE_CH + ch]; qq += dred[(1 * 16 + k) * BN_FUSE_CH + ch]; }
+  *s_out = ss;
+  *q_out = qq;
+  return true;
+}
+
+// Training forward: partial -> (mean, invstd, scale, shift, moving statistics) and y = act(x*scale + shift) (+ residual).
+__global__ __launch_bounds__(256) void bn_fwd_fused_vec_kernel(
+    const float* __restrict__ x, long M, int C, const float* __restrict__ partial, int P,
+    const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ moving_mean,
+    float* __restrict__ moving_var, float* __restrict__ save_mean, float* __restrict__ save_invstd,
+    float* __restrict__ scale, float* __restrict__ shift, float eps, float momentum, int act,
+    const float* __restrict__ residual, float* __restrict__ y, int rows_per_slab) {
+  __shared__ double dred[2 * 16 * BN_FUSE_CH];
+  __shared__ __attribute__((aligned(16))) float cf[2][BN_FUSE_CH];
+  const int c0 = blockIdx.x * BN_FUSE_CH;
+  double s, q;
+  if (chunk_sums(partial, P, C, c0, dred, &s, &q)) {
+    const int c = c0 + threadIdx.x;
+    const BnChannelStats st = bn_channel_stats(s, q, M, gamma[c], beta[c], eps);
+    cf[0][threadIdx.x] = st.scale;
+    cf[1][threadIdx.x] = st.shift;
+    if (blockIdx.y == 0) {
+      save_mean[c] = st.mean;
+      save_invstd[c] = st.invstd;
+      scale[c] = st.scale;
+      shift[c] = st.shift;
+      moving_mean[c] = bn_moving_update(moving_mean[c], momentum, st.mean);
+      moving_var[c] = bn_moving_update(moving_var[c], momentum, st.unbiased_var);
+    }
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 7, r0 = threadIdx.x >> 3;
+  const int c = c0 + lane * 4;
+  if (c >= C) return;
+  const float4 sc = *reinterpret_cast<const float4*>(&cf[0][lane * 4]);
+  const float4 sh = *reinterpret_cast<const float4*>(&cf[1][lane * 4]);
+  const long rbeg = (long)blockIdx.y * rows_per_slab;
+  const long rend = min(M, rbeg + rows_per_slab);
+  for (long r = rbeg + r0; r < rend; r += 32) {
+    const long i = r * C + c;
+    const float4 v = *reinterpret_cast<const float4*>(x + i);
+    float4 o;
+    o.x = act_fwd(fmaf(v.x, sc.x, sh.x), act);
+    o.y = act_fwd(fmaf(v.y, sc.y, sh.y), act);
+    o.z = act_fwd(fmaf(v.z, sc.z, sh.z), act);
+    o.w = act_fwd(fmaf(v.w, sc.w, sh.w), act);
+    if (residual) {
+      const float4 rr = *reinterpret_cast<const float4*>(residual + i);
+      o.x += rr.x; o.y += rr.y; o.z += rr.z; o.w += rr.w;
+    }
+    *reinterpret_cast<float4*>(y + i) = o;
+  }
+}
+
+// Backward: partial (sum g, sum g*xhat) -> dgamma, dbeta and dx = k1*g + k2*xhat + k3 (no activation behind the BN:
+// g already carries any mask).
+__global__ __launch_bounds__(256) void bn_bwd_fused_vec_kernel(
+    const float* __restrict__ x, const float* __restrict__ dy, long M, int C, const float* __restrict__ partial, int P,
+    const float* __restrict__ gamma, const float* __restrict__ mean, const float* __restrict__ invstd,
+    float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ dx, int rows_per_slab) {
+  __shared__ double dred[2 * 16 * BN_FUSE_CH];
+  __shared__ __attribute__((aligned(16))) float cf[5][BN_FUSE_CH];   // k1, k2, k3, mean, invstd
+  const int c0 = blockIdx.x * BN_FUSE_CH;
+  double sg, sgx;
+  if (chunk_sums(partial, P, C, c0, dred, &sg, &sgx)) {
+    const int c = c0 + threadIdx.x;
+    const double is = (double)invstd[c];
+    const double a = (double)gamma[c] * is;
+    const double b = -a * sgx / (double)M, d = -a * sg / (double)M;
+    cf[0][threadIdx.x] = (float)a;
+    cf[1][threadIdx.x] = (float)b;
+    cf[2][threadIdx.x] = (float)d;
+    cf[3][threadIdx.x] = mean[c];
+    cf[4][threadIdx.x] = invstd[c];
+    if (blockIdx.y == 0) {
+      dbeta[c] = (float)sg;
+      dgamma[c] = (float)sgx;
+    }
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 7, r0 = threadIdx.x >> 3;
+  const int c = c0 + lane * 4;
+  if (c >= C) return;
+  const float4 k1 = *reinterpret_cast<const float4*>(&cf[0][lane * 4]);
+  const float4 k2 = *reinterpret_cast<const float4*>(&cf[1][lane * 4]);
+  const float4 k3 = *reinterpret_cast<const float4*>(&cf[2][lane * 4]);
+  const float4 mu = *reinterpret_cast<const float4*>(&cf[3][lane * 4]);
+  const float4 is = *reinterpret_cast<const float4*>(&cf[4][lane * 4]);
+  const long rbeg = (long)blockIdx.y * rows_per_slab;
+  const long rend = min(M, rbeg + rows_per_slab);
+  for (long r = rbeg + r0; r < rend; r += 32) {
+    const long i = r * C + c;
+    const float4 v = *reinterpret_cast<const float4*>(x + i);
+    const float4 g = *reinterpret_cast<const float4*>(dy + i);
+    float4 xh, o;
+    xh.x = (v.x - mu.x) * is.x; xh.y = (v.y - mu.y) * is.y;
+    xh.z = (v.z - mu.z) * is.z; xh.w = (v.w - mu.w) * is.w;
+    o.x = fmaf(k1.x, g.x, fmaf(k2.x, xh.x, k3.x));
+    o.y = fmaf(k1.y, g.y, fmaf(k2.y, xh.y, k3.y));
+    o.z = fmaf(k1.z, g.z, fmaf(k2.z, xh.z, k3.z));
+    o.w = fmaf(k1.w, g.w, fmaf(k2.w, xh.w, k3.w));
+    *reinterpret_cast<float4*>(dx + i) = o;
+  }
+}
+
+#define BN_FUSE_MAX_P 128
+// slabs of at least 256 rows, about two workgroups per CU
+static int bn_fuse_rows_per_slab(long M, int C) {
+  const int gx = (C + BN_FUSE_CH - 1) / BN_FUSE_CH;
+  long gy = 512 / gx;
+  if (gy < 1) gy = 1;
+  long rows = (M + gy - 1) / gy;
+  if (rows < 256) rows = 256;
+  return (int)((rows + 31) / 32 * 32);
 }
 
 // ---------------------------------------------------------------- host side
@@ -527,6 +669,29 @@ extern "C" int spnet_bn_apply(const float* x, long M, int C, const float* scale_
   SPNET_RETURN_LAUNCH_STATUS();
 }
 
+// spnet_bn_finalize_fwd + spnet_bn_apply in ONE launch where the statistics arrive as at most 128 partial rows (the
+// closing BatchNorm of an Xception middle block, whose output x + BN(.) is materialised); otherwise the two launches.
+extern "C" int spnet_bn_finalize_apply(const float* partial, int P, const float* x, long M, int C, const float* gamma,
+                                       const float* beta, float* moving_mean, float* moving_var, float* save_mean,
+                                       float* save_invstd, float* scale_shift, int act, const float* residual, float* y,
+                                       float eps, float momentum, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  if ((C & 3) || P < 1) return (int)hipErrorInvalidValue;
+  if (P <= BN_FUSE_MAX_P) {
+    const int rps = bn_fuse_rows_per_slab(M, C);
+    dim3 grid((C + BN_FUSE_CH - 1) / BN_FUSE_CH, (unsigned)((M + rps - 1) / rps));
+    hipLaunchKernelGGL(bn_fwd_fused_vec_kernel, grid, dim3(256), 0, st, x, M, C, partial, P, gamma, beta, moving_mean,
+                       moving_var, save_mean, save_invstd, scale_shift, scale_shift + C, eps, momentum, act, residual, y,
+                       rps);
+    SPNET_RETURN_LAUNCH_STATUS();
+  }
+  hipLaunchKernelGGL(bn_fwd_finalize_kernel, dim3((C + BN_FIN_CH - 1) / BN_FIN_CH), dim3(256), 0, st, partial, P, C, M,
+                     gamma, beta, moving_mean, moving_var, save_mean, save_invstd, scale_shift, scale_shift + C, eps,
+                     momentum);
+  launch_apply(x, M, C, scale_shift, scale_shift + C, act, residual, 0, y, st);
+  SPNET_RETURN_LAUNCH_STATUS();
+}
+
 // Backward given the two per-channel sums as partial[P][2][C] (sum g, sum g*xhat; g already includes
 // any activation mask): dgamma, dbeta, dx = k1*g + k2*xhat + k3.
 extern "C" int spnet_bn_bwd_from_partials(const float* x, const float* dy, long M, int C, const float* gamma,
@@ -535,6 +700,13 @@ extern "C" int spnet_bn_bwd_from_partials(const float* x, const float* dy, long 
                                           float* dgamma, float* dbeta, float* coeffs, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   if (C & 3) return (int)hipErrorInvalidValue;
+  if (P <= BN_FUSE_MAX_P) {                                  // few partial rows: one launch (bit-identical results)
+    const int rps = bn_fuse_rows_per_slab(M, C);
+    dim3 grid((C + BN_FUSE_CH - 1) / BN_FUSE_CH, (unsigned)((M + rps - 1) / rps));
+    hipLaunchKernelGGL(bn_bwd_fused_vec_kernel, grid, dim3(256), 0, st, x, dy, M, C, partial, P, gamma, save_mean,
+                       save_invstd, dgamma, dbeta, dx, rps);
+    SPNET_RETURN_LAUNCH_STATUS();
+  }
   hipLaunchKernelGGL(bn_bwd_finalize_kernel<0>, dim3((C + BN_FIN_CH - 1) / BN_FIN_CH), dim3(256), 0, st, partial, P,
                      C, M, gamma, save_invstd, save_mean, dgamma, dbeta, coeffs, coeffs + C, coeffs + 2 * C);
   const long n4 = M * (C / 4);

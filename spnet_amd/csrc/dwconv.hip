@@ -58,13 +58,35 @@ __device__ __forceinline__ void dw_stage_tile(float4* __restrict__ tile, const f
   }
 }
 
+// The producer BatchNorm's forward finalize, folded into this kernel's prologue (fin.partial != NULL): every workgroup
+// turns the [rows][2][C] column sums the producing GEMM's epilogue left behind into scale / shift for ITS OWN CC4*4
+// channels -- the arithmetic of bn_fwd_finalize_kernel (bn.hip) in the same order: 16 interleaved groups of partial
+// rows summed in double, the group sums added in group order, so the coefficients are bit-identical to the stand-alone
+// kernel's and identical in every workgroup, and no workgroup ever waits for another -- and the workgroups of tile 0
+// also publish mean / invstd / scale / shift (the backward pass reads them) and update the moving statistics.
+// One dependent launch (~7 us + its boundary) less per BatchNorm for ~1 us of prologue; rows <= 128.
+struct DwBnFinalize {
+  const float* partial;     // [rows][2][C] (sum, sum of squares) or NULL
+  const float* gamma;
+  const float* beta;
+  float* moving_mean;
+  float* moving_var;
+  float* save_mean;
+  float* save_invstd;
+  float* scale;             // out: [C]
+  float* shift;             // out: [C]
+  long M;                   // pixels the statistics were taken over
+  int rows;
+  float eps, momentum;
+};
+
 template <int CC4, int TW, int TH>
 __global__ __launch_bounds__(256) void dw3x3_tile_fwd_kernel(const float* __restrict__ in,
                                                              const float* __restrict__ wt,
                                                              float* __restrict__ out, int H, int W, int C,
                                                              int relu_in, int tiles_h, int tiles_w,
                                                              int cchunks, const float* __restrict__ in_scale,
-                                                             const float* __restrict__ in_shift) {
+                                                             const float* __restrict__ in_shift, DwBnFinalize fin) {
   constexpr int PW = TW + 2;
   constexpr int CC2 = 2 * CC4;
   static_assert(CC2 * TW == 256, "thread layout");
@@ -82,18 +104,60 @@ __global__ __launch_bounds__(256) void dw3x3_tile_fwd_kernel(const float* __rest
   const int h0 = th * TH, w0 = tw * TW, c40 = cc * CC4;
   const long ibase = (long)b * H * W * C;
   const int tid = threadIdx.x;
-  dw_stage_tile<CC4, TW, TH>(tile, in, ibase, h0, w0, c40, H, W, C, c4n, tid);
-  __syncthreads();
   const int l2 = tid % CC2, tcol = tid / CC2;
   const int c2 = c40 * 2 + l2;                       // channel-pair index
+  float2 sc = make_float2(1.f, 1.f), sh = make_float2(0.f, 0.f);
+  const bool affine = in_scale != nullptr || fin.partial != nullptr;
+  if (fin.partial) {
+    // (the tile buffer doubles as reduction scratch: 2*16*NCH doubles + 2*NCH floats fit every tile shape)
+    constexpr int NCH = CC4 * 4, GR = 256 / NCH;     // channels of this workgroup, thread groups per channel
+    static_assert(2 * 16 * NCH * 8 + 2 * NCH * 4 <= (TH + 2) * PW * CC4 * 16, "reduction scratch inside the tile");
+    double* dred = reinterpret_cast<double*>(tile);  // [2][16][NCH]
+    float* ssh = reinterpret_cast<float*>(dred + 2 * 16 * NCH);   // [2][NCH]
+    const int ch = tid % NCH, grp = tid / NCH;
+    const int cg = c40 * 4 + ch;
+    for (int g = grp; g < 16; g += GR) {
+      double s0 = 0.0, q0 = 0.0;
+      if (cg < C)
+        for (int p = g; p < fin.rows; p += 16) {
+          s0 += (double)fin.partial[((long)p * 2 + 0) * C + cg];
+          q0 += (double)fin.partial[((long)p * 2 + 1) * C + cg];
+        }
+      dred[(0 * 16 + g) * NCH + ch] = s0;
+      dred[(1 * 16 + g) * NCH + ch] = q0;
+    }
+    __syncthreads();
+    if (tid < NCH && cg < C) {
+      double ss = 0.0, qq = 0.0;
+#pragma unroll
+      for (int g = 0; g < 16; ++g) { ss += dred[(0 * 16 + g) * NCH + ch]; qq += dred[(1 * 16 + g) * NCH + ch]; }
+      const BnChannelStats st = bn_channel_stats(ss, qq, fin.M, fin.gamma[cg], fin.beta[cg], fin.eps);
+      ssh[ch] = st.scale;
+      ssh[NCH + ch] = st.shift;
+      if (b == 0 && th == 0 && tw == 0) {            // one publisher per channel chunk
+        fin.save_mean[cg] = st.mean;
+        fin.save_invstd[cg] = st.invstd;
+        fin.scale[cg] = st.scale;
+        fin.shift[cg] = st.shift;
+        fin.moving_mean[cg] = bn_moving_update(fin.moving_mean[cg], fin.momentum, st.mean);
+        fin.moving_var[cg] = bn_moving_update(fin.moving_var[cg], fin.momentum, st.unbiased_var);
+      }
+    }
+    __syncthreads();
+    if (c2 * 2 < C) {
+      sc = make_float2(ssh[l2 * 2], ssh[l2 * 2 + 1]);
+      sh = make_float2(ssh[NCH + l2 * 2], ssh[NCH + l2 * 2 + 1]);
+    }
+    __syncthreads();                                 // scratch is dead: the tile may be staged over it
+  }
+  dw_stage_tile<CC4, TW, TH>(tile, in, ibase, h0, w0, c40, H, W, C, c4n, tid);
+  __syncthreads();
   if (c2 * 2 >= C) return;
   const float2* t2 = reinterpret_cast<const float2*>(tile);
   float2 k[9];
 #pragma unroll
   for (int tp = 0; tp < 9; ++tp) k[tp] = *reinterpret_cast<const float2*>(wt + (long)tp * C + c2 * 2);
-  float2 sc = make_float2(1.f, 1.f), sh = make_float2(0.f, 0.f);
-  const bool affine = in_scale != nullptr;
-  if (affine) {
+  if (in_scale != nullptr && fin.partial == nullptr) {
     sc = *reinterpret_cast<const float2*>(in_scale + c2 * 2);
     sh = *reinterpret_cast<const float2*>(in_shift + c2 * 2);
   }
@@ -556,20 +620,44 @@ static DwGeom dw_geom(int B, int H, int W, int C, bool fwd) {
   return g;
 }
 
-extern "C" int spnet_dwconv3x3_tiled_fwd(const float* x, const float* w, float* y, int B, int H, int W,
-                                         int C, int relu_in, const float* in_scale,
-                                         const float* in_shift, void* stream) {
+static int dw_tiled_fwd(const float* x, const float* w, float* y, int B, int H, int W, int C, int relu_in,
+                        const float* in_scale, const float* in_shift, const DwBnFinalize& fin, void* stream) {
   if (C & 3) return (int)hipErrorInvalidValue;
   const DwGeom g = dw_geom(B, H, W, C, true);
 #define DW_FWD(CC4, TW, TH)                                                                                     \
   hipLaunchKernelGGL((dw3x3_tile_fwd_kernel<CC4, TW, TH>), dim3((unsigned)g.nblk), dim3(256), g.lds_fwd,        \
                      (hipStream_t)stream, x, w, y, H, W, C, relu_in, g.tiles_h, g.tiles_w, g.cchunks, in_scale, \
-                     in_shift)
+                     in_shift, fin)
   if (g.cfg == 1) DW_FWD(16, 8, 6);
   else if (g.cfg == 2) DW_FWD(8, 16, 24);
   else DW_FWD(8, 16, 12);
 #undef DW_FWD
   SPNET_RETURN_LAUNCH_STATUS();
+}
+
+extern "C" int spnet_dwconv3x3_tiled_fwd(const float* x, const float* w, float* y, int B, int H, int W,
+                                         int C, int relu_in, const float* in_scale,
+                                         const float* in_shift, void* stream) {
+  DwBnFinalize fin = {};
+  return dw_tiled_fwd(x, w, y, B, H, W, C, relu_in, in_scale, in_shift, fin, stream);
+}
+
+// The same with the producer BatchNorm's forward finalize folded into the prologue (training): partial[rows][2][C]
+// are the column sums of the producer's pre-normalisation output (spnet_gemm_f32_colstats), M its row count; the kernel
+// applies relu?(x*scale + shift) with the scale / shift it derives, writes save_mean / save_invstd / scale_shift[2C] and
+// updates the moving statistics exactly like spnet_bn_finalize_fwd.  rows <= 128.
+extern "C" int spnet_dwconv3x3_tiled_fwd_bnfin(const float* x, const float* w, float* y, int B, int H, int W, int C,
+                                               int relu_in, const float* partial, int rows, long M,
+                                               const float* gamma, const float* beta, float* moving_mean,
+                                               float* moving_var, float* save_mean, float* save_invstd,
+                                               float* scale_shift, float eps, float momentum, void* stream) {
+  if (!partial || rows < 1 || rows > 128 || M < 1) return (int)hipErrorInvalidValue;
+  DwBnFinalize fin;
+  fin.partial = partial; fin.gamma = gamma; fin.beta = beta; fin.moving_mean = moving_mean; fin.moving_var = moving_var;
+  fin.save_mean = save_mean; fin.save_invstd = save_invstd; fin.scale = scale_shift; fin.shift = scale_shift + C;
+  fin.rows = rows; fin.M = M;
+  fin.eps = eps; fin.momentum = momentum;
+  return dw_tiled_fwd(x, w, y, B, H, W, C, relu_in, nullptr, nullptr, fin, stream);
 }
 
 extern "C" long spnet_dwconv3x3_tiled_rows(int B, int H, int W, int C) {

@@ -18,6 +18,16 @@
 // (deterministic; no float atomics).
 #include "gemm_tile.h"
 
+#ifndef SP_BK
+#define SP_BK 32
+#endif
+#ifndef SP_PIPE
+#define SP_PIPE 1        // 0: the compiler-scheduled main loop everywhere (A/B measurements)
+#endif
+#ifndef SP_PIPE_MIN_TILES
+#define SP_PIPE_MIN_TILES 32
+#endif
+
 // 4 waves (WM x WN), each wave owns a (BM/WM) x (BN/WN) block built from 16x16 MFMA tiles
 // (v_mfma_f32_16x16x4_f32: D col = l&15, row = 4*(l>>4)+reg).  Tile t+1 travels global -> registers while
 // tile t is multiplied, and is written to the idle LDS buffer in the MIDDLE of the MFMA stream (nobody
@@ -29,7 +39,33 @@
 // tile t % tiles_n, so the extra stores are spread evenly over the workgroups that stage that row tile.
 // (blended kernels of the small tiles are held to 3 workgroups per CU like their plain counterparts: the middle
 // flow's 768-workgroup launches are exactly one resident wave of 3 per CU)
-template <int BM, int BN, int BK, int WM, int WN, int AMAJ, int BMAJ, int AX = 0>
+#ifdef SP_STAMPS
+// Diagnostic build only (tools/gemm_phases.py): per-workgroup 100 MHz real-time stamps of the kernel's phases, written
+// to a buffer nothing else reads.  [workgroup][8]: entry, first tile in LDS, main loop done, statistics done, stores drained.
+__device__ unsigned long long sp_stamps[16384 * 8];
+#define SP_STAMP(i) do { if (tid == 0 && gwg < 16384) { sp_stamps[gwg * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); \
+  if ((i) == 1 || (i) == 2) sp_stamps[gwg * 8 + 4 + (i)] = __builtin_amdgcn_s_memtime(); } } while (0)
+extern "C" int spnet_debug_read_stamps(unsigned long long* host, int n) {
+  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(sp_stamps), sizeof(unsigned long long) * n, 0, hipMemcpyDeviceToHost);
+}
+#else
+#define SP_STAMP(i)
+#endif
+
+// N x { one MFMA, PER instructions of class MASK } for the instruction scheduler
+template <int N, int MASK, int PER>
+__device__ __forceinline__ void sp_interleave() {
+#pragma unroll
+  for (int i = 0; i < N; ++i) {
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+    __builtin_amdgcn_sched_group_barrier(MASK, PER, 0);
+  }
+}
+
+// PIPE = 1: the explicitly software-pipelined main loop (below) instead of the compiler-scheduled one.  It needs four
+// K tiles of lead-in and pays from about 32 K tiles per workgroup (the weight gradients, the exit flow): measured per
+// shape with tools/gemm_table.py, +3..8 % there, -10..20 % on the 2-8-tile GEMMs of the entry flow, equal at 23 tiles.
+template <int BM, int BN, int BK, int WM, int WN, int AMAJ, int BMAJ, int AX = 0, int PIPE = 0>
 __global__ __launch_bounds__(256, (AX && BM * BN <= 96 * 64) ? 3 : 2) void gemm_f32_kernel(const float* __restrict__ A_, int lda,
                                                        const float* __restrict__ B_, int ldb,
                                                        float* __restrict__ C_, int ldc, int M, int N,
@@ -60,6 +96,8 @@ __global__ __launch_bounds__(256, (AX && BM * BN <= 96 * 64) ? 3 : 2) void gemm_
 
   const int nblk = tiles_m * tiles_n * nsplit;
   int lid = xcd_remap(blockIdx.x, nblk);
+  const int gwg = blockIdx.x;
+  SP_STAMP(0);
   const int tn = lid % tiles_n;
   lid /= tiles_n;
   const int tm = lid % tiles_m;
@@ -87,6 +125,8 @@ __global__ __launch_bounds__(256, (AX && BM * BN <= 96 * 64) ? 3 : 2) void gemm_
 #pragma unroll
       for (int r = 0; r < 4; ++r) acc[i][j][r] = 0.f;
 
+  static_assert(!PIPE || (!AX && TM * TN < 16), "no pipelined form of the blended kernels and of the 128x128 tiles "
+                                                "(a second fragment set does not fit their register budget)");
   // Two register stages: while tile t is multiplied, tile t+1 waits in one stage (it is written to the
   // idle LDS buffer in the middle of the MFMA stream) and tile t+2 is already being fetched into the
   // other, so a global load has one and a half K tiles of MFMA time to arrive.
@@ -147,17 +187,108 @@ __global__ __launch_bounds__(256, (AX && BM * BN <= 96 * 64) ? 3 : 2) void gemm_
     }
     sa[0].store(smem, tid);
     sb[0].store(smem + SA::SIZE, tid);
+    if constexpr (PIPE) {                          // tiles 0 and 1 in LDS, tiles 2 and 3 on their way into the stages
+      if (nt > 1) {
+        sa[1].store(smem + STAGE, tid);
+        sb[1].store(smem + STAGE + SA::SIZE, tid);
+      }
+      if (nt > 2) fetch(sa[0], sb[0], kbeg + 2 * BK, wsh);
+      if (nt > 3) fetch(sa[1], sb[1], kbeg + 3 * BK, wsh);
+    }
   }
   __syncthreads();
+  SP_STAMP(1);
 
   // PAR = t & 1: tile t sits in LDS buffer PAR, tile t+1 in register stage 1-PAR, stage PAR is free.
   // FULL: tile t+2 exists and lies completely below kend -> its fetch is branch-free, the whole step is one
   // basic block and the compiler interleaves loads, LDS writes and MFMAs.
-  const long aoff = (AMAJ == SP_K_MAJOR ? (long)kbeg : (long)kbeg * lda) + 2 * SA::kstep(lda);
-  const long boff = (BMAJ == SP_K_MAJOR ? (long)kbeg : (long)kbeg * ldb) + 2 * SB::kstep(ldb);
+  const long aoff = (AMAJ == SP_K_MAJOR ? (long)kbeg : (long)kbeg * lda) + (PIPE ? 4 : 2) * SA::kstep(lda);
+  const long boff = (BMAJ == SP_K_MAJOR ? (long)kbeg : (long)kbeg * ldb) + (PIPE ? 4 : 2) * SB::kstep(ldb);
   const float* Ak = A + aoff;
   const float* Bk = B + boff;
   const float* Xk = AX ? X2 + aoff : nullptr;      // second tensor of the blended operand
+  // Plain (AX = 0) kernels: the main loop is an explicit software pipeline over the two 16-deep chunks of a K tile.
+  // Per step t (LDS buffer cur = t & 1 holds tile t; two register stages, stage t & 1 holds tile t+2):
+  //   first half    fragments of chunk 1 (cur) -> set 1  |  MFMAs of chunk 0 on set 0
+  //   barrier       (every wave has its last fragments of cur; tile t+1 is complete in nxt)
+  //   second half   fragments of chunk 0 of tile t+1 (nxt) -> set 0 | stage (tile t+2) -> cur | global loads of tile
+  //                 t+4 -> the same stage  |  MFMAs of chunk 1 on set 1
+  // Every LDS fragment read is issued a chunk (>= 16 MFMAs) ahead of its first use, the stage is written to LDS TWO
+  // steps after its global loads were issued (measured with the loads, the stage stores or the fragment reads knocked
+  // out: with ONE step of cover the waves stall 0.5 us per step in front of the stage stores, waiting for
+  // first-touch lines of the A operand) and a full step before the barrier that publishes it, so a wave
+  // reaches the barrier with nothing outstanding and leaves it with a chunk of MFMAs ready to issue.  The
+  // sched_group_barrier sequences pin that order in the branch-free FULL step and spread the LDS / global
+  // instructions one per MFMA (an MFMA occupies the SIMD's issue port for 8 of its 32 cycles): left alone, hipcc
+  // issues every fragment read directly in front of its first MFMA and sinks the global loads to the end of a step.
+  static_assert(NCH == 2, "the pipelined step is written for two chunks per K tile");
+  float fa[2][TM][4], fb[2][TN][4];
+  constexpr int NMF = TM * TN * 4;                   // MFMAs per chunk
+  constexpr int NLD = SA::NV + SB::NV;               // global loads = LDS stores per tile and thread
+  constexpr int NFR = SA::NFR + SB::NFR;             // fragment reads per chunk (before ds_read2 merging)
+  constexpr int PER = (NFR + 2 * NLD <= NMF) ? 1 : 2;   // LDS / global instructions per MFMA in the interleave
+  auto frd0 = [&](const float* buf, int c) {
+    SA::frags(buf, wm * (TM * 16), lane, c, fa[0]);
+    SB::frags(buf + SA::SIZE, wn * (TN * 16), lane, c, fb[0]);
+  };
+  auto frd1 = [&](const float* buf, int c) {
+    SA::frags(buf, wm * (TM * 16), lane, c, fa[1]);
+    SB::frags(buf + SA::SIZE, wn * (TN * 16), lane, c, fb[1]);
+  };
+  auto mma0 = [&]() {
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[0][i][q], fb[0][j][q], acc[i][j], 0, 0, 0);
+  };
+  auto mma1 = [&]() {
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[1][i][q], fb[1][j][q], acc[i][j], 0, 0, 0);
+  };
+  auto pstep = [&](auto par, auto full, int t) {
+    constexpr int PAR = decltype(par)::value;
+    constexpr bool FULL = decltype(full)::value;   // tile t+4 exists and lies completely below kend
+    float* cur = smem + PAR * STAGE;
+    const float* nxt = smem + (1 - PAR) * STAGE;
+    frd1(cur, 1);
+    mma0();
+    if (FULL) {
+      sp_interleave<(NFR + PER - 1) / PER, 0x100, PER>();
+      __builtin_amdgcn_sched_group_barrier(0x008, NMF, 0);
+      __builtin_amdgcn_sched_barrier(0);           // nothing crosses: chunk 0 is multiplied in front of the barrier
+    }
+    __syncthreads();
+    if (FULL) __builtin_amdgcn_sched_barrier(0);
+    if (FULL || t + 1 < nt) frd0(nxt, 0);
+    if (FULL || t + 2 < nt) {
+      sa[PAR].store(cur, tid);
+      sb[PAR].store(cur + SA::SIZE, tid);
+    }
+    if (FULL) {
+      sa[PAR].load_full(Ak);
+      sb[PAR].load_full(Bk);
+      Ak += SA::kstep(lda);
+      Bk += SB::kstep(ldb);
+    } else if (t + 4 < nt) {
+      fetch(sa[PAR], sb[PAR], kbeg + (t + 4) * BK, wsh);
+    }
+    mma1();
+    if (FULL) {
+      sp_interleave<(NFR + PER - 1) / PER, 0x100, PER>();
+      sp_interleave<(NLD + PER - 1) / PER, 0x200, PER>();
+      sp_interleave<(NLD + PER - 1) / PER, 0x020, PER>();
+      __builtin_amdgcn_sched_group_barrier(0x008, NMF, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
   auto step = [&](auto par, auto full, int t) {
     constexpr int PAR = decltype(par)::value;
     constexpr bool FULL = decltype(full)::value;
@@ -205,17 +336,37 @@ __global__ __launch_bounds__(256, (AX && BM * BN <= 96 * 64) ? 3 : 2) void gemm_
   typedef std::integral_constant<int, 1> P1;
   const int nfull = (kend - kbeg) / BK;            // complete K tiles of this slice
   int t = 0;
-  for (; t + 3 < nfull; t += 2) {                  // tiles t+2 and t+3 are complete
-    step(P0(), std::true_type(), t);
-    step(P1(), std::true_type(), t + 1);
-  }
-  for (; t < nt; t += 2) {
-    step(P0(), std::false_type(), t);
-    if (t + 1 < nt) step(P1(), std::false_type(), t + 1);
+  if constexpr (PIPE)
+    if (nt > 0) frd0(smem, 0);                     // fragments of tile 0, chunk 0
+  if constexpr (!PIPE) {
+    for (; t + 3 < nfull; t += 2) {                // tiles t+2 and t+3 are complete
+      step(P0(), std::true_type(), t);
+      step(P1(), std::true_type(), t + 1);
+    }
+    for (; t < nt; t += 2) {
+      step(P0(), std::false_type(), t);
+      if (t + 1 < nt) step(P1(), std::false_type(), t + 1);
+    }
+  } else {
+    for (; t + 5 < nfull; t += 2) {                // tiles t+4 and t+5 are complete
+      pstep(P0(), std::true_type(), t);
+      pstep(P1(), std::true_type(), t + 1);
+    }
+    for (; t < nt; t += 2) {
+      pstep(P0(), std::false_type(), t);
+      if (t + 1 < nt) pstep(P1(), std::false_type(), t + 1);
+    }
   }
 
+  SP_STAMP(2);
   gemm_epilogue<SA, SB, BM, BN, WM, WN, TM, TN>(acc, smem, C, ldc, M, N, m0, n0, tm, zs, slab_stride, bias, colstats,
                                                 tid, lane, wm, wn);
+#ifdef SP_STAMPS
+  SP_STAMP(3);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  SP_STAMP(4);
+#endif
 }
 
 // out[row*ldc + col] = sum_z ws[z*M*N + row*N + col] (+ bias[col]); N % 4 == 0, ldc % 4 == 0.
@@ -276,9 +427,6 @@ extern "C" int spnet_reduce_slabs(const float* ws, int nslab, int M, int N, floa
   SPNET_RETURN_LAUNCH_STATUS();
 }
 
-#ifndef SP_BK
-#define SP_BK 32
-#endif
 
 // xf: 0 = plain operands, 1 = blended A (forward form only)
 template <int BM, int BN, int WM, int WN>
@@ -289,16 +437,29 @@ static int launch_tile(const float* A, int amaj, int lda, const float* B, int bm
                        float* dy_out = nullptr) {
   const int tm = spnet_cdiv(M, BM), tn = spnet_cdiv(N, BN);
   dim3 grid(tm * tn * nsplit), block(256);
+  // the pipelined main loop from 32 K tiles per workgroup (see the kernel's header comment)
+  constexpr bool CAN_PIPE = SP_PIPE && (BM / WM / 16) * (BN / WN / 16) < 16;
+  const bool pipe = CAN_PIPE && !xf && spnet_cdiv(K < k_chunk ? K : k_chunk, SP_BK) >= SP_PIPE_MIN_TILES;
 #define SP_ARGS A, lda, B, ldb, C, ldc, M, N, K, k_chunk, slab_stride, tm, tn, nsplit, bias, colstats, batch, X2, coef, cld, dy_out
-#define SP_LAUNCH(BKV, AM, BMJ, AXV) \
-  hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, BKV, WM, WN, AM, BMJ, AXV>), grid, block, 0, st, SP_ARGS)
+#define SP_LAUNCH(BKV, AM, BMJ, AXV, PV) \
+  hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, BKV, WM, WN, AM, BMJ, AXV, PV>), grid, block, 0, st, SP_ARGS)
+#define SP_LAUNCH_P(AM, BMJ)                                          \
+  do {                                                                \
+    if constexpr (CAN_PIPE) {                                         \
+      if (pipe) SP_LAUNCH(SP_BK, AM, BMJ, 0, 1);                      \
+      else SP_LAUNCH(SP_BK, AM, BMJ, 0, 0);                           \
+    } else {                                                          \
+      SP_LAUNCH(SP_BK, AM, BMJ, 0, 0);                                \
+    }                                                                 \
+  } while (0)
   if (xf == 1) {
-    if (amaj == SP_K_MAJOR && bmaj == SP_OUT_MAJOR) SP_LAUNCH(SP_BK, SP_K_MAJOR, SP_OUT_MAJOR, 1);
+    if (amaj == SP_K_MAJOR && bmaj == SP_OUT_MAJOR) SP_LAUNCH(SP_BK, SP_K_MAJOR, SP_OUT_MAJOR, 1, 0);
     else return (int)hipErrorInvalidValue;
-  } else if (amaj == SP_K_MAJOR && bmaj == SP_OUT_MAJOR) SP_LAUNCH(SP_BK, SP_K_MAJOR, SP_OUT_MAJOR, 0);
-  else if (amaj == SP_K_MAJOR && bmaj == SP_K_MAJOR) SP_LAUNCH(SP_BK, SP_K_MAJOR, SP_K_MAJOR, 0);
-  else if (amaj == SP_OUT_MAJOR && bmaj == SP_OUT_MAJOR) SP_LAUNCH(SP_BK, SP_OUT_MAJOR, SP_OUT_MAJOR, 0);
+  } else if (amaj == SP_K_MAJOR && bmaj == SP_OUT_MAJOR) SP_LAUNCH_P(SP_K_MAJOR, SP_OUT_MAJOR);
+  else if (amaj == SP_K_MAJOR && bmaj == SP_K_MAJOR) SP_LAUNCH_P(SP_K_MAJOR, SP_K_MAJOR);
+  else if (amaj == SP_OUT_MAJOR && bmaj == SP_OUT_MAJOR) SP_LAUNCH_P(SP_OUT_MAJOR, SP_OUT_MAJOR);
   else return (int)hipErrorInvalidValue;
+#undef SP_LAUNCH_P
 #undef SP_LAUNCH
 #undef SP_ARGS
   return 0;

@@ -43,6 +43,7 @@ struct TileStage {
   static_assert(!PERM || MAJ == SP_K_MAJOR, "row permutation is for K-major images");
   static constexpr int LD = (MAJ == SP_K_MAJOR) ? (BK + 8) : (VW == 4 ? BR : (VW == 2 ? BR + 8 : BR + 4));
   static constexpr int SIZE = (MAJ == SP_K_MAJOR) ? BR * LD : BK * LD;
+  static constexpr int NFR = (MAJ == SP_K_MAJOR) ? T : 4 * (T / VW);   // ds_read instructions of one frags() call
   static_assert(BR % 16 == 0 && BK % 16 == 0, "tile shape");
   float4 v[NV];
   unsigned off[NV];     // element offset of this thread's float4 slots at k0 = 0, rows clamped into range
@@ -116,6 +117,19 @@ struct TileStage {
       float4 t = *reinterpret_cast<const float4*>(base + (ok ? offs[i] + shift : 0));
       t.x = ok ? t.x : 0.f; t.y = ok ? t.y : 0.f; t.z = ok ? t.z : 0.f; t.w = ok ? t.w : 0.f;
       v[i] = t;
+    }
+  }
+  // Cache-line prefetch of a whole tile (every 128-byte line touched once, by thread i < NLINES): address of this
+  // thread's line of the tile that starts at reduction step k0 (rows clamped like init()).
+  static constexpr int NLINES = (MAJ == SP_K_MAJOR) ? BR * (BK / 32) : BK * (BR / 32);
+  static __device__ __forceinline__ const float* line_addr(const float* __restrict__ P, int ld, int r0, int R, int k0,
+                                                           int i) {
+    if (MAJ == SP_K_MAJOR) {
+      const int r = i / (BK / 32), seg = i % (BK / 32);
+      return P + (long)min(r0 + r, R - 1) * ld + k0 + seg * 32;
+    } else {
+      const int k = i / (BR / 32), seg = i % (BR / 32);
+      return P + (long)(k0 + k) * ld + min(r0 + seg * 32, R - 4);
     }
   }
   static __device__ __forceinline__ long kstep(int ld) { return (MAJ == SP_K_MAJOR) ? (long)BK : (long)BK * ld; }

@@ -53,16 +53,28 @@ class KernelTimer:
 
     def __init__(self):
         self.records = []
+        self.tags = {}
 
     def start(self):
         e = torch.cuda.Event(enable_timing=True)
         e.record()
         return e
 
-    def stop(self, family, start, work):
+    def stop(self, family, start, work, tag=None):
         e = torch.cuda.Event(enable_timing=True)
         e.record()
         self.records.append((family, start, e, work))
+        if tag is not None:
+            self.tags[len(self.records) - 1] = tag
+
+    def tagged(self):
+        """{tag: (launches, total_ms, total_work)} of the launches that carry a tag (tools/gemm_table.py)."""
+        out = {}
+        for i, tag in self.tags.items():
+            fam, s, e, w = self.records[i]
+            n, ms, tw = out.get(tag, (0, 0.0, 0.0))
+            out[tag] = (n + 1, ms + s.elapsed_time(e), tw + w)
+        return out
 
     def totals(self):
         """{family: (launches, total_ms, total_work)} -- call after torch.cuda.synchronize()."""
@@ -319,6 +331,8 @@ class Engine:
         self._wgrad_table = None
         self._first_middle = None
         self.defer_mid_wgrad = os.environ.get("SPNET_DEFER_WGRAD", "1") != "0"
+        # BatchNorm finalize kernels folded into their consumers where the statistics arrive as <= 128 partial rows
+        self.bn_fold = os.environ.get("SPNET_BN_FOLD", "1") != "0"
         # pointwise weight gradients on a side stream (joined before Adam); SPNET_OVERLAP_WGRAD=0: one stream
         self.overlap_wgrad = os.environ.get("SPNET_OVERLAP_WGRAD", "1") != "0"
         # Optional: capture the single-GPU train step as a hipGraph after one eager step.  Off by default:
@@ -708,7 +722,7 @@ class Engine:
             L.spnet_gemm_f32_batched(a0, b0, c0, table.data_ptr(), nb, OUT_MAJOR, cin, OUT_MAJOR, cout, cout, cin, cout, M,
                                      5, _stream())
             if prof is not None:
-                prof.stop("gemm", t0, 2.0 * nb * cin * cout * M)
+                prof.stop("gemm", t0, 2.0 * nb * cin * cout * M, ("AB x%d batched" % nb, cin, cout, M))
 
         side = self.wgrad_stream
         if side is None:
@@ -869,7 +883,7 @@ def _gemm(A, a_major, lda, Bm, b_major, ldb, C, ldc, M, N, K, eng, bias=None, sp
     L.spnet_gemm_f32(L.ptr(A), a_major, lda, L.ptr(Bm), b_major, ldb, L.ptr(C), ldc, M, N, K, split_k,
                      eng.ws_ptr(region), region[1], L.ptr(bias), tile, _stream())
     if prof is not None:
-        prof.stop("gemm", t0, 2.0 * M * N * K)
+        prof.stop("gemm", t0, 2.0 * M * N * K, ("aA"[a_major] + "bB"[b_major], M, N, K))
 
 
 _stat_rows = __import__("ctypes").c_int(0)
@@ -886,7 +900,7 @@ def _gemm_colstats(A, lda, Bm, ldb, C, ldc, M, N, K, eng, region=WS_BNP):
     L.spnet_gemm_f32_colstats(L.ptr(A), K_MAJOR, lda, L.ptr(Bm), OUT_MAJOR, ldb, L.ptr(C), ldc, M, N, K, 0,
                               eng.ws_ptr(region), __import__("ctypes").addressof(_stat_rows), _stream())
     if prof is not None:
-        prof.stop("gemm", t0, 2.0 * M * N * K)
+        prof.stop("gemm", t0, 2.0 * M * N * K, ("aB+stats", M, N, K))
     return _stat_rows.value
 
 
@@ -1093,7 +1107,7 @@ class Pointwise:
         L.spnet_gemm_f32_bnblend(L.ptr(g), L.ptr(yp), L.ptr(bn.coef), bn.cld, self.cout, L.ptr(self.wT), self.cin,
                                  L.ptr(dx), self.cin, self.M, self.cin, self.cout, 0, L.ptr(dyb), _stream())
         if prof is not None:
-            prof.stop("gemm", t0, 2.0 * self.M * self.cin * self.cout)
+            prof.stop("gemm", t0, 2.0 * self.M * self.cin * self.cout, ("aB blend", self.M, self.cin, self.cout))
         side = e.wgrad_stream
         if self.defer_wgrad:
             e.deferred_wgrads.append((x, dyb, self.gw, self.cin, self.cout, self.M))
@@ -1131,7 +1145,7 @@ class Conv3x3Gemm(Node):
             return call()
         t0 = prof.start()
         call()
-        prof.stop("gemm", t0, flops)
+        prof.stop("gemm", t0, flops, ("conv3x3 implicit", int(flops / (2.0 * 9 * self.cin * self.cout)), self.cout, 9 * self.cin))
 
     def fwd(self, training):
         e = self.e
@@ -1281,6 +1295,8 @@ class SepConvBN:
         if self.rows_src * 2 * cin > WS_BNP[1]:
             raise RuntimeError("workspace regions too small for %s" % name)
         self.consumer_rows = 0              # set by the consumer (lazy mode)
+        self.fin_by_consumer = False        # set by a SepConvBN consumer: it finalizes this unit's BatchNorm forward
+        self.pending_rows = 0               # > 0: partial rows waiting in WS_BNP for the consumer's prologue
         if eng.train_capable:
             self.gwd = eng.G(name + "/depthwise_kernel")
             self.dz = eng.new(B, H, W, cin)
@@ -1296,6 +1312,9 @@ class SepConvBN:
             self.dbn = None if (bwd_inplace or self.blend) else eng.new(B, H, W, cout)
         if src.bn is not None and hasattr(src, "owner"):
             src.owner.consumer_rows = self.rows_src
+            # the producer's training-forward BatchNorm finalize runs inside this unit's depthwise prologue
+            # (spnet_dwconv3x3_tiled_fwd_bnfin) whenever its GEMM leaves at most 128 partial rows
+            src.owner.fin_by_consumer = eng.train_capable and eng.bn_fold
 
     def ref(self):
         if self.mode == "apply":
@@ -1309,13 +1328,31 @@ class SepConvBN:
         prof = e.prof
         if prof is not None:
             t0 = prof.start()
-        L.spnet_dwconv3x3_tiled_fwd(L.ptr(self.src.t), L.ptr(self.wd), L.ptr(self.z), e.B, self.H, self.W, self.cin,
-                                    self.relu_in, sb.scale_ptr if sb else None, sb.shift_ptr if sb else None, _stream())
+        owner = getattr(self.src, "owner", None)
+        if training and owner is not None and owner.pending_rows:
+            L.spnet_dwconv3x3_tiled_fwd_bnfin(L.ptr(self.src.t), L.ptr(self.wd), L.ptr(self.z), e.B, self.H, self.W,
+                                              self.cin, self.relu_in, e.ws_ptr(WS_BNP), owner.pending_rows, sb.M,
+                                              L.ptr(sb.gamma), L.ptr(sb.beta), L.ptr(sb.mm), L.ptr(sb.mv), sb.mean_ptr,
+                                              sb.invstd_ptr, L.ptr(sb.ss), BN_EPS, BN_MOMENTUM, _stream())
+            owner.pending_rows = 0
+        else:
+            L.spnet_dwconv3x3_tiled_fwd(L.ptr(self.src.t), L.ptr(self.wd), L.ptr(self.z), e.B, self.H, self.W, self.cin,
+                                        self.relu_in, sb.scale_ptr if sb else None, sb.shift_ptr if sb else None, _stream())
         if prof is not None:
-            prof.stop("dw", t0, 2.0 * 4 * self.M * self.cin)        # read x + write z
+            prof.stop("dw", t0, 2.0 * 4 * self.M * self.cin, ("dw fwd", self.H, self.W, self.cin))   # read x + write z
         if training:
             rows = self.pw.fwd_colstats(self.z, self.yp)
-            self.bn.finalize(rows)
+            if self.fin_by_consumer and rows <= 128:
+                self.pending_rows = rows            # the consumer's depthwise is the next launch on this stream
+            elif self.mode == "apply" and e.bn_fold:
+                bn = self.bn                        # finalize + y = act(BN(yp)) (+ residual) in one launch
+                L.spnet_bn_finalize_apply(e.ws_ptr(WS_BNP), rows, L.ptr(self.yp), self.M, self.cout, L.ptr(bn.gamma),
+                                          L.ptr(bn.beta), L.ptr(bn.mm), L.ptr(bn.mv), bn.mean_ptr, bn.invstd_ptr,
+                                          L.ptr(bn.ss), self.act, L.ptr(self.residual), L.ptr(self.y), BN_EPS,
+                                          BN_MOMENTUM, _stream())
+                return
+            else:
+                self.bn.finalize(rows)
         else:
             self.pw.fwd(self.z, self.yp)
             self.bn.infer()
@@ -1350,7 +1387,7 @@ class SepConvBN:
                                     st.mean_ptr if st else None, st.invstd_ptr if st else None,
                                     e.ws_ptr(WS_BNP) if st else None, L.ptr(self.src.stats_x), _stream())
         if prof is not None:
-            prof.stop("dw", t0, 3.0 * 4 * self.M * self.cin)        # read dz, read x, write dx
+            prof.stop("dw", t0, 3.0 * 4 * self.M * self.cin, ("dw bwd", self.H, self.W, self.cin))   # read dz, read x, write dx
         return self.dx
 
 

@@ -234,6 +234,103 @@ def test_dwconv_tiled_bwd_sums_for_a_block_output(L, B, H, W, C):
                                     1, None, ws.data_ptr(), None, None, None, None, None, ypd.data_ptr(), st())
 
 
+@pytest.mark.parametrize("M,C,P,act,res", [(6144, 728, 64, 0, 1), (1536, 2048, 12, 1, 0), (700, 36, 128, 0, 1), (300, 260, 3, 2, 0)])
+def test_batchnorm_finalize_folded_into_the_apply_pass(L, M, C, P, act, res):
+    """spnet_bn_finalize_apply == spnet_bn_finalize_fwd + spnet_bn_apply, bit for bit (one launch while P <= 128)."""
+    rs = np.random.RandomState(M + C)
+    x, r = dev(rs.randn(M, C)), dev(rs.randn(M, C))
+    part = dev(rs.randn(P, 2, C) * 3)
+    part[:, 1] = part[:, 1].abs() * 40 + 10
+    gamma, beta = dev(rs.rand(C) + 0.5), dev(rs.randn(C) * 0.3)
+    outs = []
+    for fused in (0, 1):
+        mm, mv = dev(np.full(C, 0.25)), dev(np.full(C, 0.75))
+        save, ss = torch.full((2 * C,), float("nan"), device="cuda"), torch.full((2 * C,), float("nan"), device="cuda")
+        y = torch.full((M, C), float("nan"), device="cuda")
+        if fused:
+            L.spnet_bn_finalize_apply(part.data_ptr(), P, x.data_ptr(), M, C, gamma.data_ptr(), beta.data_ptr(), mm.data_ptr(),
+                                      mv.data_ptr(), save.data_ptr(), save[C:].data_ptr(), ss.data_ptr(), act,
+                                      r.data_ptr() if res else None, y.data_ptr(), 1e-3, 0.99, st())
+        else:
+            L.spnet_bn_finalize_fwd(part.data_ptr(), P, M, C, gamma.data_ptr(), beta.data_ptr(), mm.data_ptr(), mv.data_ptr(),
+                                    save.data_ptr(), save[C:].data_ptr(), ss.data_ptr(), 1e-3, 0.99, st())
+            L.spnet_bn_apply(x.data_ptr(), M, C, ss.data_ptr(), act, r.data_ptr() if res else None, 0, y.data_ptr(), st())
+        torch.cuda.synchronize()
+        outs.append((y, save, ss, mm, mv))
+    for a, b in zip(*outs):
+        assert not torch.isnan(b).any()
+        assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("M,C", [(6144, 728), (1536, 1536), (500, 36)])
+def test_batchnorm_backward_from_partial_sums(L, M, C):
+    """spnet_bn_bwd_from_partials against the closed form (float64), through BOTH of its paths: the one-launch form
+    (<= 128 partial rows: finalize folded into the apply pass) and finalize + apply (more rows); the two agree bit for
+    bit when fed the same sums."""
+    rs = np.random.RandomState(M)
+    x, g = rs.randn(M, C).astype(np.float32), rs.randn(M, C).astype(np.float32)
+    gamma = (rs.rand(C) + 0.5).astype(np.float32)
+    mu, var = x.astype(np.float64).mean(0), x.astype(np.float64).var(0)
+    invstd = 1.0 / np.sqrt(var + 1e-3)
+    xh = (x - mu) * invstd
+    sg, sgx = g.astype(np.float64).sum(0), (g * xh).sum(0)
+    want = gamma * invstd * (g - sg / M - xh * sgx / M)
+    xd, gd, gam = dev(x), dev(g), dev(gamma)
+    mud, isd = dev(mu), dev(invstd)
+    res = []
+    for P in (32, 160):
+        part = np.zeros((P, 2, C), np.float32)          # the same sums, spread over the first two rows
+        part[0, 0], part[0, 1] = sg, sgx
+        dx = torch.full((M, C), float("nan"), device="cuda")
+        dga, dbe = torch.empty(C, device="cuda"), torch.empty(C, device="cuda")
+        co = torch.empty(3 * C, device="cuda")
+        L.spnet_bn_bwd_from_partials(xd.data_ptr(), gd.data_ptr(), M, C, gam.data_ptr(), gam.data_ptr(), mud.data_ptr(),
+                                     isd.data_ptr(), P, dev(part).data_ptr(), dx.data_ptr(), dga.data_ptr(), dbe.data_ptr(),
+                                     co.data_ptr(), st())
+        close(dx, want, rtol=1e-4, atol=1e-4)
+        close(dbe, sg, rtol=1e-6, atol=1e-4)
+        close(dga, sgx, rtol=1e-6, atol=1e-4)
+        res.append((dx, dga, dbe))
+    for a, b in zip(*res):
+        assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("B,H,W,C,rows,relu_in", [(4, 12, 16, 728, 64, 1), (2, 6, 8, 1536, 12, 1), (3, 24, 32, 128, 128, 0),
+                                                  (2, 12, 16, 260, 7, 1)])
+def test_dwconv_tiled_forward_with_the_producer_batchnorm_finalize_folded_in(L, B, H, W, C, rows, relu_in):
+    """spnet_dwconv3x3_tiled_fwd_bnfin == spnet_bn_finalize_fwd followed by spnet_dwconv3x3_tiled_fwd, bit for bit:
+    output, saved statistics, scale/shift and the moving-statistics update (the engine's middle / exit flow)."""
+    rs = np.random.RandomState(C + rows)
+    M = B * H * W
+    x = dev(rs.randn(B, H, W, C))
+    w = dev(rs.randn(3, 3, C) * 0.3)
+    part = dev(rs.randn(rows, 2, C) * 3)
+    part[:, 1] = part[:, 1].abs() * 40 + 10          # sums of squares
+    gamma, beta = dev(rs.rand(C) + 0.5), dev(rs.randn(C) * 0.3)
+
+    def fresh():
+        return (dev(rs.randn(C) * 0 + 0.25), dev(np.ones(C) * 0.75), torch.full((2 * C,), float("nan"), device="cuda"),
+                torch.full((2 * C,), float("nan"), device="cuda"), torch.full((B, H, W, C), float("nan"), device="cuda"))
+
+    mm0, mv0, save0, ss0, y0 = fresh()
+    L.spnet_bn_finalize_fwd(part.data_ptr(), rows, M, C, gamma.data_ptr(), beta.data_ptr(), mm0.data_ptr(), mv0.data_ptr(),
+                            save0.data_ptr(), save0[C:].data_ptr(), ss0.data_ptr(), 1e-3, 0.99, st())
+    L.spnet_dwconv3x3_tiled_fwd(x.data_ptr(), w.data_ptr(), y0.data_ptr(), B, H, W, C, relu_in, ss0.data_ptr(),
+                                ss0[C:].data_ptr(), st())
+    mm1, mv1, save1, ss1, y1 = fresh()
+    L.spnet_dwconv3x3_tiled_fwd_bnfin(x.data_ptr(), w.data_ptr(), y1.data_ptr(), B, H, W, C, relu_in, part.data_ptr(), rows, M,
+                                      gamma.data_ptr(), beta.data_ptr(), mm1.data_ptr(), mv1.data_ptr(), save1.data_ptr(),
+                                      save1[C:].data_ptr(), ss1.data_ptr(), 1e-3, 0.99, st())
+    torch.cuda.synchronize()
+    for a, b in ((y0, y1), (save0, save1), (ss0, ss1), (mm0, mm1), (mv0, mv1)):
+        assert not torch.isnan(b).any()
+        assert torch.equal(a, b)
+    with pytest.raises(L.HipError):                     # more partial rows than the prologue is written for
+        L.spnet_dwconv3x3_tiled_fwd_bnfin(x.data_ptr(), w.data_ptr(), y1.data_ptr(), B, H, W, C, relu_in, part.data_ptr(), 129,
+                                          M, gamma.data_ptr(), beta.data_ptr(), mm1.data_ptr(), mv1.data_ptr(),
+                                          save1.data_ptr(), save1[C:].data_ptr(), ss1.data_ptr(), 1e-3, 0.99, st())
+
+
 @pytest.mark.parametrize("M,N,K", [(6144, 728, 728), (372, 128, 64), (1536, 2048, 1536), (100, 64, 288), (33, 72, 40)])
 @pytest.mark.parametrize("tile", [0, 1, 2, 3, 5, 6, 7, 8])
 def test_gemm_colstats_and_bn_finalize(L, M, N, K, tile):
