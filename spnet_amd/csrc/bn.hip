@@ -375,6 +375,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_scalar_kernel(
 // per-channel results (dgamma / dbeta, or mean / invstd / scale / shift + the moving-statistics update).
 // blockDim = 256 = 8 channel quads x 32 rows; grid = (ceil(C/32), slabs).
 #define BN_FUSE_CH 32
+#define BN_FUSE_AHEAD 3     // rows per thread in flight across the prologue (a 96-row slab entirely)
 __device__ __forceinline__ bool chunk_sums(const float* __restrict__ partial, int P, int C, int c0, double* dred,
                                            double* s_out, double* q_out) {
   const int tid = threadIdx.x;
@@ -412,42 +413,59 @@ __global__ __launch_bounds__(256) void bn_fwd_fused_vec_kernel(
   __shared__ double dred[2 * 16 * BN_FUSE_CH];
   __shared__ __attribute__((aligned(16))) float cf[2][BN_FUSE_CH];
   const int c0 = blockIdx.x * BN_FUSE_CH;
+  const int lane = threadIdx.x & 7, r0 = threadIdx.x >> 3;
+  const int c = c0 + lane * 4;
+  const long rbeg = (long)blockIdx.y * rows_per_slab;
+  const long rend = min(M, rbeg + rows_per_slab);
+  // The slab's first rows are fetched BEFORE the coefficients exist: their latency and the reduction of the partial
+  // rows (an L2 round trip, two barriers) overlap instead of adding up.
+  float4 v0[BN_FUSE_AHEAD], q0[BN_FUSE_AHEAD];
+#pragma unroll
+  for (int u = 0; u < BN_FUSE_AHEAD; ++u) {
+    const long r = rbeg + r0 + 32 * u;
+    const bool ok = r < rend && c < C;
+    const long i = ok ? r * C + c : 0;
+    v0[u] = *reinterpret_cast<const float4*>(x + i);
+    q0[u] = residual ? *reinterpret_cast<const float4*>(residual + i) : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
   double s, q;
   if (chunk_sums(partial, P, C, c0, dred, &s, &q)) {
-    const int c = c0 + threadIdx.x;
-    const BnChannelStats st = bn_channel_stats(s, q, M, gamma[c], beta[c], eps);
+    const int cc = c0 + threadIdx.x;
+    const BnChannelStats st = bn_channel_stats(s, q, M, gamma[cc], beta[cc], eps);
     cf[0][threadIdx.x] = st.scale;
     cf[1][threadIdx.x] = st.shift;
     if (blockIdx.y == 0) {
-      save_mean[c] = st.mean;
-      save_invstd[c] = st.invstd;
-      scale[c] = st.scale;
-      shift[c] = st.shift;
-      moving_mean[c] = bn_moving_update(moving_mean[c], momentum, st.mean);
-      moving_var[c] = bn_moving_update(moving_var[c], momentum, st.unbiased_var);
+      save_mean[cc] = st.mean;
+      save_invstd[cc] = st.invstd;
+      scale[cc] = st.scale;
+      shift[cc] = st.shift;
+      moving_mean[cc] = bn_moving_update(moving_mean[cc], momentum, st.mean);
+      moving_var[cc] = bn_moving_update(moving_var[cc], momentum, st.unbiased_var);
     }
   }
   __syncthreads();
-  const int lane = threadIdx.x & 7, r0 = threadIdx.x >> 3;
-  const int c = c0 + lane * 4;
   if (c >= C) return;
   const float4 sc = *reinterpret_cast<const float4*>(&cf[0][lane * 4]);
   const float4 sh = *reinterpret_cast<const float4*>(&cf[1][lane * 4]);
-  const long rbeg = (long)blockIdx.y * rows_per_slab;
-  const long rend = min(M, rbeg + rows_per_slab);
-  for (long r = rbeg + r0; r < rend; r += 32) {
-    const long i = r * C + c;
-    const float4 v = *reinterpret_cast<const float4*>(x + i);
+  auto emit = [&](long r, const float4 v, const float4 rr) {
     float4 o;
     o.x = act_fwd(fmaf(v.x, sc.x, sh.x), act);
     o.y = act_fwd(fmaf(v.y, sc.y, sh.y), act);
     o.z = act_fwd(fmaf(v.z, sc.z, sh.z), act);
     o.w = act_fwd(fmaf(v.w, sc.w, sh.w), act);
-    if (residual) {
-      const float4 rr = *reinterpret_cast<const float4*>(residual + i);
-      o.x += rr.x; o.y += rr.y; o.z += rr.z; o.w += rr.w;
-    }
-    *reinterpret_cast<float4*>(y + i) = o;
+    if (residual) { o.x += rr.x; o.y += rr.y; o.z += rr.z; o.w += rr.w; }
+    *reinterpret_cast<float4*>(y + r * C + c) = o;
+  };
+#pragma unroll
+  for (int u = 0; u < BN_FUSE_AHEAD; ++u) {
+    const long r = rbeg + r0 + 32 * u;
+    if (r < rend) emit(r, v0[u], q0[u]);
+  }
+  for (long r = rbeg + r0 + 32 * BN_FUSE_AHEAD; r < rend; r += 32) {
+    const long i = r * C + c;
+    const float4 v = *reinterpret_cast<const float4*>(x + i);
+    const float4 rr = residual ? *reinterpret_cast<const float4*>(residual + i) : make_float4(0.f, 0.f, 0.f, 0.f);
+    emit(r, v, rr);
   }
 }
 
@@ -460,37 +478,43 @@ __global__ __launch_bounds__(256) void bn_bwd_fused_vec_kernel(
   __shared__ double dred[2 * 16 * BN_FUSE_CH];
   __shared__ __attribute__((aligned(16))) float cf[5][BN_FUSE_CH];   // k1, k2, k3, mean, invstd
   const int c0 = blockIdx.x * BN_FUSE_CH;
+  const int lane = threadIdx.x & 7, r0 = threadIdx.x >> 3;
+  const int c = c0 + lane * 4;
+  const long rbeg = (long)blockIdx.y * rows_per_slab;
+  const long rend = min(M, rbeg + rows_per_slab);
+  float4 v0[BN_FUSE_AHEAD], g0[BN_FUSE_AHEAD];      // fetched before the coefficients exist (see the forward kernel)
+#pragma unroll
+  for (int u = 0; u < BN_FUSE_AHEAD; ++u) {
+    const long r = rbeg + r0 + 32 * u;
+    const bool ok = r < rend && c < C;
+    const long i = ok ? r * C + c : 0;
+    v0[u] = *reinterpret_cast<const float4*>(x + i);
+    g0[u] = *reinterpret_cast<const float4*>(dy + i);
+  }
   double sg, sgx;
   if (chunk_sums(partial, P, C, c0, dred, &sg, &sgx)) {
-    const int c = c0 + threadIdx.x;
-    const double is = (double)invstd[c];
-    const double a = (double)gamma[c] * is;
+    const int cc = c0 + threadIdx.x;
+    const double is = (double)invstd[cc];
+    const double a = (double)gamma[cc] * is;
     const double b = -a * sgx / (double)M, d = -a * sg / (double)M;
     cf[0][threadIdx.x] = (float)a;
     cf[1][threadIdx.x] = (float)b;
     cf[2][threadIdx.x] = (float)d;
-    cf[3][threadIdx.x] = mean[c];
-    cf[4][threadIdx.x] = invstd[c];
+    cf[3][threadIdx.x] = mean[cc];
+    cf[4][threadIdx.x] = invstd[cc];
     if (blockIdx.y == 0) {
-      dbeta[c] = (float)sg;
-      dgamma[c] = (float)sgx;
+      dbeta[cc] = (float)sg;
+      dgamma[cc] = (float)sgx;
     }
   }
   __syncthreads();
-  const int lane = threadIdx.x & 7, r0 = threadIdx.x >> 3;
-  const int c = c0 + lane * 4;
   if (c >= C) return;
   const float4 k1 = *reinterpret_cast<const float4*>(&cf[0][lane * 4]);
   const float4 k2 = *reinterpret_cast<const float4*>(&cf[1][lane * 4]);
   const float4 k3 = *reinterpret_cast<const float4*>(&cf[2][lane * 4]);
   const float4 mu = *reinterpret_cast<const float4*>(&cf[3][lane * 4]);
   const float4 is = *reinterpret_cast<const float4*>(&cf[4][lane * 4]);
-  const long rbeg = (long)blockIdx.y * rows_per_slab;
-  const long rend = min(M, rbeg + rows_per_slab);
-  for (long r = rbeg + r0; r < rend; r += 32) {
-    const long i = r * C + c;
-    const float4 v = *reinterpret_cast<const float4*>(x + i);
-    const float4 g = *reinterpret_cast<const float4*>(dy + i);
+  auto emit = [&](long r, const float4 v, const float4 g) {
     float4 xh, o;
     xh.x = (v.x - mu.x) * is.x; xh.y = (v.y - mu.y) * is.y;
     xh.z = (v.z - mu.z) * is.z; xh.w = (v.w - mu.w) * is.w;
@@ -498,18 +522,27 @@ __global__ __launch_bounds__(256) void bn_bwd_fused_vec_kernel(
     o.y = fmaf(k1.y, g.y, fmaf(k2.y, xh.y, k3.y));
     o.z = fmaf(k1.z, g.z, fmaf(k2.z, xh.z, k3.z));
     o.w = fmaf(k1.w, g.w, fmaf(k2.w, xh.w, k3.w));
-    *reinterpret_cast<float4*>(dx + i) = o;
+    *reinterpret_cast<float4*>(dx + r * C + c) = o;
+  };
+#pragma unroll
+  for (int u = 0; u < BN_FUSE_AHEAD; ++u) {
+    const long r = rbeg + r0 + 32 * u;
+    if (r < rend) emit(r, v0[u], g0[u]);
+  }
+  for (long r = rbeg + r0 + 32 * BN_FUSE_AHEAD; r < rend; r += 32) {
+    const long i = r * C + c;
+    emit(r, *reinterpret_cast<const float4*>(x + i), *reinterpret_cast<const float4*>(dy + i));
   }
 }
 
 #define BN_FUSE_MAX_P 128
-// slabs of at least 256 rows, about two workgroups per CU
+// slabs of at least 64 rows, about eight workgroups per CU (their prologues overlap each other's streaming)
 static int bn_fuse_rows_per_slab(long M, int C) {
   const int gx = (C + BN_FUSE_CH - 1) / BN_FUSE_CH;
-  long gy = 512 / gx;
+  long gy = 2048 / gx;
   if (gy < 1) gy = 1;
   long rows = (M + gy - 1) / gy;
-  if (rows < 256) rows = 256;
+  if (rows < 64) rows = 64;
   return (int)((rows + 31) / 32 * 32);
 }
 

@@ -1637,6 +1637,15 @@ class _IRConv:
             if not self.direct:
                 L.spnet_patches(L.ptr(self.src.buf), L.ptr(self.col), e.B, self.H, self.W, self.cin, self.kh, self.kw,
                                 self.stride, self.same, 0, _stream())
+            if training and not self.bias and e.bn_fold:
+                # BatchNorm statistics out of the GEMM accumulators, finalize + normalise + ReLU in one more launch
+                # (two when the GEMM leaves more than 128 partial rows): no reduction pass over yp
+                rows = _gemm_colstats(self._A(), self.K, self.w, C, dst, C, self.M, C, self.K, e)
+                L.spnet_bn_finalize_apply(e.ws_ptr(WS_BNP), rows, L.ptr(self.yp), self.M, C, L.ptr(self.ones),
+                                          L.ptr(self.beta), L.ptr(self.mm), L.ptr(self.mv), L.ptr(self.save),
+                                          self.save[C:].data_ptr(), L.ptr(self.ss), ACT_RELU if self.relu else ACT_NONE,
+                                          None, L.ptr(y), BN_EPS, BN_MOMENTUM, _stream())
+                return
             _gemm(self._A(), K_MAJOR, self.K, self.w, OUT_MAJOR, C, dst, C, self.M, C, self.K, e,
                   bias=self.b if self.bias else None)
         if self.bias:
