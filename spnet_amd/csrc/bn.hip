@@ -409,13 +409,18 @@ __global__ __launch_bounds__(256) void bn_fwd_fused_vec_kernel(
     const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ moving_mean,
     float* __restrict__ moving_var, float* __restrict__ save_mean, float* __restrict__ save_invstd,
     float* __restrict__ scale, float* __restrict__ shift, float eps, float momentum, int act,
-    const float* __restrict__ residual, float* __restrict__ y, int rows_per_slab) {
+    const float* __restrict__ residual, float* __restrict__ y, int rows_per_slab, int chunks) {
   __shared__ double dred[2 * 16 * BN_FUSE_CH];
   __shared__ __attribute__((aligned(16))) float cf[2][BN_FUSE_CH];
-  const int c0 = blockIdx.x * BN_FUSE_CH;
+  // XCD-aware order: a row of C floats is not a whole number of 128-byte lines (C = 728), so neighbouring channel
+  // chunks of a slab share cache lines; the workgroups one XCD receives cover contiguous (slab, chunk) ids and the
+  // two halves of such a line meet in ONE L2 instead of being fetched by two.
+  const int wid = xcd_remap(blockIdx.x, gridDim.x);
+  const int bx = wid % chunks, by = wid / chunks;
+  const int c0 = bx * BN_FUSE_CH;
   const int lane = threadIdx.x & 7, r0 = threadIdx.x >> 3;
   const int c = c0 + lane * 4;
-  const long rbeg = (long)blockIdx.y * rows_per_slab;
+  const long rbeg = (long)by * rows_per_slab;
   const long rend = min(M, rbeg + rows_per_slab);
   // The slab's first rows are fetched BEFORE the coefficients exist: their latency and the reduction of the partial
   // rows (an L2 round trip, two barriers) overlap instead of adding up.
@@ -434,7 +439,7 @@ __global__ __launch_bounds__(256) void bn_fwd_fused_vec_kernel(
     const BnChannelStats st = bn_channel_stats(s, q, M, gamma[cc], beta[cc], eps);
     cf[0][threadIdx.x] = st.scale;
     cf[1][threadIdx.x] = st.shift;
-    if (blockIdx.y == 0) {
+    if (by == 0) {
       save_mean[cc] = st.mean;
       save_invstd[cc] = st.invstd;
       scale[cc] = st.scale;
@@ -474,13 +479,15 @@ __global__ __launch_bounds__(256) void bn_fwd_fused_vec_kernel(
 __global__ __launch_bounds__(256) void bn_bwd_fused_vec_kernel(
     const float* __restrict__ x, const float* __restrict__ dy, long M, int C, const float* __restrict__ partial, int P,
     const float* __restrict__ gamma, const float* __restrict__ mean, const float* __restrict__ invstd,
-    float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ dx, int rows_per_slab) {
+    float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ dx, int rows_per_slab, int chunks) {
   __shared__ double dred[2 * 16 * BN_FUSE_CH];
   __shared__ __attribute__((aligned(16))) float cf[5][BN_FUSE_CH];   // k1, k2, k3, mean, invstd
-  const int c0 = blockIdx.x * BN_FUSE_CH;
+  const int wid = xcd_remap(blockIdx.x, gridDim.x);                  // XCD-aware order (see the forward kernel)
+  const int bx = wid % chunks, by = wid / chunks;
+  const int c0 = bx * BN_FUSE_CH;
   const int lane = threadIdx.x & 7, r0 = threadIdx.x >> 3;
   const int c = c0 + lane * 4;
-  const long rbeg = (long)blockIdx.y * rows_per_slab;
+  const long rbeg = (long)by * rows_per_slab;
   const long rend = min(M, rbeg + rows_per_slab);
   float4 v0[BN_FUSE_AHEAD], g0[BN_FUSE_AHEAD];      // fetched before the coefficients exist (see the forward kernel)
 #pragma unroll
@@ -502,7 +509,7 @@ __global__ __launch_bounds__(256) void bn_bwd_fused_vec_kernel(
     cf[2][threadIdx.x] = (float)d;
     cf[3][threadIdx.x] = mean[cc];
     cf[4][threadIdx.x] = invstd[cc];
-    if (blockIdx.y == 0) {
+    if (by == 0) {
       dbeta[cc] = (float)sg;
       dgamma[cc] = (float)sgx;
     }
@@ -712,10 +719,11 @@ extern "C" int spnet_bn_finalize_apply(const float* partial, int P, const float*
   if ((C & 3) || P < 1) return (int)hipErrorInvalidValue;
   if (P <= BN_FUSE_MAX_P) {
     const int rps = bn_fuse_rows_per_slab(M, C);
-    dim3 grid((C + BN_FUSE_CH - 1) / BN_FUSE_CH, (unsigned)((M + rps - 1) / rps));
+    const int chunks = (C + BN_FUSE_CH - 1) / BN_FUSE_CH;
+    dim3 grid((unsigned)(chunks * ((M + rps - 1) / rps)));
     hipLaunchKernelGGL(bn_fwd_fused_vec_kernel, grid, dim3(256), 0, st, x, M, C, partial, P, gamma, beta, moving_mean,
                        moving_var, save_mean, save_invstd, scale_shift, scale_shift + C, eps, momentum, act, residual, y,
-                       rps);
+                       rps, chunks);
     SPNET_RETURN_LAUNCH_STATUS();
   }
   hipLaunchKernelGGL(bn_fwd_finalize_kernel, dim3((C + BN_FIN_CH - 1) / BN_FIN_CH), dim3(256), 0, st, partial, P, C, M,
@@ -735,9 +743,10 @@ extern "C" int spnet_bn_bwd_from_partials(const float* x, const float* dy, long 
   if (C & 3) return (int)hipErrorInvalidValue;
   if (P <= BN_FUSE_MAX_P) {                                  // few partial rows: one launch (bit-identical results)
     const int rps = bn_fuse_rows_per_slab(M, C);
-    dim3 grid((C + BN_FUSE_CH - 1) / BN_FUSE_CH, (unsigned)((M + rps - 1) / rps));
+    const int chunks = (C + BN_FUSE_CH - 1) / BN_FUSE_CH;
+    dim3 grid((unsigned)(chunks * ((M + rps - 1) / rps)));
     hipLaunchKernelGGL(bn_bwd_fused_vec_kernel, grid, dim3(256), 0, st, x, dy, M, C, partial, P, gamma, save_mean,
-                       save_invstd, dgamma, dbeta, dx, rps);
+                       save_invstd, dgamma, dbeta, dx, rps, chunks);
     SPNET_RETURN_LAUNCH_STATUS();
   }
   hipLaunchKernelGGL(bn_bwd_finalize_kernel<0>, dim3((C + BN_FIN_CH - 1) / BN_FIN_CH), dim3(256), 0, st, partial, P,
