@@ -96,6 +96,35 @@ def test_gemm_wgrad_form(L, M, N, K, tile):
     close(c, X.astype(np.float64).T @ dY.astype(np.float64), rtol=2e-5, atol=3e-5 * np.sqrt(K))
 
 
+@pytest.mark.parametrize("tile", [2, 3, 4, 5, 6, 7, 8])
+@pytest.mark.parametrize("split", [1, 2])
+@pytest.mark.parametrize("form", ["fwd", "dgrad", "wgrad"])
+def test_gemm_long_k_takes_the_pipelined_main_loop(L, form, tile, split):
+    """From 32 K tiles per workgroup the launcher picks the explicitly software-pipelined main loop (gemm.hip, PIPE):
+    all three operand forms with ragged M / N / K, unsplit and with a K split whose last slice is short."""
+    rs = np.random.RandomState(tile + 10 * split)
+    ws = torch.empty(WS, device="cuda")
+    if form == "fwd":          # A[M,K] K-major, B[K,N]
+        M, N, K = 100, 72, 4100
+        A, B = rs.randn(M, K).astype(np.float32), rs.randn(K, N).astype(np.float32)
+        a, b, args = dev(A), dev(B), (0, K, 1, N)
+        want = A.astype(np.float64) @ B.astype(np.float64)
+    elif form == "dgrad":      # B[N,K] K-major
+        M, N, K = 200, 68, 2180
+        A, B = rs.randn(M, K).astype(np.float32), rs.randn(N, K).astype(np.float32)
+        a, b, args = dev(A), dev(B), (0, K, 0, K)
+        want = A.astype(np.float64) @ B.astype(np.float64).T
+    else:                      # A[K,M] out-major, K not a multiple of 4
+        M, N, K = 72, 136, 5001
+        A, B = rs.randn(K, M).astype(np.float32), rs.randn(K, N).astype(np.float32)
+        a, b, args = dev(A), dev(B), (1, M, 1, N)
+        want = A.astype(np.float64).T @ B.astype(np.float64)
+    c = torch.full((M, N), float("nan"), device="cuda")
+    L.spnet_gemm_f32(a.data_ptr(), args[0], args[1], b.data_ptr(), args[2], args[3], c.data_ptr(), N, M, N, K, split,
+                     ws.data_ptr(), WS, None, tile, st())
+    close(c, want, rtol=2e-5, atol=3e-5 * np.sqrt(K))
+
+
 @pytest.mark.parametrize("tile", [0, 3, 5, 6])
 def test_gemm_batched_wgrad_form(L, tile):
     """Several weight-gradient problems of one shape in one launch == the same problems one by one."""
