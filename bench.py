@@ -447,6 +447,9 @@ def main():
             note = ("HIP events around every launch of the family during %d extra steps replayed on one stream "
                     "(weight-gradient overlap off) right after the timed region" % args.steps)
             roof_gemm["measured"] = roof_dw["measured"] = note
+            roof_gemm["clock_note"] = ("peak = 157.3 TFLOP/s at the 2.4 GHz maximum clock; inside this family's main loop the chip "
+                                       "holds 2.04-2.12 GHz on real operands (2.30-2.41 GHz on zeros), measured with in-kernel "
+                                       "s_memtime / s_memrealtime stamps: profiles/r02_c_diag_gemm_phases.txt, DESIGN.md section 3")
             roof_gemm["traffic_source"] = roof_dw["traffic_source"] = tr_note
             result["roofline"] = roof_gemm if g_ms >= d_ms else roof_dw
             result["roofline_secondary"] = roof_dw if g_ms >= d_ms else roof_gemm
