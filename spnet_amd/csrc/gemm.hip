@@ -24,6 +24,10 @@
 #ifndef SP_PIPE
 #define SP_PIPE 1        // 0: the compiler-scheduled main loop everywhere (A/B measurements)
 #endif
+#ifndef SP_SPLIT_BELOW_TILES
+#define SP_SPLIT_BELOW_TILES 256
+#define SP_SPLIT_MIN_K 2048
+#endif
 #ifndef SP_PIPE_MIN_TILES
 #define SP_PIPE_MIN_TILES 32
 #endif
@@ -480,9 +484,16 @@ static void tile_dims(int tile, int* bm, int* bn) {
   }
 }
 
-// Automatic K split of one tile shape: enough workgroups for ~2 per CU, slices at least 4 K-tiles deep.
-static int auto_split(long tiles, int M, int N, int K, bool have_ws, long ws_floats) {
-  if (tiles >= 512 || !have_ws) return 1;
+// Automatic K split of one tile shape: enough workgroups for ~2 per CU, slices at least 4 K-tiles deep -- but only
+// while the unsplit launch leaves CUs empty: from one workgroup per CU on, the slabs and their reduce launch cost more
+// than the second workgroup buys (exit-flow shapes, tile / split sweep: 1536x1024x728 32.8 -> 26.7 us, 1536x1536x1024
+// 51.5 -> 43.9, 1536x1536x2048 in the data-gradient form 87.8 -> 74.4), and not below 64 K tiles, where even a launch
+// that fills three quarters of the CUs beats its split form (1536x728x1024, data-gradient form: 35.9 -> 29.3 us).
+// (weight-gradient form: few output tiles and a long pixel axis by nature; the original rule -- split below two
+// workgroups per CU -- measures better there: 1024x1536x1536 53.2 vs 56.7 us)
+static int auto_split(long tiles, int M, int N, int K, bool have_ws, long ws_floats, int form) {
+  if (!have_ws) return 1;
+  if (form == 2 ? tiles >= 512 : (tiles >= SP_SPLIT_BELOW_TILES || K < SP_SPLIT_MIN_K)) return 1;
   long want = (512 + tiles - 1) / tiles;
   long maxk = K / (SP_BK * 4);
   if (maxk < 1) maxk = 1;
@@ -509,7 +520,7 @@ static int pick_tile(int form, int M, int N, int K, int split_k, bool have_ws, l
     int bm, bn;
     tile_dims(cand[c], &bm, &bn);
     const long tiles = (long)spnet_cdiv(M, bm) * spnet_cdiv(N, bn);
-    int ns = split_k > 0 ? split_k : auto_split(tiles, M, N, K, have_ws, ws_floats);
+    int ns = split_k > 0 ? split_k : auto_split(tiles, M, N, K, have_ws, ws_floats, form);
     const int kc = spnet_cdiv(spnet_cdiv(K, ns), SP_BK) * SP_BK;
     ns = spnet_cdiv(K, kc);
     const double rounds = (double)((tiles * ns * nbatch + 255) / 256) / nbatch;
@@ -554,7 +565,7 @@ static int gemm_impl(const float* A, int a_major, int lda, const float* B, int b
   const long tiles = (long)spnet_cdiv(M, bm) * spnet_cdiv(N, bn);
   const int BK = SP_BK;
   int nsplit = split_k;
-  if (nsplit <= 0) nsplit = auto_split(tiles, M, N, K, workspace != nullptr, ws_floats);
+  if (nsplit <= 0) nsplit = auto_split(tiles, M, N, K, workspace != nullptr, ws_floats, form);
   const int bkt = BK;
   int k_chunk = ((K + nsplit - 1) / nsplit + bkt - 1) / bkt * bkt;
   nsplit = (K + k_chunk - 1) / k_chunk;
