@@ -329,15 +329,26 @@ def main():
     side_stream = eng.wgrad_stream
     if args.no_overlap:
         eng.wgrad_stream = None
+    trace = os.environ.get("SPNET_BENCH_TRACE") == "1"      # dev: per-step GPU / host times of the timed region
+    evs, hts = [], []
     for _ in range(args.warmup):
         step()
     fence()
     t0 = time.perf_counter()
+    if trace:
+        evs.append(torch.cuda.Event(enable_timing=True)); evs[-1].record()
     for _ in range(args.steps):
+        th = time.perf_counter()
         out = step()
+        if trace:
+            evs.append(torch.cuda.Event(enable_timing=True)); evs[-1].record()
+            hts.append(1e3 * (time.perf_counter() - th))
     t_host = time.perf_counter() - t0          # host time to ENQUEUE the K steps (launches are asynchronous)
     fence()
     dt = time.perf_counter() - t0
+    if trace and rank == 0:
+        sys.stderr.write("trace: wall %.2f ms; GPU ms per step: %s\n" % (1e3 * dt, " ".join("%.2f" % evs[i].elapsed_time(evs[i + 1]) for i in range(args.steps))))
+        sys.stderr.write("trace: host ms per step: %s\n" % " ".join("%.1f" % v for v in hts))
     loss = float(out[5])
 
     # Host cost of enqueueing ONE step into an idle GPU (the figure above is taken under queue back-pressure: the

@@ -125,10 +125,18 @@ class AsyncUploader:
     step -- so the host could never run ahead and the GPU idled ~0.4 ms at every step boundary.  Per-step
     parameters therefore go through a small ring of pinned staging buffers (one ring per key / shape) and
     asynchronous copies into matching device buffers; a slot is reused only after its own copy has completed
-    (event), and stream order protects the device buffer from being overwritten while kernels still read it."""
+    (event), and stream order protects the device buffer from being overwritten while kernels still read it.
 
-    def __init__(self, device, depth=4):
-        self.device, self.depth = device, depth
+    The ring depth also bounds how far the host runs AHEAD of the GPU (a key is uploaded once per step, and the host
+    waits for the copy of `depth` steps ago before it stages the next one).  Default 1: one step of lead hides the
+    host's 4-5 ms of enqueue work per 12.5 ms step completely, and the GPU itself runs faster that way -- with three
+    or more steps queued behind the running one a train step takes 13.4-13.6 ms instead of 12.45 (bench.py
+    SPNET_BENCH_TRACE per-step trace at depth 1 / 2 / 3 / 4 / 8: 12.73 / 12.83 / 12.85 / 12.95 / 12.98 ms per step
+    over the first ten steps after a fence; the slow steps are exactly those during which the host is not blocked)."""
+
+    def __init__(self, device, depth=None):
+        self.device = device
+        self.depth = int(os.environ.get("SPNET_UPLOAD_DEPTH", "1")) if depth is None else depth
         self.rings, self.count = {}, {}
 
     def __call__(self, key, array):
