@@ -79,6 +79,9 @@ int spnet_scatter_add_s2(const float* dxs, float* dx, int B, int H, int W, int C
 /* ---- depthwise 3x3 / SAME (34 stride-1 layers per Xception forward: keras SeparableConv2D depthwise step;
  *      MobileNet's DepthwiseConv2D, stride 1 | 2).  w is [3][3][C]. ---- */
 int spnet_reduce_rows(const float* in, int P, int L, float* out, void* stream);
+/* ... with 32*L floats of scratch: many rows (a Conv2D bias gradient: keras InceptionResNetV2's block convs,
+ * spnet/models.py:357-359) are folded in 32 parallel slices first. */
+int spnet_reduce_rows_ws(const float* in, int P, int L, float* out, float* scratch, long scratch_floats, void* stream);
 /* njobs independent row reductions in one launch; jobs: DEVICE array of {in, out, P, L} (four 64-bit words
  * per job), max_L = largest L.  (All depthwise weight gradients of a step: spnet_dwconv3x3_tiled_bwd with
  * dw == NULL leaves its partial sums in the workspace.) */

@@ -37,6 +37,7 @@ _SIGS = {
     "spnet_dwconv3x3_strided_ws": (c_long, [c_int, c_int, c_int, c_int, c_int]),
     "spnet_dwconv3x3_strided": (c_int, [c_int, P, P, P, c_int, c_int, c_int, c_int, c_int, P, P]),
     "spnet_reduce_rows": (c_int, [P, c_int, c_int, P, P]),
+    "spnet_reduce_rows_ws": (c_int, [P, c_int, c_int, P, P, c_long, P]),
     "spnet_reduce_rows_batched": (c_int, [P, c_int, c_int, P]),
     "spnet_dwconv3x3_tiled_fwd": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, P, P, P]),
     "spnet_dwconv3x3_tiled_fwd_bnfin": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, P, c_int, c_long, P, P, P, P, P, P, P,

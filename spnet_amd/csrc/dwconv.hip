@@ -546,6 +546,15 @@ extern "C" int spnet_reduce_rows(const float* in, int P, int L, float* out, void
   SPNET_RETURN_LAUNCH_STATUS();
 }
 
+// The same with 32*L floats of scratch: from 129 rows on, 32 row slices are folded side by side first (a bias gradient
+// over tens of thousands of pixels otherwise runs on L/16 workgroups only).
+extern "C" int spnet_reduce_rows_ws(const float* in, int P, int L, float* out, float* scratch, long scratch_floats,
+                                    void* stream) {
+  if (scratch && scratch_floats < 32L * L) return (int)hipErrorInvalidValue;
+  launch_reduce_rows(in, P, L, out, scratch, (hipStream_t)stream);
+  SPNET_RETURN_LAUNCH_STATUS();
+}
+
 // ---------------------------------------------------------------- strided entry points
 static void same_pad(int in, int s, int* out, int* before) {
   *out = (in + s - 1) / s;

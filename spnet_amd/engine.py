@@ -1662,7 +1662,7 @@ class _IRConv:
     def bwd(self, net):
         e, C, g = self.e, self.cout, self.out.g
         if self.bias:
-            L.spnet_reduce_rows(L.ptr(g), self.M, C, L.ptr(self.gb), _stream())
+            L.spnet_reduce_rows_ws(L.ptr(g), self.M, C, L.ptr(self.gb), e.ws_ptr(WS_MISC), WS_MISC[1], _stream())
         else:       # BatchNorm (+ReLU) backward in place on the accumulated gradient; gamma is the constant 1
             L.spnet_bn_bwd(L.ptr(self.yp), L.ptr(g), self.M, C, L.ptr(self.ones), L.ptr(self.beta), L.ptr(self.save),
                            self.save[C:].data_ptr(), ACT_RELU if self.relu else ACT_NONE, L.ptr(g), L.ptr(self.gscr),

@@ -148,6 +148,19 @@ def test_gemm_batched_wgrad_form(L, tile):
             assert torch.equal(one, Cs[b])           # same tile, same k order -> same bits
 
 
+def test_reduce_rows_with_scratch(L):
+    """spnet_reduce_rows_ws: many rows folded through 32 parallel slices (a bias gradient over all pixels)."""
+    rs = np.random.RandomState(5)
+    for P, Lr in ((26320, 1088), (129, 20), (64, 320)):
+        x = dev(rs.randn(P, Lr))
+        out = torch.full((Lr,), float("nan"), device="cuda")
+        scratch = torch.empty(32 * Lr, device="cuda")
+        L.spnet_reduce_rows_ws(x.data_ptr(), P, Lr, out.data_ptr(), scratch.data_ptr(), scratch.numel(), st())
+        close(out, x.cpu().double().numpy().sum(0), rtol=1e-5, atol=1e-5 * np.sqrt(P) * 4)
+    with pytest.raises(L.HipError):
+        L.spnet_reduce_rows_ws(x.data_ptr(), P, Lr, out.data_ptr(), scratch.data_ptr(), 10, st())
+
+
 def test_reduce_rows_batched(L):
     """Several [P][L] -> [L] reductions in one launch, same bits as one spnet_reduce_rows call each."""
     rs = np.random.RandomState(4)
