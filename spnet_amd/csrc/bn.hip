@@ -478,10 +478,11 @@ __global__ __launch_bounds__(256) void bn_fwd_fused_vec_kernel(
 // g already carries any mask).
 __global__ __launch_bounds__(256) void bn_bwd_fused_vec_kernel(
     const float* __restrict__ x, const float* __restrict__ dy, long M, int C, const float* __restrict__ partial, int P,
-    const float* __restrict__ gamma, const float* __restrict__ mean, const float* __restrict__ invstd,
-    float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ dx, int rows_per_slab, int chunks) {
+    const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ mean,
+    const float* __restrict__ invstd, int act, float* __restrict__ dgamma, float* __restrict__ dbeta,
+    float* __restrict__ dx, int rows_per_slab, int chunks) {
   __shared__ double dred[2 * 16 * BN_FUSE_CH];
-  __shared__ __attribute__((aligned(16))) float cf[5][BN_FUSE_CH];   // k1, k2, k3, mean, invstd
+  __shared__ __attribute__((aligned(16))) float cf[7][BN_FUSE_CH];   // k1, k2, k3, mean, invstd, gamma, beta
   const int wid = xcd_remap(blockIdx.x, gridDim.x);                  // XCD-aware order (see the forward kernel)
   const int bx = wid % chunks, by = wid / chunks;
   const int c0 = bx * BN_FUSE_CH;
@@ -509,6 +510,8 @@ __global__ __launch_bounds__(256) void bn_bwd_fused_vec_kernel(
     cf[2][threadIdx.x] = (float)d;
     cf[3][threadIdx.x] = mean[cc];
     cf[4][threadIdx.x] = invstd[cc];
+    cf[5][threadIdx.x] = gamma[cc];
+    cf[6][threadIdx.x] = act ? beta[cc] : 0.f;
     if (by == 0) {
       dbeta[cc] = (float)sg;
       dgamma[cc] = (float)sgx;
@@ -521,10 +524,18 @@ __global__ __launch_bounds__(256) void bn_bwd_fused_vec_kernel(
   const float4 k3 = *reinterpret_cast<const float4*>(&cf[2][lane * 4]);
   const float4 mu = *reinterpret_cast<const float4*>(&cf[3][lane * 4]);
   const float4 is = *reinterpret_cast<const float4*>(&cf[4][lane * 4]);
-  auto emit = [&](long r, const float4 v, const float4 g) {
+  const float4 ga = *reinterpret_cast<const float4*>(&cf[5][lane * 4]);
+  const float4 be = *reinterpret_cast<const float4*>(&cf[6][lane * 4]);
+  auto emit = [&](long r, const float4 v, float4 g) {
     float4 xh, o;
     xh.x = (v.x - mu.x) * is.x; xh.y = (v.y - mu.y) * is.y;
     xh.z = (v.z - mu.z) * is.z; xh.w = (v.w - mu.w) * is.w;
+    if (act) {          // an activation behind the BatchNorm: its mask, exactly as bn_bwd_apply_vec_kernel forms it
+      g.x *= act_grad(fmaf(xh.x, ga.x, be.x), act);
+      g.y *= act_grad(fmaf(xh.y, ga.y, be.y), act);
+      g.z *= act_grad(fmaf(xh.z, ga.z, be.z), act);
+      g.w *= act_grad(fmaf(xh.w, ga.w, be.w), act);
+    }
     o.x = fmaf(k1.x, g.x, fmaf(k2.x, xh.x, k3.x));
     o.y = fmaf(k1.y, g.y, fmaf(k2.y, xh.y, k3.y));
     o.z = fmaf(k1.z, g.z, fmaf(k2.z, xh.z, k3.z));
@@ -661,6 +672,14 @@ extern "C" int spnet_bn_bwd(const float* x, const float* dy, long M, int C, cons
   if ((C & 3) && C > 4) return (int)hipErrorInvalidValue;
   const int parts = bn_parts(M, C);
   launch_partial<1>(x, dy, M, C, save_mean, save_invstd, gamma, beta, act, workspace, parts, st);
+  if (!(C & 3) && parts <= BN_FUSE_MAX_P) {      // few partial rows: finalize folded into the apply pass (same results)
+    const int rps = bn_fuse_rows_per_slab(M, C);
+    const int chunks = (C + BN_FUSE_CH - 1) / BN_FUSE_CH;
+    dim3 grid((unsigned)(chunks * ((M + rps - 1) / rps)));
+    hipLaunchKernelGGL(bn_bwd_fused_vec_kernel, grid, dim3(256), 0, st, x, dy, M, C, workspace, parts, gamma, beta,
+                       save_mean, save_invstd, act, dgamma, dbeta, dx, rps, chunks);
+    SPNET_RETURN_LAUNCH_STATUS();
+  }
   hipLaunchKernelGGL(bn_bwd_finalize_kernel<0>, dim3((C + BN_FIN_CH - 1) / BN_FIN_CH), dim3(256), 0, st, workspace, parts,
                      C, M, gamma, save_invstd, save_mean, dgamma, dbeta, coeffs, coeffs + C, coeffs + 2 * C);
   if (C & 3) {
@@ -745,8 +764,8 @@ extern "C" int spnet_bn_bwd_from_partials(const float* x, const float* dy, long 
     const int rps = bn_fuse_rows_per_slab(M, C);
     const int chunks = (C + BN_FUSE_CH - 1) / BN_FUSE_CH;
     dim3 grid((unsigned)(chunks * ((M + rps - 1) / rps)));
-    hipLaunchKernelGGL(bn_bwd_fused_vec_kernel, grid, dim3(256), 0, st, x, dy, M, C, partial, P, gamma, save_mean,
-                       save_invstd, dgamma, dbeta, dx, rps, chunks);
+    hipLaunchKernelGGL(bn_bwd_fused_vec_kernel, grid, dim3(256), 0, st, x, dy, M, C, partial, P, gamma, beta, save_mean,
+                       save_invstd, 0, dgamma, dbeta, dx, rps, chunks);
     SPNET_RETURN_LAUNCH_STATUS();
   }
   hipLaunchKernelGGL(bn_bwd_finalize_kernel<0>, dim3((C + BN_FIN_CH - 1) / BN_FIN_CH), dim3(256), 0, st, partial, P,
