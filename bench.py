@@ -305,7 +305,6 @@ def main():
 
     eng = Engine(H, W, BATCH, device=str(dev), seed=0, rank=rank)
     aug = DeviceAugmenter(X_pool)
-    upload = L.AsyncUploader(dev)
     reducer = eng.make_reducer() if world > 1 else None
     # 1-cycle table of the reference's own run configuration (lr_max 4e-5, 40k frames, 100 epochs)
     lrs = get_1cycle_schedule(lr_max=4e-5, n_data_points=40000, epochs=100, batch_size=BATCH * world)
@@ -325,7 +324,7 @@ def main():
         i = it[0]
         it[0] += 1
         aug.apply(drawn[0], eng.x_in)
-        torch.index_select(Y_pool, 0, upload("idx", batch_indices(i)), out=eng.y_true)
+        torch.index_select(Y_pool, 0, aug.index_dev, out=eng.y_true)      # the indices travelled with the parameters
         out = eng.train_step(None, None, float(lrs[i % len(lrs)]), reducer=reducer)
         drawn[0] = aug.draw(batch_indices(i + 1))
         return out
