@@ -48,7 +48,8 @@
 // to a buffer nothing else reads.  [workgroup][8]: entry, first tile in LDS, main loop done, statistics done, stores drained.
 __device__ unsigned long long sp_stamps[16384 * 8];
 #define SP_STAMP(i) do { if (tid == 0 && gwg < 16384) { sp_stamps[gwg * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); \
-  if ((i) == 1 || (i) == 2) sp_stamps[gwg * 8 + 4 + (i)] = __builtin_amdgcn_s_memtime(); } } while (0)
+  if ((i) == 1 || (i) == 2) sp_stamps[gwg * 8 + 4 + (i)] = __builtin_amdgcn_s_memtime(); \
+  if ((i) == 0) { unsigned xcc; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc)); sp_stamps[gwg * 8 + 7] = xcc; } } } while (0)
 extern "C" int spnet_debug_read_stamps(unsigned long long* host, int n) {
   return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(sp_stamps), sizeof(unsigned long long) * n, 0, hipMemcpyDeviceToHost);
 }
