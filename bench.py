@@ -47,7 +47,8 @@ def kernel_source_hash():
     h = hashlib.sha256()
     files = sorted(glob.glob(os.path.join(ROOT, "spnet_amd", "csrc", "*.hip")) +
                    glob.glob(os.path.join(ROOT, "spnet_amd", "csrc", "*.h")) +
-                   [os.path.join(ROOT, "spnet_amd", "engine.py"), os.path.join(ROOT, "include", "spnet_hip.h")])
+                   [os.path.join(ROOT, "spnet_amd", "engine.py"), os.path.join(ROOT, "spnet_amd", "gemm_tiles.json"),
+                    os.path.join(ROOT, "include", "spnet_hip.h")])
     for f in files:
         h.update(os.path.basename(f).encode())
         h.update(open(f, "rb").read())
