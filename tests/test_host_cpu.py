@@ -244,3 +244,28 @@ def test_prediction_csv_matches_reference_writer(golden, tmp_path):
                          out_csv=out_csv, show_true=False)
     assert open(out_csv).read() == str(golden["csv_text"])
     assert all((tmp_path / ("steelpan_pred_%05d.png" % j)).exists() for j in range(len(files)))
+
+
+def test_gemm_tile_table_precedence_and_format():
+    """spnet_amd/gemm_tiles.json (tools/autotune_gemm.py): keys parse to (a_major, b_major, stats, M, N, K), tile ids are
+    ones the library knows, and an explicit tile beats a probe beats the table beats the library's own choice (0)."""
+    import json
+    import os
+    from spnet_amd import engine as E
+    path = os.path.join(os.path.dirname(E.__file__), "gemm_tiles.json")
+    with open(path) as f:
+        tiles = json.load(f)["tiles"]
+    for k, t in tiles.items():
+        parts = [int(v) for v in k.split(",")]
+        assert len(parts) == 6 and parts[0] in (0, 1) and parts[1] in (0, 1) and parts[2] in (0, 1)
+        assert 1 <= int(t) <= 8
+        assert E.TILE_TABLE[tuple(parts)] == int(t)
+    key = next(iter(E.TILE_TABLE)) if E.TILE_TABLE else (0, 1, 0, 7, 7, 7)
+    assert E._tile_for(*key, 5) == 5                                    # explicit
+    E.TILE_PROBE[key] = 3
+    try:
+        assert E._tile_for(*key, 0) == 3                                # probe (the autotuner's override)
+    finally:
+        E.TILE_PROBE.clear()
+    assert E._tile_for(*key, 0) == E.TILE_TABLE.get(key, 0)             # table
+    assert E._tile_for(0, 1, 0, 12345, 4, 8, 0) == 0                    # unlisted shape: the library's cost model
