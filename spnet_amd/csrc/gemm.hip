@@ -45,7 +45,8 @@
 // flow's 768-workgroup launches are exactly one resident wave of 3 per CU)
 #ifdef SP_STAMPS
 // Diagnostic build only (tools/gemm_phases.py): per-workgroup 100 MHz real-time stamps of the kernel's phases, written
-// to a buffer nothing else reads.  [workgroup][8]: entry, first tile in LDS, main loop done, statistics done, stores drained.
+// to a buffer nothing else reads.  [workgroup][8]: 0 entry, 1 first tile in LDS, 2 main loop done, 3 epilogue issued, 4 stores
+// drained (real-time ticks); 5, 6 the shader clock counter at stamps 1 and 2; 7 the XCC id the workgroup ran on.
 __device__ unsigned long long sp_stamps[16384 * 8];
 #define SP_STAMP(i) do { if (tid == 0 && gwg < 16384) { sp_stamps[gwg * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); \
   if ((i) == 1 || (i) == 2) sp_stamps[gwg * 8 + 4 + (i)] = __builtin_amdgcn_s_memtime(); \

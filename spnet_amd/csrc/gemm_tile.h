@@ -119,19 +119,6 @@ struct TileStage {
       v[i] = t;
     }
   }
-  // Cache-line prefetch of a whole tile (every 128-byte line touched once, by thread i < NLINES): address of this
-  // thread's line of the tile that starts at reduction step k0 (rows clamped like init()).
-  static constexpr int NLINES = (MAJ == SP_K_MAJOR) ? BR * (BK / 32) : BK * (BR / 32);
-  static __device__ __forceinline__ const float* line_addr(const float* __restrict__ P, int ld, int r0, int R, int k0,
-                                                           int i) {
-    if (MAJ == SP_K_MAJOR) {
-      const int r = i / (BK / 32), seg = i % (BK / 32);
-      return P + (long)min(r0 + r, R - 1) * ld + k0 + seg * 32;
-    } else {
-      const int k = i / (BR / 32), seg = i % (BR / 32);
-      return P + (long)(k0 + k) * ld + min(r0 + seg * 32, R - 4);
-    }
-  }
   static __device__ __forceinline__ long kstep(int ld) { return (MAJ == SP_K_MAJOR) ? (long)BK : (long)BK * ld; }
 
   // Any K tile: elements past kend / past R read as zero.
