@@ -152,6 +152,82 @@ __global__ __launch_bounds__(256) void conv3x3_small_bwd_weight_kernel(const flo
     partial[(long)blockIdx.x * NW + i] = (red[0][i] + red[1][i]) + (red[2][i] + red[3][i]);
 }
 
+// Weight gradient of the 3 -> 3 stem convs (stride 1, SAME) on rows whose width is a multiple of 8: a thread owns RUNS of
+// eight consecutive output pixels.  Per run it fetches dy (24 floats) and, tap row by tap row, the ten input pixels the
+// eight windows of that row touch (six 16-byte loads + the two edge pixels), instead of 27 + 3 scalar loads per pixel;
+// the 81 sums stay in registers across the thread's runs.  Same two-stage deterministic reduction as the generic kernel.
+__global__ __launch_bounds__(256) void conv3x3_c3_bwd_weight_rows_kernel(const float* __restrict__ x,
+                                                                         const float* __restrict__ dy,
+                                                                         float* __restrict__ partial, int Bn, int H,
+                                                                         int W) {
+  constexpr int NW = 81;
+  __shared__ float red[4][NW];
+  float acc[NW];
+#pragma unroll
+  for (int i = 0; i < NW; ++i) acc[i] = 0.f;
+  const int runs_w = W / 8;
+  const long total = (long)Bn * H * runs_w;
+  for (long run = (long)xcd_remap(blockIdx.x, gridDim.x) * blockDim.x + threadIdx.x; run < total;
+       run += (long)gridDim.x * blockDim.x) {
+    const int rw = (int)(run % runs_w);
+    long t = run / runs_w;
+    const int h = (int)(t % H);
+    const int b = (int)(t / H);
+    const int w0 = rw * 8;
+    float g[24];                                   // dy of the eight pixels, [pixel][co]
+    {
+      const float4* gp = reinterpret_cast<const float4*>(dy + (((long)b * H + h) * W + w0) * 3);
+#pragma unroll
+      for (int q = 0; q < 6; ++q) {
+        const float4 v = gp[q];
+        g[4 * q] = v.x; g[4 * q + 1] = v.y; g[4 * q + 2] = v.z; g[4 * q + 3] = v.w;
+      }
+    }
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh) {
+      const int hh = h - 1 + kh;
+      float xr[30];                                // input pixels w0-1 .. w0+8 of row hh, [pixel][ci]; zero outside
+      if (hh >= 0 && hh < H) {
+        const float* row = x + (((long)b * H + hh) * W) * 3;
+        const float4* xp = reinterpret_cast<const float4*>(row + (long)w0 * 3);
+#pragma unroll
+        for (int q = 0; q < 6; ++q) {
+          const float4 v = xp[q];
+          xr[3 + 4 * q] = v.x; xr[3 + 4 * q + 1] = v.y; xr[3 + 4 * q + 2] = v.z; xr[3 + 4 * q + 3] = v.w;
+        }
+#pragma unroll
+        for (int ci = 0; ci < 3; ++ci) {
+          xr[ci] = (w0 > 0) ? row[(long)(w0 - 1) * 3 + ci] : 0.f;
+          xr[27 + ci] = (w0 + 8 < W) ? row[(long)(w0 + 8) * 3 + ci] : 0.f;
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < 30; ++i) xr[i] = 0.f;
+      }
+#pragma unroll
+      for (int px = 0; px < 8; ++px)
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw)
+#pragma unroll
+          for (int ci = 0; ci < 3; ++ci) {
+            const float xv = xr[(px + kw) * 3 + ci];
+#pragma unroll
+            for (int co = 0; co < 3; ++co)
+              acc[((kh * 3 + kw) * 3 + ci) * 3 + co] = fmaf(xv, g[px * 3 + co], acc[((kh * 3 + kw) * 3 + ci) * 3 + co]);
+          }
+    }
+  }
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+  for (int i = 0; i < NW; ++i) {
+    const float s = wave_sum(acc[i]);
+    if (lane == 0) red[wv][i] = s;
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < NW; i += blockDim.x)
+    partial[(long)blockIdx.x * NW + i] = (red[0][i] + red[1][i]) + (red[2][i] + red[3][i]);
+}
+
 // Weight gradient for block1_conv1 (3 -> 32, 864 weights): lanes run over the 32 output channels,
 // 8 lane-groups split the 27 (tap, ci) pairs; each group loops over the workgroup's pixels.
 template <int CIN, int COUT, int STRIDE, int PAD>
@@ -407,7 +483,15 @@ static int conv_small_dispatch(int op, const float* a, const float* b, float* ou
   } else {  // backward weight: a = x, b = dy
     const long total = (long)B * OH * OW;
     int parts;
-    if constexpr (NW <= 81) {
+    if (CIN == 3 && COUT == 3 && STRIDE == 1 && PAD == 1 && (W & 7) == 0) {
+      // runs of eight pixels per thread, about three runs per thread (the 81 wave reductions of the epilogue are a
+      // fixed cost per workgroup)
+      parts = spnet_cdiv(total / 8, 256 * 3);
+      if (parts > 512) parts = 512;
+      if (parts < 1) parts = 1;
+      if ((long)parts * NW > ws_floats) return (int)hipErrorInvalidValue;
+      hipLaunchKernelGGL(conv3x3_c3_bwd_weight_rows_kernel, dim3(parts), dim3(256), 0, st, a, b, workspace, B, H, W);
+    } else if constexpr (NW <= 81) {
       parts = spnet_cdiv(total, 256 * 16);
       if (parts > 512) parts = 512;
       if (parts < 1) parts = 1;

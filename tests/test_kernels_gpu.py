@@ -507,7 +507,10 @@ def test_avgpool(L, C):
 
 
 @pytest.mark.parametrize("cin,cout,stride,same,H,W", [(1, 3, 1, 1, 20, 28), (3, 3, 1, 1, 20, 28), (3, 32, 2, 0, 21, 28),
-                                                      (3, 32, 2, 0, 48, 64), (1, 3, 1, 1, 96, 128)])
+                                                      (3, 32, 2, 0, 48, 64), (1, 3, 1, 1, 96, 128),
+                                                      # widths that are multiples of 8: the 3 -> 3 weight gradient by pixel runs
+                                                      (3, 3, 1, 1, 7, 8), (3, 3, 1, 1, 12, 32), (3, 3, 1, 1, 48, 64),
+                                                      (3, 3, 1, 1, 1, 16)])
 def test_small_conv(L, cin, cout, stride, same, H, W):
     rs = np.random.RandomState(cin * cout + H)
     B = 2
