@@ -98,14 +98,51 @@ def labels_to_Y(label_rows):
     return U.norm_Y(Y).astype(np.float32)
 
 
+def host_cpu_share():
+    """(threads to use, description): the cores this process may really run on -- its affinity mask capped by the
+    cgroup CPU quota.  A 1-GPU box shows 100+ logical CPUs but grants about 16; a thread pool sized by the former
+    slows the oracle several times over and makes the figure box-dependent."""
+    try:
+        aff = len(os.sched_getaffinity(0))
+    except AttributeError:
+        aff = os.cpu_count() or 1
+    quota = None
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    quota = float(txt[0]) / float(txt[1])
+            else:
+                q = float(txt[0])
+                if q > 0:
+                    quota = q / float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    model = "?"
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    n = aff if quota is None else max(1, min(aff, int(quota + 0.5)))
+    n = min(n, int(os.environ.get("SPNET_CPU_BASELINE_THREADS", 32)))
+    return n, dict(affinity_cpus=aff, cgroup_quota_cpus=quota, logical_cpus=os.cpu_count(), cpu_model=model)
+
+
 def cpu_baseline(X_u8, Y, steps, batch):
     """The oracle (torch-CPU restatement of the reference path) timed on this host: numpy
-    augmentation -> forward -> custom_loss + l2 -> backward -> Keras-form Adam."""
+    augmentation -> forward -> custom_loss + l2 -> backward -> Keras-form Adam.  Median of `steps` steps after
+    one warm-up step, on the cores this process is really granted (host_cpu_share)."""
     import torch
     from oracle import numpy_ref as R
     from oracle import torch_ref as T
     from spnet_amd import fake_espi as F
-    cores = torch.get_num_threads()
+    cores, share = host_cpu_share()
+    torch.set_num_threads(cores)
     P = T.init_params(H, W, seed=0)
     tr = T.Trainer(P)
     lrs = R.one_cycle_table(4e-5, 40000, 100, batch)
@@ -119,13 +156,17 @@ def cpu_baseline(X_u8, Y, steps, batch):
         tr.step(torch.from_numpy(xb), torch.from_numpy(Y[idx]), float(lrs[i]))
 
     one(0)                                   # warm-up (allocator, thread pool)
-    t0 = time.perf_counter()
+    ts = []
     for i in range(1, steps + 1):
+        t0 = time.perf_counter()
         one(i)
-    dt = time.perf_counter() - t0
-    return dict(value=round(batch * steps / dt, 3), unit="images/sec", cores=cores, kind="port",
-                sample="%d train steps of batch %d at %dx%d (after 1 warm-up step), oracle/torch_ref.py + "
-                       "oracle/numpy_ref.py on %d threads, %.1f s" % (steps, batch, W, H, cores, dt))
+        ts.append(time.perf_counter() - t0)
+    med = float(np.median(ts))
+    return dict(value=round(batch / med, 3), unit="images/sec", cores=cores, kind="port",
+                sample="median of %d train steps of batch %d at %dx%d (after 1 warm-up step), oracle/torch_ref.py + "
+                       "oracle/numpy_ref.py on %d threads, %.1f s in all; per-step s: %s" %
+                       (steps, batch, W, H, cores, sum(ts), " ".join("%.2f" % t for t in ts)),
+                host=share)
 
 
 def secondary(args):
@@ -240,6 +281,36 @@ def predict_bench(args):
     }), flush=True)
 
 
+def rccl_version():
+    try:
+        import torch
+        return ".".join(str(v) for v in torch.cuda.nccl.version())
+    except Exception as e:      # noqa: BLE001  (diagnostic field only)
+        return "unknown (%s)" % type(e).__name__
+
+
+def self_launch(n):
+    """`python bench.py --gpus N` without a launcher: start the N ranks ourselves, the way the driver does
+    (`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ...`), as a CHILD process
+    -- this parent has not imported torch.cuda or touched the GPU, and never exec()s -- relay its output (rank 0
+    prints the one JSON line) and exit with its return code (reference capability: spnet/multi_gpu.py:35-88,
+    train_spnet.py:55)."""
+    import socket
+    import subprocess
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // n)))
+    rc = subprocess.run(cmd, env=env).returncode
+    if rc != 0:
+        sys.stderr.write("bench.py: the %d-rank child job failed with exit code %d\n" % (n, rc))
+    raise SystemExit(rc)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -253,7 +324,7 @@ def main():
     ap.add_argument("--sustained-seconds", type=float, default=6.0,
                     help="after the timed region keep stepping for this long and report the rate separately "
                          "(clocks under sustained load); 0 = skip")
-    ap.add_argument("--cpu-baseline-steps", type=int, default=2)
+    ap.add_argument("--cpu-baseline-steps", type=int, default=5)
     ap.add_argument("--cpu-baseline-batch", type=int, default=8)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timers", action="store_true")
@@ -264,9 +335,15 @@ def main():
     ap.add_argument("--batch", type=int, default=BATCH)
     ap.add_argument("--backbone", default="Xception", choices=["Xception", "MobileNet", "InceptionResNetV2"],
                     help="secondary measurements only (the headline metric is Xception)")
+    ap.add_argument("--launch-check", action="store_true",
+                    help="only start the ranks, join the process group, count them with one all-reduce and print that "
+                         "(no kernels: runs on a CPU-only host over gloo; tests/test_host_cpu.py)")
     ap.add_argument("--no-overlap", action="store_true",
                     help="run the weight-gradient GEMMs on the main stream (the roofline leg always does)")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return self_launch(args.gpus)
 
     import torch
     import torch.distributed as dist
@@ -277,6 +354,22 @@ def main():
     from spnet_amd.engine import Engine, KernelTimer
     from spnet_amd import _lib as L
 
+    if args.launch_check:
+        rank, local_rank, world = parallel.init_distributed()
+        if world != args.gpus:
+            raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+        seen = 1
+        if world > 1:
+            ones = torch.ones(1, device=parallel.local_device() if dist.get_backend() == "nccl" else "cpu")
+            dist.all_reduce(ones)
+            seen = int(round(float(ones.item())))
+        if rank == 0:
+            print(json.dumps({"launch_check": True, "n_gpus": world, "n_ranks_seen": seen,
+                              "collective_backend": dist.get_backend() if world > 1 else None}), flush=True)
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
     if args.mode == "predict" and (args.height, args.width) == (H, W) and args.batch in (BATCH, 128) \
             and args.backbone == "Xception":
         return predict_bench(args)
@@ -288,9 +381,14 @@ def main():
     if world != args.gpus:
         raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, world))
     t_gen = time.perf_counter()
-    n_host = args.pool if args.pool_source == "host" else 64      # host frames: the whole pool, or the CPU baseline's sample
-    X_u8, labels = F.generate(n_host, seed=1 + rank, workers=max(2, min(16, (os.cpu_count() or 8) // world)))
-    Y_host = labels_to_Y(labels)
+    # host frames: the whole pool, the CPU baseline's sample, or none at all (generate() forks only while no HIP
+    # context can exist in this process -- not under a profiler's preloaded runtime, fake_espi.gpu_may_be_live)
+    need_cpu = world == 1 and not args.no_cpu_baseline
+    n_host = args.pool if args.pool_source == "host" else (64 if need_cpu else 0)
+    X_u8 = Y_host = None
+    if n_host:
+        X_u8, labels = F.generate(n_host, seed=1 + rank, workers=max(2, min(16, (os.cpu_count() or 8) // world)))
+        Y_host = labels_to_Y(labels)
     rank, local_rank, world = parallel.init_distributed()
     dev = parallel.local_device()                  # (>1 rank per GPU only in gloo rehearsals)
     torch.cuda.set_device(dev)
@@ -372,10 +470,15 @@ def main():
     fence()
     t_host_idle = min(t_idle)
 
+    n_ranks_seen, backend = 1, None
     if world > 1:                # every rank must agree on the timed region before anything is derived from it
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+        ones = torch.ones(1, dtype=torch.float32, device=dev)
+        dist.all_reduce(ones)                    # how many ranks really took part in the collectives
+        n_ranks_seen = int(round(float(ones.item())))
+        backend = dist.get_backend()
 
     # Sustained leg: the same step for several seconds (reported separately; `value` stays the K timed steps).  The
     # step COUNT is fixed from the timed region's rate, identically on every rank (a time-based exit would let ranks
@@ -422,7 +525,9 @@ def main():
             "config": {"workload": "configs[1]: Xception, fake-ESPI 512x384 (HxW 384x512x1, model_type 'big'), "
                                    "batch 32 per GPU, full train step (augment+fwd+custom_loss+bwd+Adam+l2)",
                        "global_batch": BATCH * world, "frame_hw": [H, W], "pool_frames_per_gpu": args.pool,
-                       "parallelism": "dp%d" % world, "final_loss": round(loss, 6),
+                       "parallelism": "dp%d" % world, "n_ranks_seen": n_ranks_seen,
+                       "collective_backend": backend, "rccl_version": rccl_version() if backend == "nccl" else None,
+                       "devices_visible": torch.cuda.device_count(), "final_loss": round(loss, 6),
                        "wgrad_overlap": not args.no_overlap,
                        "host_enqueue_ms_per_step_backpressured": round(1e3 * t_host / args.steps, 3),
                        "host_enqueue_ms_per_step_gpu_idle": round(1e3 * t_host_idle, 3),

@@ -100,6 +100,7 @@ class Decisions:
         self.relu = list(relu) if relu is not None else []
         self.pool = list(pool) if pool is not None else []
         self._ri = self._pi = 0
+        self.n_decisions = 0     # elements / windows decided so far in force mode (the denominator of the override rate)
         self.flips = []          # (site, n_overridden, largest |x| (or window gap) among them / largest |x| of the tensor)
 
     def act(self, x, slope):
@@ -108,6 +109,7 @@ class Decisions:
             return F.leaky_relu(x, slope) if slope else F.relu(x)
         m = self.relu[self._ri].to(x.device)
         self._ri += 1
+        self.n_decisions += m.numel()
         diff = m != (x > 0)
         n = int(diff.sum())
         if n:
@@ -122,6 +124,7 @@ class Decisions:
             return torch.clamp(x, 0.0, 6.0)
         m = self.relu[self._ri].to(x.device)
         self._ri += 1
+        self.n_decisions += m.numel()
         diff = m != own
         n = int(diff.sum())
         if n:
@@ -137,6 +140,7 @@ class Decisions:
             return own
         t = self.pool[self._pi].to(cols.device)
         self._pi += 1
+        self.n_decisions += t.numel()
         diff = t != own
         n = int(diff.sum())
         if n:

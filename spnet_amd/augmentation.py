@@ -94,8 +94,9 @@ class DeviceAugmenter:
 
     def draw(self, indices, seeds=None):
         """Host-side parameter draw for the given frame indices, reference RNG order per frame.  seeds (optional,
-        one per frame): re-seed numpy's and python's global RNGs before each frame's draws (data parallel: a
-        sample's augmentation then depends on its own seed only, not on what was drawn before it)."""
+        one per frame): each frame's draws come from numpy / python streams seeded with its own seed (data parallel:
+        a sample's augmentation then depends on its seed only, not on what was drawn before it); the process-wide
+        RNG states are saved and restored around the draw, so later consumers of np.random / random are unaffected."""
         B = len(indices)
         npts = self.n_salt + self.n_pepper
         rects = np.zeros((B, MAX_RECTS, 4), np.int32)
@@ -104,6 +105,15 @@ class DeviceAugmenter:
         coords = np.zeros((B, 2, npts), np.int32)
         flag = np.zeros(B, np.int32)
         ksize = np.zeros(B, np.int32)
+        saved = (np.random.get_state(), random.getstate()) if seeds is not None else None
+        try:
+            return self._draw(indices, seeds, rects, vals, nrect, coords, flag, ksize)
+        finally:
+            if saved is not None:       # the per-sample streams must not leak into the process-wide RNGs
+                np.random.set_state(saved[0])
+                random.setstate(saved[1])
+
+    def _draw(self, indices, seeds, rects, vals, nrect, coords, flag, ksize):
         for j, i in enumerate(indices):
             if seeds is not None:
                 np.random.seed(int(seeds[j]))

@@ -106,7 +106,7 @@ class AugmentOnTheFly(Callback):
         parallel.init_distributed()          # this rank's GPU (no-op if the model already did it)
         dev = parallel.local_device()
         self.X_orig = X if isinstance(X, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(X)).to(dev)
-        self.X_aug = torch.empty_like(self.X_orig)
+        self.X_aug = self.X_orig.clone()      # rows no epoch has augmented yet hold the pristine frame, not garbage
         self.augmenter = DeviceAugmenter(self.X_orig, real_blur=real_blur)
 
     def set_model(self, model):

@@ -798,6 +798,13 @@ class Engine:
                 self._graph = g
             if self._graph is not None:
                 self._graph.replay()
+                # the host bookkeeping _step_body does outside the launches: weights, moving statistics and the
+                # transposed copies changed (the replay refreshed the latter itself), and this plan's BatchNorm
+                # scale|shift hold batch statistics again -- predict_step must rebuild its coefficients
+                self._wver[0] += 2
+                self._coeff_ver = -1
+                self._tver[0] += 1
+                self._wT_ver[0] = self._tver[0]
                 return self.loss_out
             self._graph_warm += 1
         self._step_body(reducer, None)

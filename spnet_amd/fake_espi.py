@@ -159,6 +159,20 @@ def rows_to_csv(rows):
     return "\n".join("{0},{1},{2},{3},{4},{5}".format(*r) for r in rows)
 
 
+def gpu_may_be_live():
+    """True when this process may already hold a HIP context, i.e. when fork() is unsafe: torch has initialised the
+    GPU, or a profiler's preloaded tool library has (rocprofv3 initialises the runtime before Python starts, and
+    torch.cuda.is_initialized() stays False then)."""
+    import sys
+    torch = sys.modules.get("torch")
+    if torch is not None and torch.cuda.is_available() and torch.cuda.is_initialized():
+        return True
+    env = os.environ
+    if any(k.startswith(("ROCPROFILER_", "ROCPROF_", "ROCP_")) for k in env):
+        return True
+    return any(t in env.get(k, "") for k in ("LD_PRELOAD", "HSA_TOOLS_LIB") for t in ("rocprof", "roctracer", "rocprofiler"))
+
+
 def generate(n, seed=0, workers=None):
     """n frames -> (uint8 [n,384,512], list of label rows).  Deterministic in (n, seed)."""
     seeds = frame_seeds(n, seed)
@@ -169,10 +183,7 @@ def generate(n, seed=0, workers=None):
     ctx = None
     if workers > 1 and n >= 16:
         import multiprocessing
-        import sys
-        torch = sys.modules.get("torch")
-        gpu_live = bool(torch is not None and torch.cuda.is_available() and torch.cuda.is_initialized())
-        if not gpu_live:
+        if not gpu_may_be_live():
             ctx = multiprocessing.get_context("fork")
         elif n >= 512:
             ctx = multiprocessing.get_context("spawn")

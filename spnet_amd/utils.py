@@ -153,9 +153,8 @@ def build_X(total_load, img_file_list, force_dim=224, grayscale=False):
         # forked workers are only safe while this process has not initialised the GPU (train_spnet.py evaluates and
         # predicts after training in one process): afterwards load from freshly spawned interpreters
         import multiprocessing
-        import sys
-        torch = sys.modules.get("torch")
-        gpu_live = bool(torch is not None and torch.cuda.is_available() and torch.cuda.is_initialized())
+        from .fake_espi import gpu_may_be_live
+        gpu_live = gpu_may_be_live()
         pool = multiprocessing.get_context("spawn" if gpu_live else "fork").Pool(nproc)
         try:
             for i, arr in enumerate(pool.imap(worker, img_file_list[0:total_load], chunksize=32)):

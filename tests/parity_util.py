@@ -112,17 +112,22 @@ def device_decisions(eng):
     return T.Decisions(relu, pool)
 
 
-def assert_gradients_match(eng, P, X, Y, mask, tol=5e-3, tie=1e-4, loss_type="same", sigmoid_cols=None):
+def assert_gradients_match(eng, P, X, Y, mask, tol=5e-3, tie=1e-5, loss_type="same", sigmoid_cols=None,
+                           max_override_rate=1e-5):
     """Every parameter gradient of the engine's last forward/backward against the fp64 oracle evaluated on the
     device's own discrete decisions: max|diff| <= tol * max|ref| on EVERY tensor, and every decision in which the
     device departs from the oracle's own must have been a tie (|pre-activation| or window gap <= tie x the largest
-    value of that tensor).  Returns (data_loss64, y_pred64, params64, decisions)."""
+    value of that tensor), and at most max_override_rate of all decisions may be overridden at all.  Returns (data_loss64, y_pred64, params64, decisions)."""
     dec = device_decisions(eng)
     data64, g64, yp64, P64 = oracle_grads(P, X, Y, mask, double=True, decisions=dec, loss_type=loss_type,
                                           sigmoid_cols=sigmoid_cols)
     assert dec._ri == len(dec.relu) and dec._pi == len(dec.pool), "decision sites out of step with the oracle"
     far = [f for f in dec.flips if f[2] > tie]
     assert not far, "device decisions differ from the oracle's away from ties: %s" % far[:8]
+    # ... and ties are rare: observed 10 overrides in 30 M decisions at 384x512 (every one within 4e-7 of the kink)
+    n_over = sum(f[1] for f in dec.flips)
+    assert n_over <= max(2, max_override_rate * dec.n_decisions), \
+        "%d of %d decisions overridden: %s" % (n_over, dec.n_decisions, dec.flips[:8])
     gd = eng.grad_dict()
     # a tensor whose true gradient vanishes identically (a bias in front of a training-mode BatchNorm: Inception-
     # ResNet's block8_10_conv/bias, 1e-17 in fp64) is measured against 1e-6 of the model's largest gradient entry

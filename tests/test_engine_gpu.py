@@ -141,7 +141,7 @@ def test_train_steps_follow_oracle(setup):
             frac_bad += float((d > 0.1).sum())
             n += d.size
     assert worst <= 2.0 + 1e-3, worst
-    assert frac_bad / n < 5e-3, frac_bad / n
+    assert frac_bad / n < 3e-3, frac_bad / n
 
 
 def test_device_augmentation_matches_reference_golden(golden):
@@ -162,3 +162,33 @@ def test_device_augmentation_matches_reference_golden(golden):
         torch.cuda.synchronize()
         np.testing.assert_array_equal(out.cpu().numpy(), want)          # bit-exact with the reference's numpy code
         assert np.random.rand() == float(golden[f"aug_{tag}_rng_after"])   # same RNG consumption
+
+
+def test_graph_replayed_training_invalidates_inference_coefficients():
+    """SPNET_TRAIN_GRAPH=1: replayed steps skip _step_body's host code, so train_step must itself note that the
+    weights and moving statistics moved -- otherwise predict_step replays its inference graph with BatchNorm
+    scale|shift built from the OLD gamma/beta/moving statistics (round-2 ADVICE).  Twin engines, one eager and one
+    replaying, must predict the same."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from spnet_amd.engine import Engine
+    h, w, b = 64, 96, 2
+    rs = np.random.RandomState(3)
+    X = torch.tensor(rs.rand(b, h, w, 1) * 2 - 1, dtype=torch.float32).cuda()
+    Y = torch.tensor(rs.rand(b, 576), dtype=torch.float32).cuda()
+    outs = []
+    for graph in (False, True):
+        eng = Engine(h, w, b, device="cuda:0", seed=21)
+        eng.use_graph = graph
+        eng.x_in.copy_(X)
+        first = eng.predict_step(use_graph=True).clone()      # builds the inference graph and its coefficients
+        for _ in range(4):                                     # step 1 eager (warm), 2 captures, 3-4 replay
+            eng.train_step(X, Y, 1e-3)
+        assert (eng._graph is not None) == graph
+        eng.x_in.copy_(X)
+        out = eng.predict_step(use_graph=True)
+        torch.cuda.synchronize()
+        out = (eng.out if out is None else out).clone()
+        assert float((out - first).abs().max()) > 1e-6        # four steps at lr 1e-3 moved the prediction
+        outs.append(out.cpu())
+    np.testing.assert_allclose(outs[1].numpy(), outs[0].numpy(), rtol=0, atol=1e-5)

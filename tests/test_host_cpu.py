@@ -269,3 +269,53 @@ def test_gemm_tile_table_precedence_and_format():
         E.TILE_PROBE.clear()
     assert E._tile_for(*key, 0) == E.TILE_TABLE.get(key, 0)             # table
     assert E._tile_for(0, 1, 0, 12345, 4, 8, 0) == 0                    # unlisted shape: the library's cost model
+
+
+def test_bench_self_launches_its_ranks_on_gloo():
+    """`python bench.py --gpus 2` started the way the driver starts N=1 (no launcher, no WORLD_SIZE): the parent
+    spawns the two ranks as a child torchrun job before touching torch.cuda, relays rank 0's one JSON line and
+    returns the child's exit code (--launch-check: rendezvous + one all-reduce, no kernels, so it runs here)."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--launch-check"],
+                       capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["n_ranks_seen"] == 2 and out["collective_backend"] == "gloo"
+    # a rank that fails makes the parent fail (the WORLD_SIZE / --gpus mismatch inside a launched job)
+    env2 = dict(env, WORLD_SIZE="3", RANK="0", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29631")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--launch-check"],
+                       capture_output=True, text=True, timeout=120, env=dict(env2, WORLD_SIZE="1"))
+    assert r.returncode != 0 and "WORLD_SIZE" in (r.stderr + r.stdout)
+
+
+def test_fork_is_refused_under_a_preloaded_profiler(monkeypatch):
+    """rocprofv3 initialises the HIP runtime before Python starts (torch.cuda.is_initialized() stays False): the
+    frame generator and the PNG loader must not fork then."""
+    from spnet_amd import fake_espi as F
+    for k in list(os.environ):
+        if k.startswith(("ROCPROF", "ROCP_")):
+            monkeypatch.delenv(k)
+    monkeypatch.delenv("LD_PRELOAD", raising=False)
+    monkeypatch.delenv("HSA_TOOLS_LIB", raising=False)
+    assert not F.gpu_may_be_live()
+    monkeypatch.setenv("LD_PRELOAD", "/opt/rocm/lib/rocprofiler-sdk/librocprofiler-sdk-tool.so")
+    assert F.gpu_may_be_live()
+    monkeypatch.delenv("LD_PRELOAD")
+    monkeypatch.setenv("ROCPROF_OUTPUT_PATH", "/tmp/x")
+    assert F.gpu_may_be_live()
+    X, lab = F.generate(16, seed=3, workers=4)        # serial under the "profiler"; same frames as the forked path
+    monkeypatch.delenv("ROCPROF_OUTPUT_PATH")
+    X2, lab2 = F.generate(16, seed=3, workers=4)
+    assert np.array_equal(X, X2) and lab == lab2
+
+
+def test_cpu_share_for_the_baseline():
+    sys.path.insert(0, ROOT)
+    import bench
+    n, share = bench.host_cpu_share()
+    assert 1 <= n <= share["affinity_cpus"] and n <= 32
+    if share["cgroup_quota_cpus"]:
+        assert n <= int(share["cgroup_quota_cpus"] + 0.5)
