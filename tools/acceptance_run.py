@@ -1,0 +1,245 @@
+#!/usr/bin/env python3
+"""SURVEY section 8(c) statistical acceptance: train the product the way the reference's published run was trained
+and set the outcome beside that run's log (paper/run_logs/log_DatasetA_FakeLarge_MSEloss_100ep_...txt).
+
+Layout of the reference run (its log :62-66,:176,:208): model_type 'monolithic' = every 512x384 frame resized to
+331x331 (PIL Lanczos, spnet/utils.py:330-342), Xception, 40,000 train / 4,992 val / 4,992 test fake-ESPI frames,
+batch 16, lr_max 4e-5 1-cycle, augmentation on the fly, freeze_fac 0 (`Freezing 0 / 144 layers`), loss_type 'same'.
+Here: the same flow through the product's own API (models.setup_model -> Model.fit with MyProgressCallback,
+OneCycleScheduler, AugmentOnTheFly; evaluate_spnet.py's metrics at the end).  Frames come from the device
+fake-ESPI generator (csrc/espi.hip; labels identical to the host generator's), are resized on the host with the
+codec's own PIL call and never touch the disk.  gpurun allows 20 minutes per call, so the number of epochs is an
+argument (the 1-cycle schedule is built for that many epochs, as train_spnet.py -e would).
+
+Writes <out>/acceptance.json (per-epoch rows + final metrics + the reference's figures + band verdicts) and
+<out>/acceptance_table.txt."""
+import argparse
+import json
+import os
+import sys
+import time
+from multiprocessing.pool import ThreadPool
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+# the reference's published run (file:line in /root/reference/paper/run_logs/log_DatasetA_FakeLarge_MSEloss_100ep_...txt)
+REF = {
+    "epoch_rows": {   # epoch index: train_total val_total center size angle noobj rings   (:195, :307, ... every 5th)
+        0: (2.582e-01, 2.323e-01, 2.971e-03, 2.122e-03, 1.085e-03, 3.410e-03, 2.331e-03),
+        5: (7.819e-02, 6.253e-02, 8.259e-04, 9.932e-04, 4.818e-04, 8.974e-04, 4.584e-04),
+        10: (6.465e-03, 4.995e-03, 2.235e-04, 2.207e-04, 1.649e-04, 3.991e-04, 1.863e-04),
+        20: (9.174e-04, 8.666e-04, 8.632e-05, 7.927e-05, 8.209e-05, 1.337e-04, 6.309e-05),
+        30: (5.992e-04, 6.863e-04, 8.115e-05, 7.517e-05, 6.689e-05, 1.140e-04, 8.983e-05),
+        40: (4.548e-04, 5.224e-04, 6.049e-05, 5.126e-05, 6.708e-05, 1.011e-04, 4.182e-05),
+        50: (3.604e-04, 4.389e-04, 5.883e-05, 4.077e-05, 5.490e-05, 9.374e-05, 3.178e-05),
+        60: (2.759e-04, 3.666e-04, 4.788e-05, 3.767e-05, 3.840e-05, 8.948e-05, 2.680e-05),
+        70: (2.056e-04, 2.993e-04, 3.687e-05, 3.417e-05, 3.187e-05, 7.861e-05, 1.884e-05),
+        80: (1.527e-04, 2.442e-04, 2.679e-05, 2.717e-05, 2.757e-05, 7.081e-05, 1.253e-05),
+        90: (1.239e-04, 2.133e-04, 2.188e-05, 2.365e-05, 2.412e-05, 6.339e-05, 1.084e-05),
+        99: (1.154e-04, 2.054e-04, 2.071e-05, 2.262e-05, 2.317e-05, 6.197e-05, 9.557e-06),      # :2447-2448
+    },
+    "final": {"loss": 1.1543e-04, "val_loss": 2.0538e-04,                    # :2463
+              "mAP": 0.9687651654815838, "mean_pixel_error": 5.0598817,      # :2487-2509, test set of 4,992 frames
+              "ring_correct": 14432, "total_obj": 14965, "tp_rate": 97.35382559305044,
+              "false_pos": 413, "false_neg": 396, "ring_miscounts": 137},
+    "epochs": 100,
+}
+
+# Acceptance bands, fixed BEFORE the run.  Not equality: the frames come from another rasteriser
+# (analytic device kernel vs OpenCV drawing calls, no bandpass_mixup), dropout uses another RNG, and the run may be shorter.
+BANDS = {
+    "l2_after_epoch1": (0.75, 1.25),        # (val_total - sum of the five val terms) / the reference's 0.2204 at epoch index 0
+    "final_loss_max_ratio": 3.0,            # train total  <= 3 x 1.154e-4  (for runs of >= 50 epochs)
+    "final_val_loss_max_ratio": 3.0,        # val total    <= 3 x 2.054e-4
+    "per_term_max_ratio": 3.0,              # each of the five val terms <= 3 x the reference's
+    "mAP_min": 0.93, "mean_pixel_error_max": 7.5, "ring_accuracy_min": 93.0, "tp_rate_min": 95.0,
+}
+
+
+def make_set(n, seed, dev, size, threads):
+    """n fake-ESPI frames: device rasteriser -> uint8 on the host -> the input codec's resize (PIL Lanczos to
+    size x size, utils._load_one) -> float32 [n,size,size,1] in [-1,1]; labels -> normalised grid targets."""
+    import torch
+    from PIL import Image
+    import bench
+    from spnet_amd import fake_espi as F
+    X = np.empty((n, size, size, 1), np.float32)
+    labels = []
+    pool = ThreadPool(threads)
+
+    def resize(a):
+        return np.asarray(Image.fromarray(a).resize((size, size), Image.LANCZOS), dtype=np.float32)
+
+    block = 4096
+    for k, lo in enumerate(range(0, n, block)):
+        m = min(block, n - lo)
+        _, lab, U = F.generate_device(m, seed=seed + k, device=str(dev), want_u8=True)
+        u = U.cpu().numpy()
+        del U
+        torch.cuda.empty_cache()
+        for i, arr in enumerate(pool.imap(resize, list(u), chunksize=16)):
+            X[lo + i, :, :, 0] = arr
+        labels += lab
+    pool.close()
+    X /= 255.0
+    X -= 0.5
+    X *= 2.0
+    return X, bench.labels_to_Y(labels)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--train", type=int, default=40000)
+    ap.add_argument("--val", type=int, default=4992)
+    ap.add_argument("--test", type=int, default=4992)
+    ap.add_argument("--epochs", type=int, default=50)
+    ap.add_argument("--batch", type=int, default=16)
+    ap.add_argument("--lrmax", type=float, default=4e-5)
+    ap.add_argument("--size", type=int, default=331)
+    ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "acceptance"))
+    ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--time-budget", type=float, default=0.0,
+                    help="seconds from process start; training stops early (schedule cut short, recorded) when the "
+                         "next epoch would not fit -- a guard against the 20-minute limit of a gpurun call")
+    args = ap.parse_args()
+    os.makedirs(args.out, exist_ok=True)
+    t_start = time.time()
+
+    import torch
+    from spnet import callbacks, diagnostics, models, utils
+    import spnet.config as cf
+    from bench import host_cpu_share
+    cf.model_type, cf.loss_type, cf.basemodel = "monolithic", "same", "Xception"
+    np.random.seed(args.seed)
+    threads, _ = host_cpu_share()
+    torch.set_num_threads(threads)
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+
+    # (generator seeds: frame seed = seed * 1000003 + i must stay below 2**32; one seed per block of 4,096 frames)
+    X_train, Y_train = make_set(args.train, 100 + 1000 * args.seed, dev, args.size, threads)
+    X_val, Y_val = make_set(args.val, 300 + 1000 * args.seed, dev, args.size, threads)
+    X_test, Y_test = make_set(args.test, 400 + 1000 * args.seed, dev, args.size, threads)
+    t_data = time.time() - t_start
+    print("data: %d/%d/%d frames at %dx%d in %.1f s" % (args.train, args.val, args.test, args.size, args.size, t_data),
+          flush=True)
+
+    model, _ = models.setup_model(X_train, Y_train[0].size, no_cp_fatal=False, weights_file="no_such_weights.hdf5",
+                                  parallel=False, freeze_fac=0.0)
+    log_dir = os.path.join(args.out, "log")
+    if os.path.exists(log_dir + "/losses.dat"):
+        os.remove(log_dir + "/losses.dat")
+    cbs = [callbacks.MyProgressCallback(X_val=X_val, Y_val=Y_val, val_file_list=None, log_dir=log_dir,
+                                        pred_shape=[6, 6, 2, 8], num_draw=0, make_plots=False),
+           callbacks.OneCycleScheduler(lr_max=args.lrmax, n_data_points=X_train.shape[0], epochs=args.epochs,
+                                       batch_size=args.batch, verbose=1),
+           callbacks.AugmentOnTheFly(X_train, Y_train, aug_every=1, seed=args.seed)]
+
+    class Clock(callbacks.Callback):
+        def __init__(self):
+            super().__init__()
+            self.t, self.rows = [], []
+
+        def on_epoch_begin(self, epoch, logs=None):
+            self.t0 = time.time()
+
+        def on_epoch_end(self, epoch, logs=None):
+            self.t.append(time.time() - self.t0)
+            if args.time_budget > 0 and (time.time() - t_start) + 1.3 * max(self.t) + 45 > args.time_budget:
+                print("time budget: stopping after epoch", epoch, flush=True)
+                self.model.stop_training = True
+            with open(os.path.join(args.out, "progress.txt"), "a") as f:     # survives a killed call
+                f.write("epoch %d  %.1f s  loss %.4e  val_loss %.4e\n" % (epoch, self.t[-1], logs.get("loss"),
+                                                                           logs.get("val_loss")))
+
+    clock = Clock()
+    t_fit = time.time()
+    hist = model.fit(X_train, Y_train, batch_size=args.batch, epochs=args.epochs, shuffle=True, verbose=1,
+                     validation_data=(X_val, Y_val), callbacks=[clock] + cbs)
+    t_fit = time.time() - t_fit
+
+    rows = []
+    for line in open(log_dir + "/losses.dat"):
+        if not line.startswith("#"):
+            v = line.split()
+            rows.append([int(v[0])] + [float(x) for x in v[1:]])
+    # rows: epoch train_total my_val_loss center size angle noobj rings ; Keras' val_loss (with l2) from history
+    for r, vl in zip(rows, hist["val_loss"]):
+        r.insert(2, float(vl))
+
+    # ---- evaluate_spnet.py's metrics on the held-out test set
+    t0 = time.time()
+    Y_pred = model.predict(X_test, batch_size=args.batch)
+    fps = X_test.shape[0] / (time.time() - t0)
+    Yt, Yp = utils.denorm_Y(Y_test), utils.denorm_Y(Y_pred)
+    mAP = float(diagnostics.calc_map(Yp, Yt, device=True))
+    (ring_miscounts, ring_truecounts, total_obj, false_pos, false_neg, true_pos, true_neg, pix_err,
+     ipem) = diagnostics.calc_errors(Yp, Yt)
+    tot = max(int(total_obj), 1)
+    final = {"loss": rows[-1][1], "val_loss": rows[-1][2], "mAP": mAP, "mean_pixel_error": float(np.mean(pix_err)),
+             "max_pixel_error": float(pix_err[ipem]), "ring_correct": int(ring_truecounts), "total_obj": int(total_obj),
+             "ring_accuracy": 100.0 * int(ring_truecounts) / tot, "ring_miscounts": int(ring_miscounts),
+             "false_pos": int(false_pos), "false_neg": int(false_neg), "tp_rate": 100.0 * int(true_pos) / tot,
+             "test_predict_fps": fps}
+
+    # ---- bands
+    E = args.epochs
+    ref0 = REF["epoch_rows"][0]
+    ref_l2_0 = ref0[1] - sum(ref0[2:])
+    l2_0 = rows[0][2] - sum(rows[0][4:9])
+    reff = REF["epoch_rows"][99]
+    checks = {
+        "l2_after_epoch1": {"ours": l2_0, "reference": ref_l2_0, "ratio": l2_0 / ref_l2_0,
+                            "ok": BANDS["l2_after_epoch1"][0] <= l2_0 / ref_l2_0 <= BANDS["l2_after_epoch1"][1]},
+        "final_loss": {"ours": final["loss"], "reference": reff[0], "ratio": final["loss"] / reff[0],
+                       "ok": final["loss"] <= BANDS["final_loss_max_ratio"] * reff[0]},
+        "final_val_loss": {"ours": final["val_loss"], "reference": reff[1], "ratio": final["val_loss"] / reff[1],
+                           "ok": final["val_loss"] <= BANDS["final_val_loss_max_ratio"] * reff[1]},
+        "mAP": {"ours": mAP, "reference": REF["final"]["mAP"], "ok": mAP >= BANDS["mAP_min"]},
+        "mean_pixel_error": {"ours": final["mean_pixel_error"], "reference": REF["final"]["mean_pixel_error"],
+                             "ok": final["mean_pixel_error"] <= BANDS["mean_pixel_error_max"]},
+        "ring_accuracy": {"ours": final["ring_accuracy"],
+                          "reference": 100.0 * REF["final"]["ring_correct"] / REF["final"]["total_obj"],
+                          "ok": final["ring_accuracy"] >= BANDS["ring_accuracy_min"]},
+        "tp_rate": {"ours": final["tp_rate"], "reference": REF["final"]["tp_rate"],
+                    "ok": final["tp_rate"] >= BANDS["tp_rate_min"]},
+    }
+    for j, name in enumerate(("center", "size", "angle", "noobj", "rings")):
+        ours, ref = rows[-1][4 + j], reff[2 + j]
+        checks["val_" + name] = {"ours": ours, "reference": ref, "ratio": ours / ref,
+                                 "ok": ours <= BANDS["per_term_max_ratio"] * ref}
+    result = {"args": vars(args), "epochs_run": len(rows), "stopped_early": len(rows) < args.epochs, "reference_epochs": REF["epochs"],
+              "seconds": {"data": t_data, "fit": t_fit, "per_epoch_median": float(np.median(clock.t)), "total": time.time() - t_start},
+              "train_images_per_sec_incl_validation_and_augmentation": args.train * len(rows) / t_fit,
+              "columns": ["epoch", "train_total", "val_total", "my_val_loss", "center", "size", "angle", "noobj", "rings"],
+              "rows": rows, "final": final, "bands": BANDS, "checks": checks,
+              "all_ok": all(c["ok"] for c in checks.values()),
+              "reference": {"final": REF["final"], "epoch_rows": {str(k): v for k, v in REF["epoch_rows"].items()}}}
+    with open(os.path.join(args.out, "acceptance.json"), "w") as f:
+        json.dump(result, f, indent=1)
+
+    # ---- table: our epoch e of E beside the reference's epoch at the same fraction of its 1-cycle schedule
+    lines = ["acceptance run: %d epochs x %d frames at %dx%d, batch %d, lr_max %g (reference: 100 epochs)" %
+             (len(rows), args.train, args.size, args.size, args.batch, args.lrmax),
+             "fit %.0f s (%.1f s/epoch median; %.0f images/s including validation, progress callback and augmentation)" %
+             (t_fit, float(np.median(clock.t)), result["train_images_per_sec_incl_validation_and_augmentation"]), "",
+             "%5s %5s | %-10s %-10s | %-10s %-10s | five val terms (ours / reference): center size angle noobj rings" %
+             ("ep", "refep", "train", "ref", "val", "ref")]
+    for ref_ep in sorted(REF["epoch_rows"]):
+        e = min(len(rows) - 1, int(round(ref_ep * (E - 1) / 99.0)))
+        r, q = rows[e], REF["epoch_rows"][ref_ep]
+        lines.append("%5d %5d | %.3e  %.3e | %.3e  %.3e | %s" % (
+            e, ref_ep, r[1], q[0], r[2], q[1], "  ".join("%.2e/%.2e" % (r[4 + j], q[2 + j]) for j in range(5))))
+    lines += ["", "final metrics on %d held-out frames (ours / reference / band):" % args.test]
+    for k, c in checks.items():
+        lines.append("  %-18s %.5g / %.5g   %s" % (k, c["ours"], c["reference"], "ok" if c["ok"] else "OUT OF BAND"))
+    lines.append("all_ok = %s" % result["all_ok"])
+    open(os.path.join(args.out, "acceptance_table.txt"), "w").write("\n".join(lines) + "\n")
+    print("\n".join(lines), flush=True)
+
+
+if __name__ == "__main__":
+    main()
