@@ -201,23 +201,15 @@ def secondary(args):
                       "config": {"workload": "%s, %s, %dx%d frames, batch %d" % (args.mode, args.backbone, w, h, b)}}))
 
 
-def predict_bench(args):
-    """BASELINE configs[4]: predict_spnet.py's inference loop -- Xception, batch 128, 512x384 frames -- on one GPU.
-    A step = one batch of 128 frames through the hipGraph-captured forward (Engine.predict_step); frames are resident
-    in HBM when the timed region starts.  Also reported: the same loop through Model.predict over HOST frames
-    (pinned ring + copy stream: the PCIe-inclusive rate, never `value`), and the eager-launch rate."""
+def predict_measure(X_pool, dev, steps, warmup, host_frames=1024):
+    """BASELINE configs[4] on frames already resident in HBM (X_pool [n,384,512,1] on `dev`, n a multiple of 128):
+    hipGraph-captured forward of batch 128 (Engine.predict_step), the eager-launch rate, the family rooflines from
+    HIP events, and Model.predict over HOST frames (pinned ring + copy stream: PCIe-inclusive, never `value`)."""
     import torch
-    from spnet_amd import fake_espi as F
-    from spnet_amd import parallel
     from spnet_amd.engine import Engine, KernelTimer
+    from spnet_amd.models import Model
     PB = 128
-    pool = max(PB, min(args.pool, 2048) // PB * PB)
-    X_u8, _ = F.generate(pool, seed=11, workers=max(2, min(16, os.cpu_count() or 8)))
-    parallel.init_distributed()
-    dev = parallel.local_device()
-    torch.cuda.set_device(dev)
-    X_host = F.to_network_input(X_u8)
-    X_pool = torch.from_numpy(X_host).to(dev)
+    pool = X_pool.shape[0] // PB * PB
     eng = Engine(H, W, PB, device=str(dev), seed=0, train=False)
     it = [0]
 
@@ -228,7 +220,7 @@ def predict_bench(args):
         return eng.predict_step(use_graph=graph)
 
     def timed(n, graph):
-        for _ in range(args.warmup):
+        for _ in range(warmup):
             step(graph)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -237,39 +229,45 @@ def predict_bench(args):
         torch.cuda.synchronize()
         return time.perf_counter() - t0
 
-    dt = timed(args.steps, True)
-    dt_eager = timed(args.steps, False)
+    dt = timed(steps, True)
+    dt_eager = timed(steps, False)
     timer = KernelTimer()
     eng.prof = timer
-    timed(args.steps, False)
+    timed(steps, False)
     eng.prof = None
     tot = timer.totals()
     g_n, g_ms, g_flop = tot["gemm"]
     d_n, d_ms, _ = tot["dw"]
-    n_prof = args.steps + args.warmup
+    n_prof = steps + warmup
     gemm_tflops = g_flop / (g_ms * 1e-3) / 1e12
     dw_gbs = DW_FWD_BYTES_PER_IMAGE * PB * n_prof / (d_ms * 1e-3) / 1e9
+    del eng
     # PCIe-inclusive: model.predict over host frames, as predict_spnet.py calls it
-    from spnet_amd.models import Model
+    nh = min(pool, host_frames) // PB * PB
+    X_host = X_pool[:nh].cpu().numpy()
     m = Model((H, W, 1), Y0size=576, seed=0, device=str(dev))
-    nh = min(pool, 1024)
     m.predict(X_host[:PB], batch_size=PB)
     t0 = time.perf_counter()
-    m.predict(X_host[:nh], batch_size=PB)
+    m.predict(X_host, batch_size=PB)
     dt_host = time.perf_counter() - t0
+    # ... and over uint8 host frames (4x fewer bytes over PCIe; the /255*2-1 scaling of utils.py:340-342 on the device)
+    host_u8 = None
+    if hasattr(m, "predict_u8"):
+        U8 = np.clip(np.rint((X_host[..., 0] + 1.0) * 127.5), 0, 255).astype(np.uint8)
+        m.predict_u8(U8[:PB], batch_size=PB)
+        t0 = time.perf_counter()
+        m.predict_u8(U8, batch_size=PB)
+        host_u8 = round(nh / (time.perf_counter() - t0), 1)
+    del m
+    torch.cuda.empty_cache()
     note = "HIP events around every launch of the family during %d eager forwards after the timed region" % n_prof
-    print(json.dumps({
-        "metric": "inference frames/sec, predict_spnet.py path (model.predict), Xception, batch 128 over 512x384 frames "
-                  "(BASELINE configs[4]; secondary to the training metric)",
-        "value": round(PB * args.steps / dt, 1), "unit": "frames/sec", "n_gpus": 1, "steps": args.steps,
-        "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True,
-        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "configs[4]: inference-only forward, Xception, 512x384 fake-ESPI frames, batch 128, "
-                               "hipGraph-captured plan, frames resident in HBM", "batch": PB, "frame_hw": [H, W],
-                   "pool_frames": pool, "eager_frames_per_sec": round(PB * args.steps / dt_eager, 1),
-                   "host_frames_streamed_frames_per_sec": round(nh / dt_host, 1),
-                   "host_frames_note": "Model.predict over %d host frames: pageable -> pinned ring -> HBM on a copy "
-                                       "stream, overlapped with the forward passes (PCIe-inclusive; not `value`)" % nh},
+    return {
+        "frames_per_sec": round(PB * steps / dt, 1), "ms_per_step": round(1e3 * dt / steps, 3), "steps": steps,
+        "batch": PB, "pool_frames": pool, "eager_frames_per_sec": round(PB * steps / dt_eager, 1),
+        "host_streamed_frames_per_sec": round(nh / dt_host, 1),
+        "host_streamed_u8_frames_per_sec": host_u8,
+        "host_frames_note": "Model.predict over %d host frames: pageable -> pinned ring -> HBM on a copy stream, "
+                            "overlapped with the forward passes (PCIe-inclusive; not `value`)" % nh,
         "roofline": {"kernel": "fp32 MFMA GEMM family, forward form (pointwise / residual / Dense + conv3x3_fwd_kernel)",
                      "bound": "mfma", "achieved": round(gemm_tflops, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                      "frac": round(gemm_tflops / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
@@ -278,7 +276,72 @@ def predict_bench(args):
                                "achieved": round(dw_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                "frac": round(dw_gbs / HBM_PEAK_GBS, 4), "traffic": None,
                                "launches_per_step": d_n / n_prof, "ms_per_step": round(d_ms / n_prof, 3), "measured": note},
+    }
+
+
+def predict_bench(args):
+    """`bench.py --mode predict`: BASELINE configs[4] as its own line -- predict_spnet.py's inference loop (Xception,
+    batch 128, 512x384 frames) on one GPU.  A step = one batch of 128 frames through the hipGraph-captured forward;
+    frames are resident in HBM when the timed region starts."""
+    import torch
+    from spnet_amd import fake_espi as F
+    from spnet_amd import parallel
+    PB = 128
+    pool = max(PB, min(args.pool, 2048) // PB * PB)
+    parallel.init_distributed()
+    dev = parallel.local_device()
+    torch.cuda.set_device(dev)
+    X_pool, _ = F.generate_device(pool, seed=11, device=str(dev))
+    r = predict_measure(X_pool, dev, args.steps, args.warmup)
+    print(json.dumps({
+        "metric": "inference frames/sec, predict_spnet.py path (model.predict), Xception, batch 128 over 512x384 frames "
+                  "(BASELINE configs[4]; secondary to the training metric)",
+        "value": r["frames_per_sec"], "unit": "frames/sec", "n_gpus": 1, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": r["ms_per_step"], "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "configs[4]: inference-only forward, Xception, 512x384 fake-ESPI frames, batch 128, "
+                               "hipGraph-captured plan, frames resident in HBM", "batch": PB, "frame_hw": [H, W],
+                   "pool_frames": pool, "eager_frames_per_sec": r["eager_frames_per_sec"],
+                   "host_frames_streamed_frames_per_sec": r["host_streamed_frames_per_sec"],
+                   "host_frames_u8_streamed_frames_per_sec": r["host_streamed_u8_frames_per_sec"],
+                   "host_frames_note": r["host_frames_note"]},
+        "roofline": r["roofline"], "roofline_secondary": r["roofline_secondary"],
     }), flush=True)
+
+
+def layout_331_measure(dev, steps=20, warmup=3):
+    """The reference's own layout (model_type 'monolithic': 331x331 frames, batch 16 -- what its published 96-131
+    training images/s and 444-717 inference FPS on TITAN X / 2080 Ti refer to): train steps of
+    batch 16 and inference forwards of batch 32 on uniform-noise frames."""
+    import torch
+    from spnet_amd.engine import Engine
+    out = {}
+    for mode, b in (("train", 16), ("predict", 32)):
+        eng = Engine(331, 331, b, device=str(dev), seed=0, train=(mode == "train"))
+        X = torch.rand(b, 331, 331, 1, device=dev) * 2 - 1
+        Y = torch.rand(b, 576, device=dev)
+
+        def step():
+            if mode == "train":
+                eng.train_step(X, Y, 1e-5)
+            else:
+                eng.x_in.copy_(X)
+                eng.predict_step()
+
+        for _ in range(warmup):
+            step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        out[mode] = {"images_per_sec": round(b * steps / dt, 1), "batch": b, "ms_per_step": round(1e3 * dt / steps, 3),
+                     "steps": steps}
+        del eng
+        torch.cuda.empty_cache()
+    out["reference_published"] = "train 96-131 images/s, predict 444-717 FPS (TITAN X / RTX 2080 Ti, BASELINE.md section 1)"
+    return out
 
 
 def rccl_version():
@@ -328,6 +391,8 @@ def main():
     ap.add_argument("--cpu-baseline-batch", type=int, default=8)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timers", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true",
+                    help="skip the configs[4] inference leg and the 331x331 layout leg appended to the N=1 line")
     ap.add_argument("--mode", choices=["train", "predict"], default="train",
                     help="predict: inference-only forward (BASELINE configs[4]); secondary, not the headline metric")
     ap.add_argument("--height", type=int, default=H)
@@ -570,6 +635,22 @@ def main():
                        "algorithmic_bytes_per_launch": round(DW_TRAIN_BYTES_PER_IMAGE * BATCH * args.steps / d_n),
                        "avg_launch_us": round(1e3 * d_ms / d_n, 2), "launches_per_step": d_n / args.steps,
                        "ms_per_step": round(d_ms / args.steps, 3)}
+            # the depthwise family by sub-family: entry flow (blocks 2-4: 93x125 / 47x63 / 24x32 planes, large tensors),
+            # middle flow (12x16x728 planes: 18 MB tensors, latency-bound launches), exit flow (6x8 planes); bytes =
+            # the per-launch algorithmic figure (8 B per element forward, 12 B backward)
+            subs = {}
+            for tag, (n, ms, work) in timer.tagged().items():
+                if not (isinstance(tag, tuple) and len(tag) == 4 and str(tag[0]).startswith("dw")):
+                    continue
+                ph, pw_ = tag[1], tag[2]
+                key = "entry" if ph * pw_ > 12 * 16 else ("middle" if ph * pw_ == 12 * 16 else "exit")
+                a = subs.setdefault(key, [0, 0.0, 0.0])
+                a[0] += n; a[1] += ms; a[2] += work
+            roof_dw["sub_families"] = {
+                k: {"launches_per_step": v[0] / args.steps, "ms_per_step": round(v[1] / args.steps, 3),
+                    "algorithmic_bytes_per_step": round(v[2] / args.steps),
+                    "achieved": round(v[2] / (v[1] * 1e-3) / 1e9, 1), "unit": "GB/s",
+                    "frac": round(v[2] / (v[1] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)} for k, v in sorted(subs.items())}
             note = ("HIP events around every launch of the family during %d extra steps replayed on one stream "
                     "(weight-gradient overlap off) right after the timed region" % args.steps)
             roof_gemm["measured"] = roof_dw["measured"] = note
@@ -580,6 +661,14 @@ def main():
             result["roofline"] = roof_gemm if g_ms >= d_ms else roof_dw
             result["roofline_secondary"] = roof_dw if g_ms >= d_ms else roof_gemm
             result["kernel_families"] = fam
+        if world == 1 and not args.no_secondary:
+            # the secondary configurations, in the same driver-witnessed line (N = 1 only; ~10 s): BASELINE configs[4]
+            # (predict_spnet.py:84-87's FPS) on the resident pool, and the reference's own 331x331 layout
+            del eng, aug
+            torch.cuda.empty_cache()
+            result["predict"] = predict_measure(X_pool[:min(args.pool, 2048) // 128 * 128], dev, 10, 2)
+            result["layout_331"] = layout_331_measure(dev)
+            eng = aug = None
         if world == 1 and not args.no_cpu_baseline:
             del eng, aug, X_pool
             torch.cuda.empty_cache()

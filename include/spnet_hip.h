@@ -167,6 +167,14 @@ int spnet_maxpool3x3s2_add_fwd(const float* x, const float* residual, float* y, 
                                int H, int W, int C, const float* x_ss, const float* r_ss, void* stream);
 int spnet_maxpool3x3s2_bwd(const float* dy, const uint32_t* idx4, float* dx, int B, int H, int W, int C,
                            void* stream);
+/* The same, also emitting the backward sums (sum dx, sum dx*xhat) of the BatchNorm whose un-materialised output was
+ * pooled -- yp = its pre-normalisation tensor [B,H,W,C], mean / invstd as saved by its forward -- as
+ * partial[rows][2][C], rows = spnet_maxpool3x3s2_bwd_rows(B,H,W,C) <= 128: the gradient path of block{2,3,4,13}_pool +
+ * block*_sepconv2_bn in keras.applications.Xception (call site spnet/models.py:357-359) without a reduction pass. */
+long spnet_maxpool3x3s2_bwd_rows(int B, int H, int W, int C);
+int spnet_maxpool3x3s2_bwd_bnsums(const float* dy, const uint32_t* idx4, float* dx, int B, int H, int W, int C,
+                                  const float* yp, const float* mean, const float* invstd, float* partial,
+                                  void* stream);
 /* AveragePooling2D(2) of the stem (spnet/models.py:323,337); any C. */
 int spnet_avgpool2_fwd(const float* x, float* y, int B, int H, int W, int C, void* stream);
 int spnet_avgpool2_bwd(const float* dy, float* dx, int B, int H, int W, int C, void* stream);
@@ -232,6 +240,11 @@ int spnet_calc_errors(const float* yp, const float* yt, long N, int ncols, int* 
 int spnet_adam_step(float* p, const float* g, float* m, float* v, long n, long l2_n, float lr_t,
                     float beta1, float beta2, float eps, float l2, float grad_scale, const float* mask,
                     float* sq_scratch, float* l2_loss_out, const float* lr_t_dev, void* stream);
+
+/* ---- input codec on the device (spnet/utils.py:340-342, load_X_one_proc) ------------------------------------------ */
+/* uint8 grey levels -> float32 network input, dst = (src / 255 - 0.5) * 2 with numpy's float32 roundings (bit-identical
+ * to the host conversion); n pixels, pointers 16-byte aligned.  Lets frames cross PCIe as bytes. */
+int spnet_u8_to_input(const unsigned char* src, float* dst, long n, void* stream);
 
 /* ---- augmentation (spnet/callbacks.py:272-341, spnet/augmentation.py) ---------------------------- */
 /* per-frame min/max -> mm[N][2]; scratch: N*32 floats */

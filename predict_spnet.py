@@ -16,7 +16,7 @@ default_image_dir = '/home/shawley/datasets/zooniverse_steelpan/'
 
 
 def predict_network(weights_file="spnet.model", datapath=default_image_dir, fraction=1.0, log_dir='logs/Predicting/',
-                    batch_size=16, model=None, X_pred=''):
+                    batch_size=16, model=None, X_pred='', u8_frames=False):
     img_file_list = []
     if isinstance(X_pred, str) and X_pred == '':
         print(f"Getting data from {datapath}, fraction = {fraction}.")
@@ -32,7 +32,8 @@ def predict_network(weights_file="spnet.model", datapath=default_image_dir, frac
         if batch_size is not None:
             total_load = nearest_multiple(total_load, batch_size)
         print("      Total files = ", total_files, ", going to load total_load = ", total_load)
-        X_pred, _ = build_X(total_load, img_file_list, force_dim=force_dim, grayscale=grayscale)
+        X_pred, _ = build_X(total_load, img_file_list, force_dim=force_dim, grayscale=grayscale,
+                            as_uint8=bool(u8_frames) and grayscale)
         print("")
 
     if model is None:
@@ -75,9 +76,12 @@ if __name__ == '__main__':
     p.add_argument('-b', '--batch_size', type=int, default=16, help='Batch size to use')
     p.add_argument('--model_type', default=None, help="override spnet.config.model_type ('monolithic' | 'big')")
     p.add_argument('--loss_type', default=None, help="override spnet.config.loss_type")
+    p.add_argument('--u8_frames', action='store_true',
+                   help="(additive) keep the decoded frames as uint8 and scale them to [-1,1] on the GPU: same "
+                        "predictions, a quarter of the host-to-device bytes")
     args = p.parse_args()
     for attr, val in (("model_type", args.model_type), ("loss_type", args.loss_type)):
         if val is not None:
             setattr(cf, attr, val)
     predict_network(weights_file=args.weights, datapath=args.datapath, fraction=args.fraction, log_dir=args.logdir,
-                    batch_size=args.batch_size)
+                    batch_size=args.batch_size, u8_frames=args.u8_frames)

@@ -61,6 +61,8 @@ _SIGS = {
     "spnet_bn_bwd": (c_int, [P, P, c_long, c_int, P, P, P, P, c_int, P, P, P, P, P, P]),
     "spnet_maxpool3x3s2_add_fwd": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, P, P, P]),
     "spnet_maxpool3x3s2_bwd": (c_int, [P, P, P, c_int, c_int, c_int, c_int, P]),
+    "spnet_maxpool3x3s2_bwd_rows": (c_long, [c_int, c_int, c_int, c_int]),
+    "spnet_maxpool3x3s2_bwd_bnsums": (c_int, [P, P, P, c_int, c_int, c_int, c_int, P, P, P, P, P]),
     "spnet_maxpool3x3s2_valid_fwd": (c_int, [P, P, P, c_int, c_int, c_int, c_int, P]),
     "spnet_maxpool3x3s2_valid_bwd": (c_int, [P, P, P, c_int, c_int, c_int, c_int, P]),
     "spnet_avgpool3x3s1_same": (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, P]),
@@ -78,6 +80,7 @@ _SIGS = {
     "spnet_ellipse_iou": (c_int, [P, P, c_long, c_int, c_int, P, P]),
     "spnet_calc_errors": (c_int, [P, P, c_long, c_int, P, P, P]),
     "spnet_adam_step": (c_int, [P, P, P, P, c_long, c_long, c_float, c_float, c_float, c_float, c_float, c_float, P, P, P, P, P]),
+    "spnet_u8_to_input": (c_int, [P, P, c_long, P]),
     "spnet_minmax": (c_int, [P, c_int, c_long, P, P, P]),
     "spnet_cutout": (c_int, [P, P, P, c_int, c_int, c_int, P, P, P, P]),
     "spnet_saltpepper": (c_int, [P, c_int, c_int, c_int, P, c_int, c_int, P, P, P]),

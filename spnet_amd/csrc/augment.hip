@@ -284,3 +284,39 @@ extern "C" int spnet_warp_affine_fixed(const float* src, float* dst, int N, int 
                      xcol);
   SPNET_RETURN_LAUNCH_STATUS();
 }
+
+// ------------------------------------------------------------------------------------------------
+// Input codec on the device: uint8 grey levels -> the network's float32 input, x = (v / 255 - 0.5) * 2 with every step
+// rounded as numpy rounds it in load_X_one_proc (spnet/utils.py:340-342: `img /= 255.0; img -= 0.5; img *= 2.0` on
+// float32), so a frame converted here is bit-identical to one converted on the host.  Frames then cross PCIe as one
+// byte per pixel instead of four; the pass replaces the device-to-device copy into the plan's input buffer.
+// 16 pixels per thread step: one 16-byte load, four 16-byte stores (+ a scalar tail); both pointers 16-byte aligned.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float u8_to_input(unsigned v) {
+  return __fmul_rn(__fsub_rn(__fdiv_rn((float)v, 255.f), 0.5f), 2.f);
+}
+
+__global__ __launch_bounds__(256) void u8_to_input_kernel(const unsigned char* __restrict__ src8, float* __restrict__ dstf,
+                                                          long n) {
+  const uint4* __restrict__ src = reinterpret_cast<const uint4*>(src8);
+  float4* __restrict__ dst = reinterpret_cast<float4*>(dstf);
+  const long n16 = n / 16;
+  const long gtid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  for (long i = gtid; i < n16; i += (long)gridDim.x * blockDim.x) {
+    const uint4 q = src[i];
+    const unsigned w[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      dst[i * 4 + k] = make_float4(u8_to_input(w[k] & 0xffu), u8_to_input((w[k] >> 8) & 0xffu),
+                                   u8_to_input((w[k] >> 16) & 0xffu), u8_to_input(w[k] >> 24));
+  }
+  const long t = n16 * 16 + gtid;                    // the < 16 pixels past the last whole vector
+  if (t < n) dstf[t] = u8_to_input(src8[t]);
+}
+
+extern "C" int spnet_u8_to_input(const unsigned char* src, float* dst, long n, void* stream) {
+  if (n < 0 || !src || !dst || (((uintptr_t)src | (uintptr_t)dst) & 15)) return (int)hipErrorInvalidValue;
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(u8_to_input_kernel, dim3(spnet_ew_grid((n + 15) / 16, 256)), dim3(256), 0, (hipStream_t)stream, src, dst, n);
+  SPNET_RETURN_LAUNCH_STATUS();
+}

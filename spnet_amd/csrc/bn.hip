@@ -213,15 +213,81 @@ __device__ __forceinline__ int combine_partials(const float* __restrict__ partia
   return c;
 }
 
+// ---------------------------------------------------------------- many partial rows: two stages
+// The entry-flow GEMMs leave thousands of partial rows (M = 372,000 pixels in 32-row tiles: P = 11,625 -- 12 MB), and a
+// finalize grid of C/16 workgroups (8 for 128 channels) walks them in 48 us.  Stage 1 spreads the walk over
+// C/16 x S workgroups: slice s = rows [s*L, (s+1)*L) (the last slice takes the remainder) is combined exactly like
+// combine_partials() and its two double sums are left IN PLACE as (hi, lo) float pairs -- hi in row s*L, lo in row
+// s*L + 1, in the workgroup's own channel columns, which no other workgroup reads -- so no extra workspace is needed
+// and hi + lo carries 48 significant bits.  Stage 2 (combine_slices) adds the S slice sums in the same 16-group order.
+// Fixed order throughout: deterministic, but not the order of the one-stage walk (used from BN_SLICE_MIN_P rows on; the
+// folded finalize kernels handle at most 128 rows and stay bit-identical to the one-stage kernel).
+#define BN_SLICE_MIN_P 1024
+#define BN_SLICES 64
+__global__ __launch_bounds__(256) void bn_slice_partials_kernel(float* __restrict__ partial, int P, int C, int L, int S) {
+  __shared__ double cred[2][16][BN_FIN_CH];
+  const int lane = threadIdx.x & (BN_FIN_CH - 1), g = threadIdx.x >> 4;
+  const int c = blockIdx.x * BN_FIN_CH + lane;
+  const int sl = blockIdx.y;
+  const int p0 = sl * L, p1 = (sl == S - 1) ? P : p0 + L;
+  double s = 0.0, q = 0.0;
+  if (c < C) {
+#pragma unroll 4
+    for (int p = p0 + g; p < p1; p += 16) {
+      s += (double)partial[((long)p * 2 + 0) * C + c];
+      q += (double)partial[((long)p * 2 + 1) * C + c];
+    }
+  }
+  cred[0][g][lane] = s;
+  cred[1][g][lane] = q;
+  __syncthreads();                                   // every read of this workgroup's columns is done
+  if (g != 0 || c >= C) return;
+  double ss = 0.0, qq = 0.0;
+#pragma unroll
+  for (int k = 0; k < 16; ++k) { ss += cred[0][k][lane]; qq += cred[1][k][lane]; }
+  const float sh = (float)ss, qh = (float)qq;
+  partial[((long)p0 * 2 + 0) * C + c] = sh;
+  partial[((long)p0 * 2 + 1) * C + c] = qh;
+  partial[((long)(p0 + 1) * 2 + 0) * C + c] = (float)(ss - (double)sh);
+  partial[((long)(p0 + 1) * 2 + 1) * C + c] = (float)(qq - (double)qh);
+}
+
+// Stage 2: the S slice sums (hi in row s*L, lo in row s*L + 1) -> the channel's two sums, 16 interleaved groups.
+__device__ __forceinline__ int combine_slices(const float* __restrict__ partial, int S, int L, int C,
+                                              double* s_out, double* q_out) {
+  __shared__ double cred2[2][16][BN_FIN_CH];
+  const int lane = threadIdx.x & (BN_FIN_CH - 1), g = threadIdx.x >> 4;
+  const int c = blockIdx.x * BN_FIN_CH + lane;
+  double s = 0.0, q = 0.0;
+  if (c < C) {
+    for (int k = g; k < S; k += 16) {
+      const long r = (long)k * L;
+      s += (double)partial[(r * 2 + 0) * C + c] + (double)partial[((r + 1) * 2 + 0) * C + c];
+      q += (double)partial[(r * 2 + 1) * C + c] + (double)partial[((r + 1) * 2 + 1) * C + c];
+    }
+  }
+  cred2[0][g][lane] = s;
+  cred2[1][g][lane] = q;
+  __syncthreads();
+  if (g != 0 || c >= C) return -1;
+  double ss = 0.0, qq = 0.0;
+#pragma unroll
+  for (int k = 0; k < 16; ++k) { ss += cred2[0][k][lane]; qq += cred2[1][k][lane]; }
+  *s_out = ss;
+  *q_out = qq;
+  return c;
+}
+
 // ---------------------------------------------------------------- finalize (16 channels per workgroup)
 // Forward: partial [P][2][C] -> batch mean / invstd, affine coefficients, moving-stat update.
+// L > 0: `partial` holds P = S slice sums left by bn_slice_partials_kernel (rows of L apart).
 __global__ __launch_bounds__(256) void bn_fwd_finalize_kernel(
     const float* __restrict__ partial, int P, int C, long M, const float* __restrict__ gamma,
     const float* __restrict__ beta, float* __restrict__ moving_mean, float* __restrict__ moving_var,
     float* __restrict__ save_mean, float* __restrict__ save_invstd, float* __restrict__ scale,
-    float* __restrict__ shift, float eps, float momentum) {
+    float* __restrict__ shift, float eps, float momentum, int L) {
   double s, q;
-  const int c = combine_partials(partial, P, C, &s, &q);
+  const int c = L > 0 ? combine_slices(partial, P, L, C, &s, &q) : combine_partials(partial, P, C, &s, &q);
   if (c < 0) return;
   const BnChannelStats st = bn_channel_stats(s, q, M, gamma[c], beta[c], eps);
   save_mean[c] = st.mean;
@@ -643,7 +709,7 @@ extern "C" int spnet_bn_fwd_train(const float* x, long M, int C, const float* ga
   launch_partial<0>(x, nullptr, M, C, nullptr, nullptr, nullptr, nullptr, 0, workspace, parts, st);
   hipLaunchKernelGGL(bn_fwd_finalize_kernel, dim3((C + BN_FIN_CH - 1) / BN_FIN_CH), dim3(256), 0, st, workspace, parts,
                      C, M, gamma, beta, moving_mean, moving_var, save_mean, save_invstd, scale_shift,
-                     scale_shift + C, eps, momentum);
+                     scale_shift + C, eps, momentum, 0);
   launch_apply(x, M, C, scale_shift, scale_shift + C, act, residual, res_bcast, y, st);
   SPNET_RETURN_LAUNCH_STATUS();
 }
@@ -705,9 +771,19 @@ extern "C" int spnet_bn_finalize_fwd(const float* partial, int P, long M, int C,
                                      const float* beta, float* moving_mean, float* moving_var,
                                      float* save_mean, float* save_invstd, float* scale_shift, float eps,
                                      float momentum, void* stream) {
-  hipLaunchKernelGGL(bn_fwd_finalize_kernel, dim3((C + BN_FIN_CH - 1) / BN_FIN_CH), dim3(256), 0,
+  const unsigned gx = (C + BN_FIN_CH - 1) / BN_FIN_CH;
+  if (P >= BN_SLICE_MIN_P) {     // `partial` is scratch of the caller: the slice sums are left in its own rows
+    const int L = P / BN_SLICES, S = BN_SLICES;
+    hipLaunchKernelGGL(bn_slice_partials_kernel, dim3(gx, S), dim3(256), 0, (hipStream_t)stream,
+                       const_cast<float*>(partial), P, C, L, S);
+    hipLaunchKernelGGL(bn_fwd_finalize_kernel, dim3(gx), dim3(256), 0, (hipStream_t)stream, partial, S, C, M, gamma,
+                       beta, moving_mean, moving_var, save_mean, save_invstd, scale_shift, scale_shift + C, eps,
+                       momentum, L);
+    SPNET_RETURN_LAUNCH_STATUS();
+  }
+  hipLaunchKernelGGL(bn_fwd_finalize_kernel, dim3(gx), dim3(256), 0,
                      (hipStream_t)stream, partial, P, C, M, gamma, beta, moving_mean, moving_var, save_mean,
-                     save_invstd, scale_shift, scale_shift + C, eps, momentum);
+                     save_invstd, scale_shift, scale_shift + C, eps, momentum, 0);
   SPNET_RETURN_LAUNCH_STATUS();
 }
 
@@ -745,9 +821,11 @@ extern "C" int spnet_bn_finalize_apply(const float* partial, int P, const float*
                        rps, chunks);
     SPNET_RETURN_LAUNCH_STATUS();
   }
-  hipLaunchKernelGGL(bn_fwd_finalize_kernel, dim3((C + BN_FIN_CH - 1) / BN_FIN_CH), dim3(256), 0, st, partial, P, C, M,
-                     gamma, beta, moving_mean, moving_var, save_mean, save_invstd, scale_shift, scale_shift + C, eps,
-                     momentum);
+  {     // many partial rows: the two-stage finalize of spnet_bn_finalize_fwd
+    const int rc = spnet_bn_finalize_fwd(partial, P, M, C, gamma, beta, moving_mean, moving_var, save_mean, save_invstd,
+                                         scale_shift, eps, momentum, stream);
+    if (rc) return rc;
+  }
   launch_apply(x, M, C, scale_shift, scale_shift + C, act, residual, 0, y, st);
   SPNET_RETURN_LAUNCH_STATUS();
 }

@@ -108,7 +108,24 @@ __global__ __launch_bounds__(256) void dw3x3_tile_fwd_kernel(const float* __rest
   const int c2 = c40 * 2 + l2;                       // channel-pair index
   float2 sc = make_float2(1.f, 1.f), sh = make_float2(0.f, 0.f);
   const bool affine = in_scale != nullptr || fin.partial != nullptr;
+  // With the finalize prologue the halo tile is fetched FIRST, into registers (the raw tensor does not depend on the
+  // statistics): its global loads are in flight while the partial rows are fetched and combined, instead of
+  // starting behind two barriers and a double-precision chain (the 12x16x728 planes: 16.1 us with the fetch behind
+  // the prologue).  The tile buffer is the prologue's scratch, so the values wait in registers until it is dead.
+  constexpr int TILE_F4 = (TH + 2) * PW * CC4, NPRE = (TILE_F4 + 255) / 256;
+  float4 pre[NPRE];
   if (fin.partial) {
+#pragma unroll
+    for (int i = 0; i < NPRE; ++i) {
+      const int idx = tid + i * 256;
+      const int l = idx % CC4, p = idx / CC4;
+      const int pw = p % PW, ph = p / PW;
+      const int h = h0 - 1 + ph, w = w0 - 1 + pw, c4 = c40 + l;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (idx < TILE_F4 && h >= 0 && h < H && w >= 0 && w < W && c4 < c4n)
+        v = *reinterpret_cast<const float4*>(in + ibase + ((long)h * W + w) * C + c4 * 4);
+      pre[i] = v;
+    }
     // (the tile buffer doubles as reduction scratch: 2*16*NCH doubles + 2*NCH floats fit every tile shape)
     constexpr int NCH = CC4 * 4, GR = 256 / NCH;     // channels of this workgroup, thread groups per channel
     static_assert(2 * 16 * NCH * 8 + 2 * NCH * 4 <= (TH + 2) * PW * CC4 * 16, "reduction scratch inside the tile");
@@ -149,8 +166,12 @@ __global__ __launch_bounds__(256) void dw3x3_tile_fwd_kernel(const float* __rest
       sh = make_float2(ssh[NCH + l2 * 2], ssh[NCH + l2 * 2 + 1]);
     }
     __syncthreads();                                 // scratch is dead: the tile may be staged over it
+#pragma unroll
+    for (int i = 0; i < NPRE; ++i)
+      if (tid + i * 256 < TILE_F4) tile[tid + i * 256] = pre[i];
+  } else {
+    dw_stage_tile<CC4, TW, TH>(tile, in, ibase, h0, w0, c40, H, W, C, c4n, tid);
   }
-  dw_stage_tile<CC4, TW, TH>(tile, in, ibase, h0, w0, c40, H, W, C, c4n, tid);
   __syncthreads();
   if (c2 * 2 >= C) return;
   const float2* t2 = reinterpret_cast<const float2*>(tile);

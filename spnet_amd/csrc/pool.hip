@@ -102,6 +102,91 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const float* __restric
   }
 }
 
+// The same data gradient, plus the BatchNorm-backward sums of the layer whose (never materialised) output was pooled:
+// dx IS dL/d(BN output), so sum dx and sum dx * xhat(yp) are accumulated while dx is produced -- one extra read of
+// yp instead of a stand-alone reduction pass that reads dx AND yp again.  blockDim = (CL, 256/CL): x over channel
+// quads, y over pixels; a thread keeps its channel quad, so its two float4 sums stay in registers.  One partial
+// row [2][C] per grid row, fixed order (rows of the thread block in y order).
+__global__ __launch_bounds__(256) void maxpool_bwd_bnsums_kernel(const float* __restrict__ dy,
+                                                                 const uint32_t* __restrict__ idx4,
+                                                                 float* __restrict__ dx, int Bn, int H, int W,
+                                                                 int C, int OH, int OW, int pt, int pl,
+                                                                 const float* __restrict__ yp,
+                                                                 const float* __restrict__ mean,
+                                                                 const float* __restrict__ invstd,
+                                                                 float* __restrict__ partial) {
+  extern __shared__ __attribute__((aligned(16))) float4 pred4[];   // [blockDim.y][2][blockDim.x]
+  const int c4n = C >> 2;
+  const int c4 = blockIdx.x * blockDim.x + threadIdx.x;
+  const bool active = c4 < c4n;
+  float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0;
+  if (active) {
+    const float4 mu = *reinterpret_cast<const float4*>(mean + c4 * 4);
+    const float4 is = *reinterpret_cast<const float4*>(invstd + c4 * 4);
+    const long npix = (long)Bn * H * W;
+    for (long r = (long)blockIdx.y * blockDim.y + threadIdx.y; r < npix; r += (long)gridDim.y * blockDim.y) {
+      const int w = (int)(r % W);
+      long t = r / W;
+      const int h = (int)(t % H);
+      const int b = (int)(t / H);
+      const float4 v = *reinterpret_cast<const float4*>(yp + r * C + c4 * 4);
+      float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+      const int oh_lo = max(0, (h + pt - 2 + 1) >> 1), oh_hi = min(OH - 1, (h + pt) >> 1);
+      const int ow_lo = max(0, (w + pl - 2 + 1) >> 1), ow_hi = min(OW - 1, (w + pl) >> 1);
+      for (int oh = oh_lo; oh <= oh_hi; ++oh) {
+        const uint32_t kh = h - (oh * 2 - pt);
+        for (int ow = ow_lo; ow <= ow_hi; ++ow) {
+          const uint32_t tap = kh * 3 + (w - (ow * 2 - pl));
+          const long o = (((long)b * OH + oh) * OW + ow) * c4n + c4;
+          const uint32_t id = idx4[o];
+          const float4 g = *reinterpret_cast<const float4*>(dy + o * 4);
+          if ((id & 0xffu) == tap) s.x += g.x;
+          if (((id >> 8) & 0xffu) == tap) s.y += g.y;
+          if (((id >> 16) & 0xffu) == tap) s.z += g.z;
+          if ((id >> 24) == tap) s.w += g.w;
+        }
+      }
+      *reinterpret_cast<float4*>(dx + r * C + c4 * 4) = s;
+      s0.x += s.x; s0.y += s.y; s0.z += s.z; s0.w += s.w;
+      s1.x = fmaf(s.x, (v.x - mu.x) * is.x, s1.x); s1.y = fmaf(s.y, (v.y - mu.y) * is.y, s1.y);
+      s1.z = fmaf(s.z, (v.z - mu.z) * is.z, s1.z); s1.w = fmaf(s.w, (v.w - mu.w) * is.w, s1.w);
+    }
+  }
+  const int bx = blockDim.x, by = blockDim.y;
+  pred4[(threadIdx.y * 2 + 0) * bx + threadIdx.x] = s0;
+  pred4[(threadIdx.y * 2 + 1) * bx + threadIdx.x] = s1;
+  __syncthreads();
+  if (threadIdx.y == 0 && active) {
+    for (int q = 0; q < 2; ++q) {
+      float4 sm = pred4[q * bx + threadIdx.x];
+      for (int y = 1; y < by; ++y) {
+        const float4 u = pred4[(y * 2 + q) * bx + threadIdx.x];
+        sm.x += u.x; sm.y += u.y; sm.z += u.z; sm.w += u.w;
+      }
+      *reinterpret_cast<float4*>(partial + ((long)blockIdx.y * 2 + q) * C + c4 * 4) = sm;
+    }
+  }
+}
+
+static int pool_chan_lanes(int c4n) {
+  int cl = 8;
+  while (cl < c4n && cl < 64) cl <<= 1;
+  return cl;
+}
+
+// partial rows spnet_maxpool3x3s2_bwd_bnsums leaves for a [B,H,W,C] input: at most 128 (the BatchNorm backward then
+// runs its one-launch finalize + apply form), about eight workgroups per CU
+extern "C" long spnet_maxpool3x3s2_bwd_rows(int B, int H, int W, int C) {
+  const int cl = pool_chan_lanes(C / 4), by = 256 / cl;
+  const int gx = (C / 4 + cl - 1) / cl;
+  long gy = ((long)B * H * W + (long)by * 8 - 1) / ((long)by * 8);
+  long cap = 2048 / gx;
+  if (cap > 128) cap = 128;
+  if (cap < 1) cap = 1;
+  if (gy > cap) gy = cap;
+  return gy < 1 ? 1 : gy;
+}
+
 __global__ __launch_bounds__(256) void avgpool2_fwd_kernel(const float* __restrict__ x,
                                                            float* __restrict__ y, int Bn, int H, int W,
                                                            int C, int OH, int OW) {
@@ -167,6 +252,24 @@ extern "C" int spnet_maxpool3x3s2_bwd(const float* dy, const uint32_t* idx4, flo
   const long total = (long)B * H * W * (C / 4);
   hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(spnet_ew_grid(total, 256)), dim3(256), 0,
                      (hipStream_t)stream, dy, idx4, dx, B, H, W, C, OH, OW, pt, pl);
+  SPNET_RETURN_LAUNCH_STATUS();
+}
+
+// spnet_maxpool3x3s2_bwd that also emits the backward sums (sum dx, sum dx * xhat) of the BatchNorm whose
+// pre-normalisation tensor is yp [B,H,W,C] (mean / invstd saved by its forward): partial[rows][2][C],
+// rows = spnet_maxpool3x3s2_bwd_rows(B,H,W,C).  Replaces the TF MaxPoolGrad + the reduction half of the fused
+// BatchNorm gradient behind block{2,3,4,13}_pool of keras.applications.Xception (call site spnet/models.py:357-359).
+extern "C" int spnet_maxpool3x3s2_bwd_bnsums(const float* dy, const uint32_t* idx4, float* dx, int B, int H, int W,
+                                             int C, const float* yp, const float* mean, const float* invstd,
+                                             float* partial, void* stream) {
+  if ((C & 3) || !yp || !mean || !invstd || !partial) return (int)hipErrorInvalidValue;
+  int OH, OW, pt, pl;
+  same_pool_geom(H, &OH, &pt);
+  same_pool_geom(W, &OW, &pl);
+  const int cl = pool_chan_lanes(C / 4), by = 256 / cl;
+  dim3 grid((C / 4 + cl - 1) / cl, (unsigned)spnet_maxpool3x3s2_bwd_rows(B, H, W, C)), block(cl, by);
+  hipLaunchKernelGGL(maxpool_bwd_bnsums_kernel, grid, block, (size_t)by * 2 * cl * sizeof(float4), (hipStream_t)stream,
+                     dy, idx4, dx, B, H, W, C, OH, OW, pt, pl, yp, mean, invstd, partial);
   SPNET_RETURN_LAUNCH_STATUS();
 }
 

@@ -334,6 +334,8 @@ class Engine:
         self.defer_mid_wgrad = os.environ.get("SPNET_DEFER_WGRAD", "1") != "0"
         # BatchNorm finalize kernels folded into their consumers where the statistics arrive as <= 128 partial rows
         self.bn_fold = os.environ.get("SPNET_BN_FOLD", "1") != "0"
+        # dev toggle: BatchNorm backward sums from the max-pool backward pass (StridedBlock) instead of a reduction pass
+        self.pool_stats = os.environ.get("SPNET_POOL_STATS", "1") != "0"
         # pointwise weight gradients on a side stream (joined before Adam); SPNET_OVERLAP_WGRAD=0: one stream
         self.overlap_wgrad = os.environ.get("SPNET_OVERLAP_WGRAD", "1") != "0"
         # Optional: capture the single-GPU train step as a hipGraph after one eager step.  Off by default:
@@ -1489,6 +1491,12 @@ class StridedBlock(Node):
             self.blend = self.pwr.blend
             self.dyr = eng.new(B, OH, OW, c2) if self.blend else None
             self.dpool = eng.new(B, H, W, c2)
+            # the pooling backward produces dL/d(BN output of u2) and, in the same pass, that BatchNorm's two backward
+            # sums (spnet_maxpool3x3s2_bwd_bnsums): u2 then takes the from-partials path, no reduction pass of its own
+            rows = L.spnet_maxpool3x3s2_bwd_rows(B, H, W, c2)
+            self.pool_stats = eng.pool_stats and rows * 2 * c2 <= WS_BNP[1]
+            if self.pool_stats:
+                self.u2.consumer_rows = rows
         else:
             self.idx = None
 
@@ -1518,7 +1526,12 @@ class StridedBlock(Node):
 
     def bwd(self, g):
         e = self.e
-        L.spnet_maxpool3x3s2_bwd(L.ptr(g), L.ptr(self.idx), L.ptr(self.dpool), e.B, self.H, self.W, self.c2, _stream())
+        if self.pool_stats:
+            bn2 = self.u2.bn
+            L.spnet_maxpool3x3s2_bwd_bnsums(L.ptr(g), L.ptr(self.idx), L.ptr(self.dpool), e.B, self.H, self.W, self.c2,
+                                            L.ptr(self.u2.yp), bn2.mean_ptr, bn2.invstd_ptr, e.ws_ptr(WS_BNP), _stream())
+        else:
+            L.spnet_maxpool3x3s2_bwd(L.ptr(g), L.ptr(self.idx), L.ptr(self.dpool), e.B, self.H, self.W, self.c2, _stream())
         if self.blend:
             self.bnr.coeffs_full(self.yr, g)
             self.pwr.bwd_blend(self.xs, g, self.yr, self.bnr, self.dyr, self.dxs)

@@ -132,22 +132,28 @@ def build_Y(total_load, meta_file_list, img_file_list, pred_grid=[6, 6, 2], set_
 
 
 # ----------------------------------------------------------------------------- frames
-def _load_one(force_dim, grayscale, filename):
+def _load_one(force_dim, grayscale, filename, as_uint8=False):
     img = Image.open(filename).convert("RGB")
     if force_dim is not None:
         img = img.resize((force_dim, force_dim), Image.LANCZOS)     # PIL.Image.ANTIALIAS of the reference
+    if as_uint8:           # grey levels as decoded (channel 0); Model.predict scales them on the device
+        return np.asarray(img, dtype=np.uint8)[:, :, 0:1]
     arr = np.asarray(img, dtype=np.float32)
     arr = (arr / 255.0 - 0.5) * 2.0
     return arr[:, :, 0:1] if grayscale else arr
 
 
-def build_X(total_load, img_file_list, force_dim=224, grayscale=False):
-    """PNG -> X float32 [N,H,W,C] scaled to [-1,1]; channel 0 only when grayscale (utils.py:325-421)."""
+def build_X(total_load, img_file_list, force_dim=224, grayscale=False, as_uint8=False):
+    """PNG -> X float32 [N,H,W,C] scaled to [-1,1]; channel 0 only when grayscale (utils.py:325-421).
+    as_uint8 (additive, grayscale only): keep the decoded grey levels, uint8 [N,H,W,1]; Model.predict applies the
+    same scaling on the device (bit-identical), and the frames cross PCIe as bytes."""
     print("      Reading images and assigning as input X...")
-    first = _load_one(force_dim, grayscale, img_file_list[0])
+    if as_uint8 and not grayscale:
+        raise ValueError("as_uint8 is for grayscale input (model_type 'big' / 'monolithic')")
+    first = _load_one(force_dim, grayscale, img_file_list[0], as_uint8)
     img_dims = first.shape
-    X = np.zeros((total_load,) + img_dims, dtype=cf.dtype)
-    worker = partial(_load_one, force_dim, grayscale)
+    X = np.zeros((total_load,) + img_dims, dtype=np.uint8 if as_uint8 else cf.dtype)
+    worker = partial(_load_one, force_dim, grayscale, as_uint8=as_uint8)
     nproc = min(cpu_count(), max(1, total_load // 64))
     if nproc > 1:
         # forked workers are only safe while this process has not initialised the GPU (train_spnet.py evaluates and

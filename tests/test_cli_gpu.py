@@ -47,3 +47,8 @@ def test_train_evaluate_predict_cli(tmp_path):
     assert "FPS = " in out
     csv = (work / "logs" / "Predicting" / "hawley_spnet.csv").read_text().strip().splitlines()
     assert len(csv) >= 16 and all(len(l.split(",")) == 7 for l in csv)
+    # the same predictions from uint8 frames scaled on the device (additive flag): identical CSV
+    out = run([os.path.join(ROOT, "predict_spnet.py"), "-w", "final_weights.hdf5", "-d", str(data / "Val"), "-b", "8",
+               "-l", "logs/PredictingU8/", "--u8_frames"], str(work))
+    assert "FPS = " in out
+    assert (work / "logs" / "PredictingU8" / "hawley_spnet.csv").read_text().strip().splitlines() == csv

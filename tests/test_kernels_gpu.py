@@ -304,6 +304,40 @@ def test_batchnorm_finalize_folded_into_the_apply_pass(L, M, C, P, act, res):
         assert torch.equal(a, b)
 
 
+@pytest.mark.parametrize("P,C", [(11625, 128), (1024, 64), (2961, 256), (1031, 36), (1500, 728)])
+def test_batchnorm_finalize_from_many_partial_rows(L, P, C):
+    """>= 1,024 partial rows (the entry flow's GEMM epilogues leave up to 11,625) take the two-stage finalize: slice sums
+    left in place as (hi, lo) float pairs, then combined.  Against the float64 sums of the same rows; the partial buffer
+    is the caller's scratch and may be overwritten.  A second run from a fresh copy gives the same bits."""
+    rs = np.random.RandomState(P + C)
+    M = 32 * P
+    part_h = (rs.randn(P, 2, C) * 3).astype(np.float32)
+    part_h[:, 1] = np.abs(part_h[:, 1]) * 40 + 10
+    s, q = part_h[:, 0].astype(np.float64).sum(0), part_h[:, 1].astype(np.float64).sum(0)
+    mu = s / M
+    var = np.maximum(q / M - mu * mu, 0.0)
+    gamma, beta = dev(rs.rand(C) + 0.5), dev(rs.randn(C) * 0.3)
+    runs = []
+    for _ in range(2):
+        part = dev(part_h)
+        mm, mv = dev(np.full(C, 0.25)), dev(np.full(C, 0.75))
+        save, ss = torch.full((2 * C,), float("nan"), device="cuda"), torch.full((2 * C,), float("nan"), device="cuda")
+        L.spnet_bn_finalize_fwd(part.data_ptr(), P, M, C, gamma.data_ptr(), beta.data_ptr(), mm.data_ptr(), mv.data_ptr(),
+                                save.data_ptr(), save[C:].data_ptr(), ss.data_ptr(), 1e-3, 0.99, st())
+        torch.cuda.synchronize()
+        runs.append((save, ss, mm, mv))
+    save, ss, mm, mv = runs[0]
+    close(save[:C], mu, rtol=2e-7, atol=1e-7 * np.abs(mu).max())
+    close(save[C:], 1 / np.sqrt(var + 1e-3), rtol=2e-7, atol=0)
+    sc = gamma.cpu().double().numpy() / np.sqrt(var + 1e-3)
+    close(ss[:C], sc, rtol=3e-7, atol=0)
+    close(ss[C:], beta.cpu().double().numpy() - mu * sc, rtol=1e-6, atol=1e-6)
+    close(mm, 0.99 * 0.25 + 0.01 * mu, rtol=1e-6, atol=1e-7)
+    close(mv, 0.99 * 0.75 + 0.01 * var * M / (M - 1), rtol=1e-6, atol=1e-7)
+    for a, b in zip(*runs):
+        assert torch.equal(a, b)
+
+
 @pytest.mark.parametrize("M,C", [(6144, 728), (1536, 1536), (500, 36)])
 def test_batchnorm_backward_from_partial_sums(L, M, C):
     """spnet_bn_bwd_from_partials against the closed form (float64), through BOTH of its paths: the one-launch form
@@ -487,6 +521,21 @@ def test_maxpool_add(L, B, H, W, C):
     dxd = torch.empty_like(xd)
     L.spnet_maxpool3x3s2_bwd(dyd.data_ptr(), idx.data_ptr(), dxd.data_ptr(), B, H, W, C, st())
     close(dxd, x.grad, rtol=1e-6, atol=1e-6)
+    # the same gradient with the BatchNorm-backward sums of the pooled layer taken in the same pass
+    rows = L.spnet_maxpool3x3s2_bwd_rows(B, H, W, C)
+    assert 1 <= rows <= 128
+    yp = dev(rs.randn(B, H, W, C))
+    mu, istd = dev(rs.randn(C) * 0.2), dev(rs.rand(C) + 0.5)
+    part = torch.full((rows, 2, C), float("nan"), device="cuda")
+    dx2 = torch.full_like(xd, float("nan"))
+    L.spnet_maxpool3x3s2_bwd_bnsums(dyd.data_ptr(), idx.data_ptr(), dx2.data_ptr(), B, H, W, C, yp.data_ptr(), mu.data_ptr(),
+                                    istd.data_ptr(), part.data_ptr(), st())
+    assert torch.equal(dx2, dxd)
+    g64 = dxd.cpu().double().reshape(-1, C)
+    xh = (yp.cpu().double().reshape(-1, C) - mu.cpu().double()) * istd.cpu().double()
+    sums = part.sum(0).cpu()
+    close(sums[0], g64.sum(0), rtol=1e-4, atol=1e-4 * np.sqrt(B * H * W))
+    close(sums[1], (g64 * xh).sum(0), rtol=1e-4, atol=2e-4 * np.sqrt(B * H * W))
 
 
 @pytest.mark.parametrize("C", [1, 3])

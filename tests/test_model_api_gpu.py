@@ -236,3 +236,33 @@ def test_compound_head_model(tmp_path):
     again.set_weights([a * 0 for a in w])
     z = again.predict(X.numpy(), batch_size=B)
     assert np.allclose(z[:, 6::8], 0.5) and float(np.abs(np.delete(z, np.s_[6::8], axis=1)).max()) < 1e-3
+
+
+def test_uint8_frames_are_scaled_on_the_device_bit_for_bit():
+    """spnet_u8_to_input == the host codec's scaling (utils.py:340-342: /255, -0.5, *2 on float32), for every grey
+    level and for lengths with a scalar tail; Model.predict over uint8 frames (a quarter of the PCIe bytes) ==
+    Model.predict over the host-converted float frames, bit for bit, including a ragged last batch."""
+    import torch
+    from spnet_amd import _lib as L
+    from spnet_amd import fake_espi as F
+    from spnet_amd import models as M
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    rs = np.random.RandomState(9)
+    for n in (256, 16, 5, 331 * 331 * 3, 4099):
+        u = np.arange(n, dtype=np.int64) % 256 if n == 256 else rs.randint(0, 256, n)
+        u = u.astype(np.uint8)
+        want = F.to_network_input(u.reshape(1, 1, n))[0, 0, :, 0]
+        ud = torch.from_numpy(u).cuda()
+        out = torch.full((n,), float("nan"), device="cuda")
+        L.spnet_u8_to_input(ud.data_ptr(), out.data_ptr(), n, torch.cuda.current_stream().cuda_stream)
+        assert np.array_equal(out.cpu().numpy(), want)
+    H, W = 64, 96
+    U = rs.randint(0, 256, (11, H, W)).astype(np.uint8)
+    model = M.Model((H, W, 1), Y0size=576, seed=5)
+    y_f = model.predict(F.to_network_input(U), batch_size=4)
+    y_u = model.predict(U, batch_size=4)
+    y_u2 = model.predict_u8(U[..., None], batch_size=4)
+    assert np.array_equal(y_f, y_u) and np.array_equal(y_u, y_u2)
+    with pytest.raises(TypeError):
+        model.predict_u8(U.astype(np.float32))

@@ -13,7 +13,7 @@ TAG=$1; COMMIT=${2:-unknown}
 OUT=gpurun_out/profiles_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
-COMMON="--no-cpu-baseline --sustained-seconds 0 --pool 512"
+COMMON="--no-cpu-baseline --no-secondary --sustained-seconds 0 --pool 512"
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_$TAG -- python3 bench.py --steps 5 --warmup 2 --no-overlap $COMMON \
     > $OUT/${TAG}_bench_no_overlap_under_rocprof.json 2> gpurun_out/prof_$TAG.err
 S=$(ls gpurun_out/prof_$TAG/*/*_kernel_stats.csv | head -1); cp $S $OUT/${TAG}_bench_no_overlap_kernel_stats.csv
