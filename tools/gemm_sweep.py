@@ -75,6 +75,19 @@ def main():
             print("blend %-5s M=%-6d N=%-4d K=%-4d | plain gemm %6.1f us | blend+dy_out %6.1f | blend only %6.1f | finalize+apply %6.1f | finalize only %5.1f"
                   % (name, M, N, K, plain, blend, blend0, apply_, fin), flush=True)
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "nsweep":
+        # Does a narrower last column tile pay?  The middle-flow GEMM (6144 x 728 x 728) on the 96x64 tile is 64 x 12 = 768
+        # workgroups = exactly 3 per CU, all resident at once; the kernel ends when the busiest CU ends.  N = 704 is
+        # 11 column tiles (704 workgroups: 2.75 per CU -> most CUs still hold 3), N = 640 ten (2.5 per CU), N = 512
+        # eight (exactly 2 per CU).  Time falls with N only where a whole workgroup per CU disappears.
+        for form in ("fwd", "dgrad"):
+            res = []
+            for N in (768, 736, 728, 704, 640, 576, 512):
+                m, n, k = (6144, N, 728) if form == "fwd" else (6144, N, 728)
+                us, tf = run(form, m, n, k, 6, split=1, iters=40)
+                res.append("N=%d %5.1fus (%d wgs)" % (N, us, 64 * ((N + 63) // 64)))
+            print("nsweep %-5s tile 96x64 | %s" % (form, " | ".join(res)), flush=True)
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "ksweep":
         # fixed cost vs per-K-tile cost of the middle-flow GEMM: time(K) = t0 + slope*K
         for form in ("fwd", "dgrad", "wgrad"):
