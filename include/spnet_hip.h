@@ -169,11 +169,11 @@ int spnet_maxpool3x3s2_bwd(const float* dy, const uint32_t* idx4, float* dx, int
                            void* stream);
 /* The same, also emitting the backward sums (sum dx, sum dx*xhat) of the BatchNorm whose un-materialised output was
  * pooled -- yp = its pre-normalisation tensor [B,H,W,C], mean / invstd as saved by its forward -- as
- * partial[rows][2][C], rows = spnet_maxpool3x3s2_bwd_rows(B,H,W,C) <= 128: the gradient path of block{2,3,4,13}_pool +
+ * partial[rows][2][C], rows = spnet_maxpool3x3s2_bwd_rows(B,H,W,C,max_rows) <= max_rows: the gradient path of block{2,3,4,13}_pool +
  * block*_sepconv2_bn in keras.applications.Xception (call site spnet/models.py:357-359) without a reduction pass. */
-long spnet_maxpool3x3s2_bwd_rows(int B, int H, int W, int C);
+long spnet_maxpool3x3s2_bwd_rows(int B, int H, int W, int C, int max_rows);
 int spnet_maxpool3x3s2_bwd_bnsums(const float* dy, const uint32_t* idx4, float* dx, int B, int H, int W, int C,
-                                  const float* yp, const float* mean, const float* invstd, float* partial,
+                                  const float* yp, const float* mean, const float* invstd, float* partial, int rows,
                                   void* stream);
 /* AveragePooling2D(2) of the stem (spnet/models.py:323,337); any C. */
 int spnet_avgpool2_fwd(const float* x, float* y, int B, int H, int W, int C, void* stream);

@@ -61,8 +61,8 @@ _SIGS = {
     "spnet_bn_bwd": (c_int, [P, P, c_long, c_int, P, P, P, P, c_int, P, P, P, P, P, P]),
     "spnet_maxpool3x3s2_add_fwd": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, P, P, P]),
     "spnet_maxpool3x3s2_bwd": (c_int, [P, P, P, c_int, c_int, c_int, c_int, P]),
-    "spnet_maxpool3x3s2_bwd_rows": (c_long, [c_int, c_int, c_int, c_int]),
-    "spnet_maxpool3x3s2_bwd_bnsums": (c_int, [P, P, P, c_int, c_int, c_int, c_int, P, P, P, P, P]),
+    "spnet_maxpool3x3s2_bwd_rows": (c_long, [c_int, c_int, c_int, c_int, c_int]),
+    "spnet_maxpool3x3s2_bwd_bnsums": (c_int, [P, P, P, c_int, c_int, c_int, c_int, P, P, P, P, c_int, P]),
     "spnet_maxpool3x3s2_valid_fwd": (c_int, [P, P, P, c_int, c_int, c_int, c_int, P]),
     "spnet_maxpool3x3s2_valid_bwd": (c_int, [P, P, P, c_int, c_int, c_int, c_int, P]),
     "spnet_avgpool3x3s1_same": (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, P]),

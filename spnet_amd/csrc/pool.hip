@@ -168,21 +168,15 @@ __global__ __launch_bounds__(256) void maxpool_bwd_bnsums_kernel(const float* __
   }
 }
 
-static int pool_chan_lanes(int c4n) {
-  int cl = 8;
-  while (cl < c4n && cl < 64) cl <<= 1;
-  return cl;
-}
-
-// partial rows spnet_maxpool3x3s2_bwd_bnsums leaves for a [B,H,W,C] input: at most 128 (the BatchNorm backward then
-// runs its one-launch finalize + apply form), about eight workgroups per CU
-extern "C" long spnet_maxpool3x3s2_bwd_rows(int B, int H, int W, int C) {
-  const int cl = pool_chan_lanes(C / 4), by = 256 / cl;
-  const int gx = (C / 4 + cl - 1) / cl;
-  long gy = ((long)B * H * W + (long)by * 8 - 1) / ((long)by * 8);
-  long cap = 2048 / gx;
-  if (cap > 128) cap = 128;
-  if (cap < 1) cap = 1;
+// Launch shape of the fused kernel: 8 channel-quad lanes x 32 pixel rows per workgroup (a wave reads 8 rows of
+// 128 contiguous bytes), grid (ceil(C/32), rows).  The number of partial rows doubles as the number of workgroup rows,
+// so it decides the parallelism: at most `max_rows` (128 where the consumer is the one-launch BatchNorm backward, more
+// where only per-channel coefficients are derived from the sums), at least four pixels per thread.
+#define POOL_CL 8
+extern "C" long spnet_maxpool3x3s2_bwd_rows(int B, int H, int W, int C, int max_rows) {
+  const int by = 256 / POOL_CL;
+  long gy = ((long)B * H * W + (long)by * 4 - 1) / ((long)by * 4);
+  long cap = max_rows < 1 ? 1 : max_rows;
   if (gy > cap) gy = cap;
   return gy < 1 ? 1 : gy;
 }
@@ -257,17 +251,18 @@ extern "C" int spnet_maxpool3x3s2_bwd(const float* dy, const uint32_t* idx4, flo
 
 // spnet_maxpool3x3s2_bwd that also emits the backward sums (sum dx, sum dx * xhat) of the BatchNorm whose
 // pre-normalisation tensor is yp [B,H,W,C] (mean / invstd saved by its forward): partial[rows][2][C],
-// rows = spnet_maxpool3x3s2_bwd_rows(B,H,W,C).  Replaces the TF MaxPoolGrad + the reduction half of the fused
+// rows = spnet_maxpool3x3s2_bwd_rows(B,H,W,C,max_rows) (or fewer).  Replaces the TF MaxPoolGrad + the reduction half of the fused
 // BatchNorm gradient behind block{2,3,4,13}_pool of keras.applications.Xception (call site spnet/models.py:357-359).
 extern "C" int spnet_maxpool3x3s2_bwd_bnsums(const float* dy, const uint32_t* idx4, float* dx, int B, int H, int W,
                                              int C, const float* yp, const float* mean, const float* invstd,
-                                             float* partial, void* stream) {
+                                             float* partial, int rows, void* stream) {
   if ((C & 3) || !yp || !mean || !invstd || !partial) return (int)hipErrorInvalidValue;
   int OH, OW, pt, pl;
   same_pool_geom(H, &OH, &pt);
   same_pool_geom(W, &OW, &pl);
-  const int cl = pool_chan_lanes(C / 4), by = 256 / cl;
-  dim3 grid((C / 4 + cl - 1) / cl, (unsigned)spnet_maxpool3x3s2_bwd_rows(B, H, W, C)), block(cl, by);
+  if (rows < 1 || rows > spnet_maxpool3x3s2_bwd_rows(B, H, W, C, rows)) return (int)hipErrorInvalidValue;
+  const int cl = POOL_CL, by = 256 / cl;
+  dim3 grid((C / 4 + cl - 1) / cl, (unsigned)rows), block(cl, by);
   hipLaunchKernelGGL(maxpool_bwd_bnsums_kernel, grid, block, (size_t)by * 2 * cl * sizeof(float4), (hipStream_t)stream,
                      dy, idx4, dx, B, H, W, C, OH, OW, pt, pl, yp, mean, invstd, partial);
   SPNET_RETURN_LAUNCH_STATUS();

@@ -1493,10 +1493,12 @@ class StridedBlock(Node):
             self.dpool = eng.new(B, H, W, c2)
             # the pooling backward produces dL/d(BN output of u2) and, in the same pass, that BatchNorm's two backward
             # sums (spnet_maxpool3x3s2_bwd_bnsums): u2 then takes the from-partials path, no reduction pass of its own
-            rows = L.spnet_maxpool3x3s2_bwd_rows(B, H, W, c2)
+            # (the partial rows are the kernel's workgroup rows: 128 where u2's BatchNorm backward is the one-launch
+            # finalize + apply, 1,024 where u2 only derives blend coefficients from the sums)
+            rows = L.spnet_maxpool3x3s2_bwd_rows(B, H, W, c2, 1024 if self.u2.blend else 128)
             self.pool_stats = eng.pool_stats and rows * 2 * c2 <= WS_BNP[1]
             if self.pool_stats:
-                self.u2.consumer_rows = rows
+                self.u2.consumer_rows = self.pool_rows = rows
         else:
             self.idx = None
 
@@ -1529,7 +1531,8 @@ class StridedBlock(Node):
         if self.pool_stats:
             bn2 = self.u2.bn
             L.spnet_maxpool3x3s2_bwd_bnsums(L.ptr(g), L.ptr(self.idx), L.ptr(self.dpool), e.B, self.H, self.W, self.c2,
-                                            L.ptr(self.u2.yp), bn2.mean_ptr, bn2.invstd_ptr, e.ws_ptr(WS_BNP), _stream())
+                                            L.ptr(self.u2.yp), bn2.mean_ptr, bn2.invstd_ptr, e.ws_ptr(WS_BNP),
+                                            self.pool_rows, _stream())
         else:
             L.spnet_maxpool3x3s2_bwd(L.ptr(g), L.ptr(self.idx), L.ptr(self.dpool), e.B, self.H, self.W, self.c2, _stream())
         if self.blend:
