@@ -620,6 +620,12 @@ __global__ __launch_bounds__(256) void bn_bwd_fused_vec_kernel(
 }
 
 #define BN_FUSE_MAX_P 128
+// ... and, on small tensors (Inception-ResNet-v2 at batch 16: 9,744 x 32..96), up to 512 rows: there the stand-alone
+// finalize is a second dependent launch in front of a pass that is itself at the launch floor, and the 2-16 workgroups
+// of the fused form re-reading 512 x 2 x 32 partial sums each is noise.
+static inline bool bn_fuse_ok(int P, long M, int C) {
+  return P <= BN_FUSE_MAX_P || (P <= 512 && M * C <= (4L << 20));
+}
 // slabs of at least 64 rows, about eight workgroups per CU (their prologues overlap each other's streaming)
 static int bn_fuse_rows_per_slab(long M, int C) {
   const int gx = (C + BN_FUSE_CH - 1) / BN_FUSE_CH;
@@ -738,7 +744,7 @@ extern "C" int spnet_bn_bwd(const float* x, const float* dy, long M, int C, cons
   if ((C & 3) && C > 4) return (int)hipErrorInvalidValue;
   const int parts = bn_parts(M, C);
   launch_partial<1>(x, dy, M, C, save_mean, save_invstd, gamma, beta, act, workspace, parts, st);
-  if (!(C & 3) && parts <= BN_FUSE_MAX_P) {      // few partial rows: finalize folded into the apply pass (same results)
+  if (!(C & 3) && bn_fuse_ok(parts, M, C)) {      // few partial rows: finalize folded into the apply pass (same results)
     const int rps = bn_fuse_rows_per_slab(M, C);
     const int chunks = (C + BN_FUSE_CH - 1) / BN_FUSE_CH;
     dim3 grid((unsigned)(chunks * ((M + rps - 1) / rps)));
@@ -812,7 +818,7 @@ extern "C" int spnet_bn_finalize_apply(const float* partial, int P, const float*
                                        float eps, float momentum, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   if ((C & 3) || P < 1) return (int)hipErrorInvalidValue;
-  if (P <= BN_FUSE_MAX_P) {
+  if (bn_fuse_ok(P, M, C)) {
     const int rps = bn_fuse_rows_per_slab(M, C);
     const int chunks = (C + BN_FUSE_CH - 1) / BN_FUSE_CH;
     dim3 grid((unsigned)(chunks * ((M + rps - 1) / rps)));
@@ -838,7 +844,7 @@ extern "C" int spnet_bn_bwd_from_partials(const float* x, const float* dy, long 
                                           float* dgamma, float* dbeta, float* coeffs, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   if (C & 3) return (int)hipErrorInvalidValue;
-  if (P <= BN_FUSE_MAX_P) {                                  // few partial rows: one launch (bit-identical results)
+  if (bn_fuse_ok(P, M, C)) {                                  // few partial rows: one launch (bit-identical results)
     const int rps = bn_fuse_rows_per_slab(M, C);
     const int chunks = (C + BN_FUSE_CH - 1) / BN_FUSE_CH;
     dim3 grid((unsigned)(chunks * ((M + rps - 1) / rps)));
