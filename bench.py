@@ -194,11 +194,30 @@ def secondary(args):
         step()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    print(json.dumps({"metric": "%s images/sec, %s backbone (secondary measurement)" % (args.mode, args.backbone),
-                      "value": round(b * args.steps / dt, 2), "unit": "images/sec", "n_gpus": 1, "steps": args.steps,
-                      "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3), "dtype": "f32",
-                      "data": "synthetic (uniform noise)",
-                      "config": {"workload": "%s, %s, %dx%d frames, batch %d" % (args.mode, args.backbone, w, h, b)}}))
+    out = {"metric": "%s images/sec, %s backbone (secondary measurement)" % (args.mode, args.backbone),
+           "value": round(b * args.steps / dt, 2), "unit": "images/sec", "n_gpus": 1, "steps": args.steps,
+           "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3), "dtype": "f32",
+           "data": "synthetic (uniform noise)",
+           "config": {"workload": "%s, %s, %dx%d frames, batch %d" % (args.mode, args.backbone, w, h, b)}}
+    if not args.no_kernel_timers:       # the GEMM family of this configuration against the fp32 MFMA peak (HIP events)
+        from spnet_amd.engine import KernelTimer
+        timer = KernelTimer()
+        eng.prof = timer
+        for _ in range(args.steps):
+            step()
+        torch.cuda.synchronize()
+        eng.prof = None
+        tot = timer.totals()
+        if "gemm" in tot:
+            g_n, g_ms, g_flop = tot["gemm"]
+            tf = g_flop / (g_ms * 1e-3) / 1e12
+            out["roofline"] = {"kernel": "fp32 MFMA GEMM family (every convolution / dense layer of this configuration)",
+                               "bound": "mfma", "achieved": round(tf, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                               "frac": round(tf / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                               "launches_per_step": g_n / args.steps, "ms_per_step": round(g_ms / args.steps, 3),
+                               "algorithmic_flops_per_step": round(g_flop / args.steps),
+                               "measured": "HIP events around every GEMM launch during %d extra steps" % args.steps}
+    print(json.dumps(out))
 
 
 def predict_measure(X_pool, dev, steps, warmup, host_frames=1024):

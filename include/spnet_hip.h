@@ -45,6 +45,15 @@ int spnet_gemm_f32_colstats(const float* A, int a_major, int lda, const float* B
 int spnet_gemm_f32_batched(const float* A0, const float* B0, float* C0, const long long* offsets, int nbatch,
                            int a_major, int lda, int b_major, int ldb, int ldc, int M, int N, int K, int tile,
                            void* stream);
+/* ... with every problem's K axis cut into `ksplit` slices: fp32 slabs in `workspace` (nbatch * ksplit * M * N floats),
+ * summed per problem in slice order by one more launch (deterministic).  ldc == N.  For many same-shaped weight
+ * gradients whose outputs are too small to fill the chip even side by side (the repeated blocks of keras
+ * InceptionResNetV2 at batch 16; call site spnet/models.py:357-359).  spnet_gemm_batched_ksplit: the slice count (and
+ * tile id) this library would choose for such a batch; 1 = no split. */
+long spnet_gemm_batched_ksplit(int M, int N, int K, int nbatch, int* tile_out);
+int spnet_gemm_f32_batched_splitk(const float* A0, const float* B0, float* C0, const long long* offsets, int nbatch,
+                                  int a_major, int lda, int b_major, int ldb, int ldc, int M, int N, int K, int tile,
+                                  int ksplit, float* workspace, long ws_floats, void* stream);
 
 /* dX[M,N] = dY[M,K] B[K,N] where dY = a[k]*g + b[k]*yp + c[k] is the output of a BatchNormalization backward
  * (keras BatchNormalization behind every SeparableConv2D / Conv2D of Xception), blended from the incoming gradient

@@ -55,6 +55,9 @@ _SIGS = {
     "spnet_bn_bwd_coeffs_from_partials": (c_int, [c_int, P, c_long, c_int, P, P, P, P, P, P, c_int, P]),
     "spnet_bn_bwd_coeffs": (c_int, [P, P, c_long, c_int, P, P, P, P, P, P, P, c_int, P, P]),
     "spnet_gemm_f32_batched": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P]),
+    "spnet_gemm_batched_ksplit": (c_long, [c_int, c_int, c_int, c_int, P]),
+    "spnet_gemm_f32_batched_splitk": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
+                                              c_int, P, c_long, P]),
     "spnet_bn_ws": (c_long, [c_long, c_int]),
     "spnet_bn_fwd_train": (c_int, [P, c_long, c_int, P, P, P, P, P, P, P, c_int, P, c_int, P, c_float, c_float, P, P]),
     "spnet_bn_fwd_infer": (c_int, [P, c_long, c_int, P, P, P, P, P, c_int, P, c_int, P, c_float, P]),

@@ -123,7 +123,7 @@ __global__ __launch_bounds__(256, (AX && BM * BN <= 96 * 64) ? 3 : 2) void gemm_
                                                        const long long* __restrict__ batch,
                                                        const float* __restrict__ X2,
                                                        const float* __restrict__ coef, int cld,
-                                                       float* __restrict__ dy_out) {
+                                                       float* __restrict__ dy_out, int kslices) {
   static_assert(WM * WN == 4, "4 waves per workgroup");
   static_assert(!AX || AMAJ == SP_K_MAJOR, "blended A operands are K-major");
   constexpr int TM = BM / WM / 16, TN = BN / WN / 16;
@@ -158,18 +158,21 @@ __global__ __launch_bounds__(256, (AX && BM * BN <= 96 * 64) ? 3 : 2) void gemm_
   const int z = lid / tiles_m;
 
   const int m0 = tm * BM, n0 = tn * BN;
-  // batch != NULL: grid.z-like index z selects one of `nsplit` independent problems of identical shape
-  // (operand pointers from the table {A0,B0,C0,A1,B1,C1,...}); otherwise z is the K slice.
-  // (the table holds element OFFSETS from problem 0's operands, which arrive as kernel arguments: pointers
+  // batch != NULL: grid.z-like index z selects one of nsplit / kslices independent problems of identical shape
+  // (operand pointers from the table {A0,B0,C0,A1,B1,C1,...}) and one of its `kslices` K slices; otherwise z is the
+  // K slice.  (the table holds element OFFSETS from problem 0's operands, which arrive as kernel arguments: pointers
   // read from memory would be generic and turn every operand fetch into a flat_load, which also counts on
   // lgkmcnt and serialises with the LDS traffic)
-  const float* __restrict__ A = batch ? A_ + batch[3 * z] : A_;
-  const float* __restrict__ B = batch ? B_ + batch[3 * z + 1] : B_;
-  float* __restrict__ C = batch ? C_ + batch[3 * z + 2] : C_;
-  const int kbeg = batch ? 0 : z * k_chunk;
+  // Batched problems with a K split (kslices > 1) write fp32 slabs: C_ is then the slab workspace, slab z.
+  const int bz = batch ? z / kslices : 0;
+  const int ks = batch ? z - bz * kslices : z;
+  const float* __restrict__ A = batch ? A_ + batch[3 * bz] : A_;
+  const float* __restrict__ B = batch ? B_ + batch[3 * bz + 1] : B_;
+  float* __restrict__ C = (batch && kslices == 1) ? C_ + batch[3 * bz + 2] : C_;
+  const int kbeg = ks * k_chunk;
   const int kend = min(K, kbeg + k_chunk);
   const int nt = (kend - kbeg + BK - 1) / BK;
-  const int zs = batch ? 0 : z;                    // slab index
+  const int zs = batch ? (kslices > 1 ? z : 0) : z;     // slab index
 
   f32x4 acc[TM][TN];
 #pragma unroll
@@ -499,7 +502,7 @@ static int launch_tile(const float* A, int amaj, int lda, const float* B, int bm
                        int ldc, int M, int N, int K, int nsplit, int k_chunk, long slab_stride,
                        const float* bias, float* colstats, const long long* batch, hipStream_t st,
                        int xf = 0, const float* X2 = nullptr, const float* coef = nullptr, int cld = 0,
-                       float* dy_out = nullptr) {
+                       float* dy_out = nullptr, int kslices = 1) {
   const int tm = spnet_cdiv(M, BM), tn = spnet_cdiv(N, BN);
   dim3 grid(tm * tn * nsplit), block(256);
 #ifdef SP_DWMOCK
@@ -508,7 +511,7 @@ static int launch_tile(const float* A, int amaj, int lda, const float* B, int bm
   // the pipelined main loop from 32 K tiles per workgroup (see the kernel's header comment)
   constexpr bool CAN_PIPE = SP_PIPE && (BM / WM / 16) * (BN / WN / 16) < 16;
   const bool pipe = CAN_PIPE && !xf && spnet_cdiv(K < k_chunk ? K : k_chunk, SP_BK) >= SP_PIPE_MIN_TILES;
-#define SP_ARGS A, lda, B, ldb, C, ldc, M, N, K, k_chunk, slab_stride, tm, tn, nsplit, bias, colstats, batch, X2, coef, cld, dy_out
+#define SP_ARGS A, lda, B, ldb, C, ldc, M, N, K, k_chunk, slab_stride, tm, tn, nsplit, bias, colstats, batch, X2, coef, cld, dy_out, kslices
 #define SP_LAUNCH(BKV, AM, BMJ, AXV, PV) \
   hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, BKV, WM, WN, AM, BMJ, AXV, PV>), grid, block, 0, st, SP_ARGS)
 #define SP_LAUNCH_P(AM, BMJ)                                          \
@@ -595,17 +598,37 @@ static int pick_tile(int form, int M, int N, int K, int split_k, bool have_ws, l
   return best;
 }
 
+// out_j[i] = sum over the kslices slabs of problem j, slice order (deterministic); out_j = C0 + offsets[3j + 2].
+__global__ __launch_bounds__(256) void reduce_slabs_batched_kernel(const float* __restrict__ ws, int kslices, long mn,
+                                                                   float* __restrict__ C0,
+                                                                   const long long* __restrict__ offsets) {
+  const int j = blockIdx.y;
+  const long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
+  if (i >= mn) return;
+  const float* p = ws + (long)j * kslices * mn + i;
+  float4 s = *reinterpret_cast<const float4*>(p);
+  for (int k = 1; k < kslices; ++k) {
+    const float4 t = *reinterpret_cast<const float4*>(p + (long)k * mn);
+    s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
+  }
+  *reinterpret_cast<float4*>(C0 + offsets[3 * j + 2] + i) = s;
+}
+
 static int gemm_impl(const float* A, int a_major, int lda, const float* B, int b_major, int ldb, float* C,
                      int ldc, int M, int N, int K, int split_k, float* workspace, long ws_floats,
                      const float* bias, int tile, float* colstats, int* stat_rows, void* stream,
                      const long long* batch = nullptr, int nbatch = 0, int xf = 0, const float* X2 = nullptr,
                      const float* coef = nullptr, int cld = 0, float* dy_out = nullptr) {
   hipStream_t st = (hipStream_t)stream;
-  if (batch) {                       // nbatch whole problems side by side: no K split, no workspace
+  if (batch) {                       // nbatch whole problems side by side; a K split only when the caller asks for one
     if (nbatch < 1 || bias || colstats) return (int)hipErrorInvalidValue;
-    split_k = 1;
-    workspace = nullptr;
-    ws_floats = 0;
+    if (split_k <= 1 || !workspace) {
+      split_k = 1;
+      workspace = nullptr;
+      ws_floats = 0;
+    } else if (ldc != N) {
+      return (int)hipErrorInvalidValue;          // the slab reduce writes dense M x N outputs
+    }
   }
   if (colstats) split_k = 1;   // statistics are taken from complete dot products
   if (M <= 0 || N <= 0 || K <= 0) return (int)hipErrorInvalidValue;
@@ -638,7 +661,7 @@ static int gemm_impl(const float* A, int a_major, int lda, const float* B, int b
   long slab = 0;
   const float* kbias = bias;
   if (nsplit > 1) {
-    if (!workspace || (long)nsplit * M * N > ws_floats) return (int)hipErrorInvalidValue;
+    if (!workspace || (long)nsplit * (batch ? nbatch : 1) * M * N > ws_floats) return (int)hipErrorInvalidValue;
     if (((uintptr_t)workspace) & 15) return (int)hipErrorInvalidValue;
     out = workspace;
     out_ld = N;
@@ -646,22 +669,29 @@ static int gemm_impl(const float* A, int a_major, int lda, const float* B, int b
     kbias = nullptr;
   }
   if (stat_rows) *stat_rows = spnet_cdiv(M, bm);
-  if (batch) nsplit = nbatch;        // the kernel's slice index selects the problem
+  const int kslices = batch ? nsplit : 1;
+  float* C0 = C;
+  if (batch) nsplit = nbatch * kslices;      // the kernel's slice index selects (problem, K slice)
   int rc;
   switch (tile) {
-    case 1: rc = launch_tile<128, 128, 2, 2>(A, a_major, lda, B, b_major, ldb, out, out_ld, M, N, K, nsplit, k_chunk, slab, kbias, colstats, batch, st, xf, X2, coef, cld, dy_out); break;
-    case 2: rc = launch_tile<128, 64, 2, 2>(A, a_major, lda, B, b_major, ldb, out, out_ld, M, N, K, nsplit, k_chunk, slab, kbias, colstats, batch, st, xf, X2, coef, cld, dy_out); break;
-    case 3: rc = launch_tile<64, 64, 2, 2>(A, a_major, lda, B, b_major, ldb, out, out_ld, M, N, K, nsplit, k_chunk, slab, kbias, colstats, batch, st, xf, X2, coef, cld, dy_out); break;
-    case 5: rc = launch_tile<96, 96, 2, 2>(A, a_major, lda, B, b_major, ldb, out, out_ld, M, N, K, nsplit, k_chunk, slab, kbias, colstats, batch, st, xf, X2, coef, cld, dy_out); break;
-    case 6: rc = launch_tile<96, 64, 2, 2>(A, a_major, lda, B, b_major, ldb, out, out_ld, M, N, K, nsplit, k_chunk, slab, kbias, colstats, batch, st, xf, X2, coef, cld, dy_out); break;
-    case 7: rc = launch_tile<64, 128, 2, 2>(A, a_major, lda, B, b_major, ldb, out, out_ld, M, N, K, nsplit, k_chunk, slab, kbias, colstats, batch, st, xf, X2, coef, cld, dy_out); break;
-    case 8: rc = launch_tile<128, 96, 2, 2>(A, a_major, lda, B, b_major, ldb, out, out_ld, M, N, K, nsplit, k_chunk, slab, kbias, colstats, batch, st, xf, X2, coef, cld, dy_out); break;
-    default: rc = launch_tile<32, 128, 1, 4>(A, a_major, lda, B, b_major, ldb, out, out_ld, M, N, K, nsplit, k_chunk, slab, kbias, colstats, batch, st, xf, X2, coef, cld, dy_out); break;
+    case 1: rc = launch_tile<128, 128, 2, 2>(A, a_major, lda, B, b_major, ldb, out, out_ld, M, N, K, nsplit, k_chunk, slab, kbias, colstats, batch, st, xf, X2, coef, cld, dy_out, kslices); break;
+    case 2: rc = launch_tile<128, 64, 2, 2>(A, a_major, lda, B, b_major, ldb, out, out_ld, M, N, K, nsplit, k_chunk, slab, kbias, colstats, batch, st, xf, X2, coef, cld, dy_out, kslices); break;
+    case 3: rc = launch_tile<64, 64, 2, 2>(A, a_major, lda, B, b_major, ldb, out, out_ld, M, N, K, nsplit, k_chunk, slab, kbias, colstats, batch, st, xf, X2, coef, cld, dy_out, kslices); break;
+    case 5: rc = launch_tile<96, 96, 2, 2>(A, a_major, lda, B, b_major, ldb, out, out_ld, M, N, K, nsplit, k_chunk, slab, kbias, colstats, batch, st, xf, X2, coef, cld, dy_out, kslices); break;
+    case 6: rc = launch_tile<96, 64, 2, 2>(A, a_major, lda, B, b_major, ldb, out, out_ld, M, N, K, nsplit, k_chunk, slab, kbias, colstats, batch, st, xf, X2, coef, cld, dy_out, kslices); break;
+    case 7: rc = launch_tile<64, 128, 2, 2>(A, a_major, lda, B, b_major, ldb, out, out_ld, M, N, K, nsplit, k_chunk, slab, kbias, colstats, batch, st, xf, X2, coef, cld, dy_out, kslices); break;
+    case 8: rc = launch_tile<128, 96, 2, 2>(A, a_major, lda, B, b_major, ldb, out, out_ld, M, N, K, nsplit, k_chunk, slab, kbias, colstats, batch, st, xf, X2, coef, cld, dy_out, kslices); break;
+    default: rc = launch_tile<32, 128, 1, 4>(A, a_major, lda, B, b_major, ldb, out, out_ld, M, N, K, nsplit, k_chunk, slab, kbias, colstats, batch, st, xf, X2, coef, cld, dy_out, kslices); break;
   }
   if (rc) return rc;
   if (nsplit > 1 && !batch) {
     const long total4 = (long)M * N / 4;
     launch_reduce_slabs(workspace, nsplit, M, N, C, ldc, bias, st);
+  }
+  if (batch && kslices > 1) {
+    const long mn = (long)M * N;
+    hipLaunchKernelGGL(reduce_slabs_batched_kernel, dim3((unsigned)((mn / 4 + 255) / 256), nbatch), dim3(256), 0, st,
+                       workspace, kslices, mn, C0, batch);
   }
   SPNET_RETURN_LAUNCH_STATUS();
 }
@@ -684,6 +714,35 @@ extern "C" int spnet_gemm_f32_batched(const float* A0, const float* B0, float* C
   if (!offsets || !A0 || !B0 || !C0) return (int)hipErrorInvalidValue;
   return gemm_impl(A0, a_major, lda, B0, b_major, ldb, C0, ldc, M, N, K, 1, nullptr, 0, nullptr, tile, nullptr, nullptr,
                    stream, offsets, nbatch);
+}
+
+// The same with every problem's K axis cut into `ksplit` slices (fp32 slabs in `workspace`, nbatch * ksplit * M * N
+// floats, summed per problem in slice order by one more launch): many same-shaped weight gradients whose outputs are
+// too small to fill the chip even side by side -- the repeated blocks of Inception-ResNet-v2 at batch 16 (10 x block35,
+// 20 x block17, 10 x block8: dW of 288x32 ... 2080x192 over K = 384 ... 9,744 pixels).  ldc == N.
+// spnet_gemm_batched_ksplit: the slice count this library would choose (about three workgroups per CU, slices at
+// least four K tiles deep) and the tile it goes with; 1 = no split.
+extern "C" long spnet_gemm_batched_ksplit(int M, int N, int K, int nbatch, int* tile_out) {
+  const int tile = N <= 64 ? 6 : 5;                  // 96x64 | 96x96
+  int bm, bn;
+  tile_dims(tile, &bm, &bn);
+  const long tiles = (long)spnet_cdiv(M, bm) * spnet_cdiv(N, bn) * (nbatch < 1 ? 1 : nbatch);
+  long want = (768 + tiles - 1) / tiles;
+  long maxk = K / (SP_BK * 4);
+  if (maxk < 1) maxk = 1;
+  if (want > maxk) want = maxk;
+  if (want > 64) want = 64;
+  if (tile_out) *tile_out = tile;
+  return want < 1 ? 1 : want;
+}
+extern "C" int spnet_gemm_f32_batched_splitk(const float* A0, const float* B0, float* C0, const long long* offsets,
+                                             int nbatch, int a_major, int lda, int b_major, int ldb, int ldc, int M,
+                                             int N, int K, int tile, int ksplit, float* workspace, long ws_floats,
+                                             void* stream) {
+  if (!offsets || !A0 || !B0 || !C0) return (int)hipErrorInvalidValue;
+  if (ksplit > 1 && (!workspace || (((uintptr_t)workspace) & 15))) return (int)hipErrorInvalidValue;
+  return gemm_impl(A0, a_major, lda, B0, b_major, ldb, C0, ldc, M, N, K, ksplit > 1 ? ksplit : 1, workspace, ws_floats,
+                   nullptr, tile, nullptr, nullptr, stream, offsets, nbatch);
 }
 
 // dX[M,N] = dY[M,K] B[K,N] where dY is the BatchNorm-backward output dy = a[k]*g + b[k]*yp + c[k], blended from the

@@ -1612,6 +1612,29 @@ class IRv2Backbone(Node):
         self.t_out = cur["x"]
         # one scratch for every conv's patch-matrix gradient (used and consumed on the main stream, op by op)
         self.dcol = eng.new(max_dcol) if (eng.train_capable and max_dcol) else None
+        # Weight gradients of the repeated blocks (10 x block35, 20 x block17, 10 x block8: 17 shapes cover 226 of the
+        # 244 convolutions) are deferred to the end of backward and run as ONE batched GEMM per shape with a K split
+        # (spnet_gemm_f32_batched_splitk) instead of a small split-K GEMM + slab reduce per layer: their operands --
+        # the patch matrix / block input and the BatchNorm-backward output left in the gradient accumulator -- stay
+        # untouched until the next step.  SPNET_IR_BATCH_WGRAD=0: per-layer launches.
+        self.wg_groups, self.wg_ws = [], None
+        if eng.train_capable and os.environ.get("SPNET_IR_BATCH_WGRAD", "1") != "0":
+            by_shape = {}
+            for o in self.ops:
+                if isinstance(o, _IRConv) and not o.small:
+                    by_shape.setdefault((o.K, o.cout, o.M), []).append(o)
+            need = 0
+            for (K, C, M), members in by_shape.items():
+                if len(members) < 2:
+                    continue
+                tile = __import__("ctypes").c_int(0)
+                ksl = int(L.spnet_gemm_batched_ksplit(K, C, M, len(members), __import__("ctypes").addressof(tile)))
+                for o in members:
+                    o.deferred_wgrad = True
+                self.wg_groups.append(dict(members=members, K=K, C=C, M=M, ksl=ksl, tile=tile.value, table=None, key=None))
+                if ksl > 1:
+                    need = max(need, len(members) * ksl * K * C)
+            self.wg_ws = eng.new(need) if need else None
 
     def const_ones(self, C):
         if C not in self.ones:
@@ -1629,7 +1652,41 @@ class IRv2Backbone(Node):
         self.t_out.g = g
         for o in reversed(self.ops):
             o.bwd(self)
+        self.flush_wgrads()
         return self.t_in.g
+
+    def flush_wgrads(self):
+        """The deferred weight gradients, one batched launch (+ one slab reduce) per shape, on the weight-gradient
+        stream.  The operand offset tables live in device memory and are rebuilt only if a buffer address changed."""
+        if not self.wg_groups:
+            return
+        e = self.e
+
+        def run():
+            for g in self.wg_groups:
+                ms = g["members"]
+                a0, b0, c0 = ms[0]._A().data_ptr(), ms[0].out.g.data_ptr(), ms[0].gw.data_ptr()
+                offs = tuple(v for o in ms for v in ((o._A().data_ptr() - a0) // 4, (o.out.g.data_ptr() - b0) // 4,
+                                                     (o.gw.data_ptr() - c0) // 4))
+                if g["key"] != (a0, b0, c0) + offs:
+                    g["key"] = (a0, b0, c0) + offs
+                    g["table"] = torch.tensor(offs, dtype=torch.int64, device=e.dev)
+                K, C, M, nb = g["K"], g["C"], g["M"], len(ms)
+                prof = e.prof
+                t0 = prof.start() if prof is not None else None
+                L.spnet_gemm_f32_batched_splitk(a0, b0, c0, g["table"].data_ptr(), nb, OUT_MAJOR, K, OUT_MAJOR, C, C, K, C, M,
+                                                g["tile"], g["ksl"], L.ptr(self.wg_ws),
+                                                self.wg_ws.numel() if self.wg_ws is not None else 0, _stream())
+                if prof is not None:
+                    prof.stop("gemm", t0, 2.0 * nb * K * C * M, ("AB x%d batched" % nb, K, C, M))
+
+        side = e.wgrad_stream
+        if side is None:
+            run()
+        else:
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                run()
 
 
 def _ir_acc(t, gbuf, eng):
@@ -1654,6 +1711,7 @@ class _IRConv:
         self.M, self.K = B * OH * OW, self.kh * self.kw * cin
         self.direct = (self.kh == 1 and self.kw == 1 and stride == 1)
         self.small = (cin == 3)                      # the first conv: 3 -> 32, 3x3 / stride 2 / valid (stem.hip)
+        self.deferred_wgrad = False                  # set by IRv2Backbone: dW comes out of a batched launch per shape
         self.w = eng.P(cname + "/kernel")
         self.col = None if (self.direct or self.small) else eng.new(self.M, self.K)
         self.col_floats = 0 if (self.direct or self.small) else self.M * self.K
@@ -1727,7 +1785,9 @@ class _IRConv:
         else:
             def wgrad(region):
                 _gemm(self._A(), OUT_MAJOR, self.K, g, OUT_MAJOR, C, self.gw, C, self.K, C, self.M, e, region=region)
-        if side is None:
+        if self.deferred_wgrad:
+            pass                                     # IRv2Backbone.flush_wgrads: g (= dy now) stays as it is until then
+        elif side is None:
             wgrad(WS_GEMM)
         else:           # weight gradient off the data-gradient chain (see Pointwise.bwd)
             side.wait_stream(torch.cuda.current_stream())

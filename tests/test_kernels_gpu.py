@@ -148,6 +148,44 @@ def test_gemm_batched_wgrad_form(L, tile):
             assert torch.equal(one, Cs[b])           # same tile, same k order -> same bits
 
 
+@pytest.mark.parametrize("nb,M,N,K,ksplit", [(5, 72, 136, 700, 3), (10, 288, 32, 9744, 0), (20, 384, 1088, 2240, 0),
+                                             (3, 96, 64, 130, 4), (4, 100, 36, 777, 2)])
+def test_gemm_batched_wgrad_form_with_k_split(L, nb, M, N, K, ksplit):
+    """Many same-shaped weight gradients in one launch with every K axis cut into slices (fp32 slabs + one batched slab
+    reduce): against float64, and against the same problem run alone with the same tile and split (bit-identical below four slices).  ksplit 0 =
+    the slice count the library suggests (spnet_gemm_batched_ksplit; Inception-ResNet-v2's block35 / block17 shapes)."""
+    import ctypes
+    rs = np.random.RandomState(nb + M)
+    tile = ctypes.c_int(0)
+    sugg = int(L.spnet_gemm_batched_ksplit(M, N, K, nb, ctypes.addressof(tile)))
+    assert 1 <= sugg <= 64 and tile.value in (5, 6)
+    ks = ksplit or sugg
+    Xs = [dev(rs.randn(K, M).astype(np.float32)) for _ in range(nb)]
+    Ds = [dev(rs.randn(K, N).astype(np.float32)) for _ in range(nb)]
+    Cs = [torch.full((M, N), float("nan"), device="cuda") for _ in range(nb)]
+    a0, b0, c0 = Xs[0].data_ptr(), Ds[0].data_ptr(), Cs[0].data_ptr()
+    table = torch.tensor([v for b in range(nb) for v in ((Xs[b].data_ptr() - a0) // 4, (Ds[b].data_ptr() - b0) // 4,
+                                                         (Cs[b].data_ptr() - c0) // 4)], dtype=torch.int64, device="cuda")
+    ws = torch.full((nb * ks * M * N,), float("nan"), device="cuda")
+    L.spnet_gemm_f32_batched_splitk(a0, b0, c0, table.data_ptr(), nb, 1, M, 1, N, N, M, N, K, tile.value, ks, ws.data_ptr(),
+                                    ws.numel(), st())
+    ws1 = torch.empty(max(ks, 1) * M * N, device="cuda")
+    for b in (0, nb - 1):
+        want = Xs[b].cpu().double().numpy().T @ Ds[b].cpu().double().numpy()
+        close(Cs[b], want, rtol=2e-5, atol=3e-5 * np.sqrt(K))
+        one = torch.empty(M, N, device="cuda")
+        L.spnet_gemm_f32(Xs[b].data_ptr(), 1, M, Ds[b].data_ptr(), 1, N, one.data_ptr(), N, M, N, K, ks, ws1.data_ptr(),
+                         ws1.numel(), None, tile.value, st())
+        if ks < 4:
+            assert torch.equal(one, Cs[b])           # same tile, same slices, same summation order -> same bits
+        else:                                        # (the single-problem slab reduce adds >= 4 slabs in lane groups)
+            close(Cs[b], one.cpu().double().numpy(), rtol=1e-5, atol=1e-5 * np.sqrt(K))
+    if ks > 1:
+        with pytest.raises(L.HipError):              # workspace too small for the slabs
+            L.spnet_gemm_f32_batched_splitk(a0, b0, c0, table.data_ptr(), nb, 1, M, 1, N, N, M, N, K, tile.value, ks,
+                                            ws.data_ptr(), nb * M * N, st())
+
+
 def test_reduce_rows_with_scratch(L):
     """spnet_reduce_rows_ws: many rows folded through 32 parallel slices (a bias gradient over all pixels)."""
     rs = np.random.RandomState(5)
