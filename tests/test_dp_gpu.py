@@ -81,3 +81,27 @@ def test_two_rank_training_through_train_network(tmp_path):
     assert len(rows) == 2 and all(np.isfinite(float(x.split()[1])) for x in rows)
     sums = [open(str(work / "wsum") + ".%d" % k).read().strip() for k in (0, 1)]
     assert sums[0] == sums[1], sums                         # replicas in lock-step
+
+
+def test_bench_self_launched_two_ranks_on_one_gpu():
+    """`python bench.py --gpus 2` with no launcher around it (the shape of the driver's N = 1 command): the parent starts
+    two ranks itself, both on the one GPU over gloo here, and relays rank 0's single JSON line -- the full
+    data-parallel benchmark step (sharded pools, bucketed all-reduce during backward, 1/world in Adam) at reduced pool
+    and step counts; `n_ranks_seen` is counted by an all-reduce, `value` is the whole job's rate."""
+    import json
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(PYTHONPATH=ROOT, SPNET_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                        "--pool", "128", "--sustained-seconds", "0", "--no-kernel-timers"],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + "\n" + r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["config"]["n_ranks_seen"] == 2 and out["config"]["global_batch"] == 64
+    assert out["config"]["collective_backend"] == "gloo" and out["scaling"] == "weak"
+    assert out["value"] > 0 and np.isfinite(out["config"]["final_loss"])
+    assert "cpu_baseline" not in out and "predict" not in out          # N = 1 only
