@@ -199,6 +199,18 @@ int spnet_avgpool3x3s1_same(const float* in, float* out, int B, int H, int W, in
  * spnet_gemm_f32 on col and the flattened HWIO kernel (1x1 convs skip the patch matrix). */
 int spnet_patches(const float* in, float* out, int B, int H, int W, int C, int KH, int KW, int stride, int same, int backward,
                   void* stream);
+/* Gradient producers that also leave the BatchNorm-backward sums (sum g, sum g*xhat) of the conv2d_bn layer whose output
+ * y = relu(BN(yp)) they differentiate, g masked with y > 0 when relu != 0: partial[rows][2][C], rows <=
+ * spnet_grad_bnsums_rows(pixels, max_rows).  spnet_patches_bwd_bnsums = spnet_patches(backward = 1) + mask + sums (the
+ * consumer is a k x k convolution); spnet_copy_cols_bnsums = one branch of a Concatenate backward (strided column block
+ * -> dense) + mask + sums.  The layer's BatchNorm backward then runs spnet_bn_bwd_from_partials with no activation
+ * (keras InceptionResNetV2 conv2d_bn chains; call site spnet/models.py:357-359). */
+long spnet_grad_bnsums_rows(long npix, int max_rows);
+int spnet_patches_bwd_bnsums(const float* dcol, float* dx, int B, int H, int W, int C, int KH, int KW, int stride, int same,
+                             const float* y, const float* yp, const float* mean, const float* invstd, int relu,
+                             float* partial, int rows, void* stream);
+int spnet_copy_cols_bnsums(const float* src, int lds, float* dst, long M, int C, const float* y, const float* yp,
+                           const float* mean, const float* invstd, int relu, float* partial, int rows, void* stream);
 /* inception_resnet_block: y = x + scale*up (+ ReLU); backward: dx = g*(y>0 if relu), dup = scale*dx. */
 int spnet_resadd(const float* x, const float* up, float* y, long n, float scale, int relu, void* stream);
 int spnet_resadd_bwd(const float* y, const float* g, float* dx, float* dup, long n, float scale, int relu, void* stream);

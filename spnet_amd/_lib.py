@@ -70,6 +70,10 @@ _SIGS = {
     "spnet_maxpool3x3s2_valid_bwd": (c_int, [P, P, P, c_int, c_int, c_int, c_int, P]),
     "spnet_avgpool3x3s1_same": (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, P]),
     "spnet_patches": (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P]),
+    "spnet_grad_bnsums_rows": (c_long, [c_long, c_int]),
+    "spnet_patches_bwd_bnsums": (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P, P, P, c_int, P,
+                                         c_int, P]),
+    "spnet_copy_cols_bnsums": (c_int, [P, c_int, P, c_long, c_int, P, P, P, P, c_int, P, c_int, P]),
     "spnet_resadd": (c_int, [P, P, P, c_long, c_float, c_int, P]),
     "spnet_resadd_bwd": (c_int, [P, P, P, P, c_long, c_float, c_int, P]),
     "spnet_copy_cols": (c_int, [P, c_int, P, c_int, c_long, c_int, c_int, P]),

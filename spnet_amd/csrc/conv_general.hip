@@ -61,6 +61,94 @@ __global__ __launch_bounds__(256) void col2im_kernel(const float* __restrict__ d
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Gradient producers that also leave the BatchNorm-backward sums of the layer whose output they differentiate.
+// A conv2d_bn output y = relu(BN(yp)) of Inception-ResNet-v2 has exactly one consumer: a k x k convolution (its gradient
+// comes out of the adjoint patch gather) or a Concatenate (a column block of the concatenated gradient).  Both passes
+// produce dL/dy element by element; these kernels mask it with the ReLU decision (y > 0) and accumulate, per channel,
+// sum g and sum g * xhat(yp) on the way -- the reduction pass of the BatchNorm backward (read yp and g again, one more
+// dependent launch on the main stream) disappears, and the BatchNorm backward runs from partial rows with no
+// activation left to handle.  blockDim = (8 channel quads, 32 rows); one partial row [2][C] per grid row, fixed order.
+//   MODE 0: g = col2im(dcol)      MODE 1: g = src[r * lds + c] (strided column block)
+// ------------------------------------------------------------------------------------------------
+#define GS_CL 8
+template <int MODE>
+__global__ __launch_bounds__(256) void grad_bnsums_kernel(const float* __restrict__ src, int lds, float* __restrict__ dx,
+                                                          int Bn, int H, int W, int C, int KH, int KW, int s, int pt, int pl,
+                                                          int OH, int OW, const float* __restrict__ y,
+                                                          const float* __restrict__ yp, const float* __restrict__ mean,
+                                                          const float* __restrict__ invstd, int relu,
+                                                          float* __restrict__ partial) {
+  __shared__ __attribute__((aligned(16))) float4 red4[32 * 2 * GS_CL];
+  const int c4n = C >> 2;
+  const int c4 = blockIdx.x * GS_CL + threadIdx.x;
+  const bool active = c4 < c4n;
+  float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0;
+  if (active) {
+    const float4 mu = *reinterpret_cast<const float4*>(mean + c4 * 4);
+    const float4 is = *reinterpret_cast<const float4*>(invstd + c4 * 4);
+    const long npix = (long)Bn * H * W;
+    const long K = (long)KH * KW * C;
+    for (long r = (long)blockIdx.y * 32 + threadIdx.y; r < npix; r += (long)gridDim.y * 32) {
+      float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (MODE == 1) {
+        g = *reinterpret_cast<const float4*>(src + r * lds + c4 * 4);
+      } else {
+        const int w = (int)(r % W);
+        long t = r / W;
+        const int h = (int)(t % H);
+        const int b = (int)(t / H);
+        for (int kh = 0; kh < KH; ++kh) {
+          const int hh = h + pt - kh;
+          if (hh < 0 || hh % s) continue;
+          const int oh = hh / s;
+          if (oh >= OH) continue;
+          for (int kw = 0; kw < KW; ++kw) {
+            const int ww = w + pl - kw;
+            if (ww < 0 || ww % s) continue;
+            const int ow = ww / s;
+            if (ow >= OW) continue;
+            const float4 v = *reinterpret_cast<const float4*>(src + (((long)b * OH + oh) * OW + ow) * K +
+                                                              ((long)kh * KW + kw) * C + c4 * 4);
+            g.x += v.x; g.y += v.y; g.z += v.z; g.w += v.w;
+          }
+        }
+      }
+      const float4 xv = *reinterpret_cast<const float4*>(yp + r * C + c4 * 4);
+      if (relu) {
+        const float4 yv = *reinterpret_cast<const float4*>(y + r * C + c4 * 4);
+        g.x = yv.x > 0.f ? g.x : 0.f; g.y = yv.y > 0.f ? g.y : 0.f;
+        g.z = yv.z > 0.f ? g.z : 0.f; g.w = yv.w > 0.f ? g.w : 0.f;
+      }
+      *reinterpret_cast<float4*>(dx + r * C + c4 * 4) = g;
+      s0.x += g.x; s0.y += g.y; s0.z += g.z; s0.w += g.w;
+      s1.x = fmaf(g.x, (xv.x - mu.x) * is.x, s1.x); s1.y = fmaf(g.y, (xv.y - mu.y) * is.y, s1.y);
+      s1.z = fmaf(g.z, (xv.z - mu.z) * is.z, s1.z); s1.w = fmaf(g.w, (xv.w - mu.w) * is.w, s1.w);
+    }
+  }
+  red4[(threadIdx.y * 2 + 0) * GS_CL + threadIdx.x] = s0;
+  red4[(threadIdx.y * 2 + 1) * GS_CL + threadIdx.x] = s1;
+  __syncthreads();
+  if (threadIdx.y == 0 && active) {
+    for (int q = 0; q < 2; ++q) {
+      float4 sm = red4[q * GS_CL + threadIdx.x];
+      for (int yy = 1; yy < 32; ++yy) {
+        const float4 u = red4[(yy * 2 + q) * GS_CL + threadIdx.x];
+        sm.x += u.x; sm.y += u.y; sm.z += u.z; sm.w += u.w;
+      }
+      *reinterpret_cast<float4*>(partial + ((long)blockIdx.y * 2 + q) * C + c4 * 4) = sm;
+    }
+  }
+}
+
+// partial rows (= workgroup rows) for npix pixels: at most max_rows, at least four pixels per thread
+extern "C" long spnet_grad_bnsums_rows(long npix, int max_rows) {
+  long gy = (npix + 32L * 4 - 1) / (32L * 4);
+  long cap = max_rows < 1 ? 1 : max_rows;
+  if (gy > cap) gy = cap;
+  return gy < 1 ? 1 : gy;
+}
+
 static void conv_geom(int in, int k, int s, int same, int* out, int* before) {
   if (same) {
     *out = (in + s - 1) / s;
@@ -90,6 +178,36 @@ extern "C" int spnet_patches(const float* in, float* out, int B, int H, int W, i
     hipLaunchKernelGGL(col2im_kernel, dim3(spnet_ew_grid(total, 256)), dim3(256), 0, (hipStream_t)stream, in, out, B, H, W,
                        C, KH, KW, stride, pt, pl, OH, OW);
   }
+  SPNET_RETURN_LAUNCH_STATUS();
+}
+
+// spnet_patches(backward = 1) that also masks the gradient with the ReLU of the layer that produced x (y = its output,
+// relu != 0) and leaves that layer's BatchNorm-backward sums: partial[rows][2][C], rows <= spnet_grad_bnsums_rows(B*H*W, .).
+extern "C" int spnet_patches_bwd_bnsums(const float* dcol, float* dx, int B, int H, int W, int C, int KH, int KW, int stride,
+                                        int same, const float* y, const float* yp, const float* mean, const float* invstd,
+                                        int relu, float* partial, int rows, void* stream) {
+  if ((C & 3) || KH < 1 || KW < 1 || (stride != 1 && stride != 2) || !yp || !mean || !invstd || !partial || (relu && !y))
+    return (int)hipErrorInvalidValue;
+  int OH, OW, pt, pl;
+  conv_geom(H, KH, stride, same, &OH, &pt);
+  conv_geom(W, KW, stride, same, &OW, &pl);
+  if (OH < 1 || OW < 1 || rows < 1 || rows > spnet_grad_bnsums_rows((long)B * H * W, rows)) return (int)hipErrorInvalidValue;
+  dim3 grid((C / 4 + GS_CL - 1) / GS_CL, (unsigned)rows), block(GS_CL, 32);
+  hipLaunchKernelGGL(grad_bnsums_kernel<0>, grid, block, 0, (hipStream_t)stream, dcol, 0, dx, B, H, W, C, KH, KW, stride, pt,
+                     pl, OH, OW, y, yp, mean, invstd, relu ? 1 : 0, partial);
+  SPNET_RETURN_LAUNCH_STATUS();
+}
+
+// dst[r][c] = src[r * lds + c] (* ReLU mask), c < C, dense dst -- the Concatenate backward of one branch -- with the same
+// BatchNorm-backward sums of the branch's last layer.
+extern "C" int spnet_copy_cols_bnsums(const float* src, int lds, float* dst, long M, int C, const float* y, const float* yp,
+                                      const float* mean, const float* invstd, int relu, float* partial, int rows,
+                                      void* stream) {
+  if ((C & 3) || (lds & 3) || M < 1 || !yp || !mean || !invstd || !partial || (relu && !y)) return (int)hipErrorInvalidValue;
+  if (rows < 1 || rows > spnet_grad_bnsums_rows(M, rows)) return (int)hipErrorInvalidValue;
+  dim3 grid((C / 4 + GS_CL - 1) / GS_CL, (unsigned)rows), block(GS_CL, 32);
+  hipLaunchKernelGGL(grad_bnsums_kernel<1>, grid, block, 0, (hipStream_t)stream, src, lds, dst, 1, 1, (int)M, C, 1, 1, 1, 0, 0,
+                     1, (int)M, y, yp, mean, invstd, relu ? 1 : 0, partial);
   SPNET_RETURN_LAUNCH_STATUS();
 }
 

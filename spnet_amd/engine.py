@@ -1570,6 +1570,7 @@ class _T:
 
     def __init__(self, buf):
         self.buf, self.g = buf, None
+        self.owner, self.consumers = None, 0      # producing op; number of ops that read the tensor
 
 
 class IRv2Backbone(Node):
@@ -1610,6 +1611,23 @@ class IRv2Backbone(Node):
             self.ops.append(o)
         self.y = cur["x"].buf
         self.t_out = cur["x"]
+        # A conv2d_bn output with ONE consumer that is a k x k convolution or a Concatenate gets its BatchNorm-backward
+        # sums from that consumer's gradient pass (spnet_patches_bwd_bnsums / spnet_copy_cols_bnsums) instead of a
+        # reduction pass of its own (SPNET_IR_FUSE_BNSUMS=0: stand-alone reductions).
+        if eng.train_capable and os.environ.get("SPNET_IR_FUSE_BNSUMS", "1") != "0":
+            for o in self.ops:
+                o.out.owner = o
+            for o in self.ops:
+                for t in o.srcs():
+                    t.consumers += 1
+            for o in self.ops:
+                for t in o.srcs():
+                    p = t.owner
+                    ok = (isinstance(p, _IRConv) and not p.bias and t.consumers == 1 and
+                          ((isinstance(o, _IRConv) and not o.direct and not o.small) or isinstance(o, _IRConcat)))
+                    if ok:
+                        p.sum_rows = int(L.spnet_grad_bnsums_rows(p.M, 128))
+                        p.sum_part = eng.new(p.sum_rows * 2 * p.cout)
         # one scratch for every conv's patch-matrix gradient (used and consumed on the main stream, op by op)
         self.dcol = eng.new(max_dcol) if (eng.train_capable and max_dcol) else None
         # Weight gradients of the repeated blocks (10 x block35, 20 x block17, 10 x block8: 17 shapes cover 226 of the
@@ -1712,6 +1730,7 @@ class _IRConv:
         self.direct = (self.kh == 1 and self.kw == 1 and stride == 1)
         self.small = (cin == 3)                      # the first conv: 3 -> 32, 3x3 / stride 2 / valid (stem.hip)
         self.deferred_wgrad = False                  # set by IRv2Backbone: dW comes out of a batched launch per shape
+        self.sum_rows, self.sum_part = 0, None       # set by IRv2Backbone: my BatchNorm-backward sums come from my consumer
         self.w = eng.P(cname + "/kernel")
         self.col = None if (self.direct or self.small) else eng.new(self.M, self.K)
         self.col_floats = 0 if (self.direct or self.small) else self.M * self.K
@@ -1735,6 +1754,9 @@ class _IRConv:
 
     def _A(self):
         return self.src.buf if self.direct else self.col
+
+    def srcs(self):
+        return [self.src]
 
     def fwd(self, training):
         e, C = self.e, self.cout
@@ -1773,6 +1795,10 @@ class _IRConv:
         e, C, g = self.e, self.cout, self.out.g
         if self.bias:
             L.spnet_reduce_rows_ws(L.ptr(g), self.M, C, L.ptr(self.gb), e.ws_ptr(WS_MISC), WS_MISC[1], _stream())
+        elif self.sum_rows:     # my one consumer left the masked gradient in g and the two sums in sum_part
+            L.spnet_bn_bwd_from_partials(L.ptr(self.yp), L.ptr(g), self.M, C, L.ptr(self.ones), L.ptr(self.beta),
+                                         L.ptr(self.save), self.save[C:].data_ptr(), self.sum_rows, L.ptr(self.sum_part),
+                                         L.ptr(g), L.ptr(self.gscr), L.ptr(self.gbeta), L.ptr(e.small[:3 * C]), _stream())
         else:       # BatchNorm (+ReLU) backward in place on the accumulated gradient; gamma is the constant 1
             L.spnet_bn_bwd(L.ptr(self.yp), L.ptr(g), self.M, C, L.ptr(self.ones), L.ptr(self.beta), L.ptr(self.save),
                            self.save[C:].data_ptr(), ACT_RELU if self.relu else ACT_NONE, L.ptr(g), L.ptr(self.gscr),
@@ -1800,8 +1826,14 @@ class _IRConv:
             _gemm(g, K_MAJOR, C, self.w, K_MAJOR, C, self.dx, self.K, self.M, self.K, C, e)
         else:
             _gemm(g, K_MAJOR, C, self.w, K_MAJOR, C, net.dcol, self.K, self.M, self.K, C, e)
-            L.spnet_patches(L.ptr(net.dcol), L.ptr(self.dx), e.B, self.H, self.W, self.cin, self.kh, self.kw, self.stride,
-                            self.same, 1, _stream())
+            p = self.src.owner
+            if p is not None and getattr(p, "sum_rows", 0):      # + ReLU mask and BatchNorm sums of the producing layer
+                L.spnet_patches_bwd_bnsums(L.ptr(net.dcol), L.ptr(self.dx), e.B, self.H, self.W, self.cin, self.kh, self.kw,
+                                           self.stride, self.same, L.ptr(self.src.buf), L.ptr(p.yp), L.ptr(p.save),
+                                           p.save[p.cout:].data_ptr(), int(p.relu), L.ptr(p.sum_part), p.sum_rows, _stream())
+            else:
+                L.spnet_patches(L.ptr(net.dcol), L.ptr(self.dx), e.B, self.H, self.W, self.cin, self.kh, self.kw,
+                                self.stride, self.same, 1, _stream())
         _ir_acc(self.src, self.dx, e)
 
 
@@ -1817,6 +1849,9 @@ class _IRPool:
             OH, OW = H, W
         self.out = _T(eng.new(B, OH, OW, C))
         self.dx = eng.new(B, H, W, C) if eng.train_capable else None
+
+    def srcs(self):
+        return [self.src]
 
     def fwd(self, training):
         e = self.e
@@ -1837,23 +1872,32 @@ class _IRPool:
 
 class _IRConcat:
     def __init__(self, eng, srcs):
-        self.e, self.srcs = eng, srcs
+        self.e, self.srcs_ = eng, srcs
         B, H, W, _ = srcs[0].buf.shape
         self.cs = [t.buf.shape[-1] for t in srcs]
         self.rows = B * H * W
         self.out = _T(eng.new(B, H, W, sum(self.cs)))
         self.dparts = [eng.new(*t.buf.shape) for t in srcs] if eng.train_capable else None
 
+    def srcs(self):
+        return self.srcs_
+
     def fwd(self, training):
         ct, off = sum(self.cs), 0
-        for t, c in zip(self.srcs, self.cs):
+        for t, c in zip(self.srcs_, self.cs):
             L.spnet_copy_cols(L.ptr(t.buf), c, self.out.buf.data_ptr() + 4 * off, ct, self.rows, c, 0, _stream())
             off += c
 
     def bwd(self, net):
         ct, off, g = sum(self.cs), 0, self.out.g
-        for t, c, d in zip(self.srcs, self.cs, self.dparts):
-            L.spnet_copy_cols(g.data_ptr() + 4 * off, ct, L.ptr(d), c, self.rows, c, 0, _stream())
+        for t, c, d in zip(self.srcs_, self.cs, self.dparts):
+            p = t.owner
+            if p is not None and getattr(p, "sum_rows", 0):      # + ReLU mask and BatchNorm sums of the branch's last layer
+                L.spnet_copy_cols_bnsums(g.data_ptr() + 4 * off, ct, L.ptr(d), self.rows, c, L.ptr(t.buf), L.ptr(p.yp),
+                                         L.ptr(p.save), p.save[c:].data_ptr(), int(p.relu), L.ptr(p.sum_part), p.sum_rows,
+                                         _stream())
+            else:
+                L.spnet_copy_cols(g.data_ptr() + 4 * off, ct, L.ptr(d), c, self.rows, c, 0, _stream())
             _ir_acc(t, d, self.e)
             off += c
 
@@ -1864,6 +1908,9 @@ class _IRResAdd:
         self.out = _T(eng.new(*x.buf.shape))
         if eng.train_capable:
             self.dx, self.dup = eng.new(*x.buf.shape), eng.new(*x.buf.shape)
+
+    def srcs(self):
+        return [self.x, self.up]
 
     def fwd(self, training):
         L.spnet_resadd(L.ptr(self.x.buf), L.ptr(self.up.buf), L.ptr(self.out.buf), self.out.buf.numel(), self.scale,

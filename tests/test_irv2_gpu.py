@@ -66,6 +66,38 @@ def test_general_convolution_through_patches_and_gemm(B, H, W, C, kh, kw, stride
     L.spnet_gemm_f32(col.data_ptr(), 1, K, dyd.data_ptr(), 1, cout, gw.data_ptr(), cout, K, cout, M, 0, ws.data_ptr(),
                      ws.numel(), None, 0, st)
     np.testing.assert_allclose(gw.cpu().numpy().reshape(w.shape), w.grad.numpy(), rtol=1e-4, atol=1e-4 * np.sqrt(M))
+    # the adjoint gather that also masks with the producer's ReLU and leaves its BatchNorm-backward sums
+    rows = int(L.spnet_grad_bnsums_rows(B * H * W, 128))
+    assert 1 <= rows <= 128
+    yprod = torch.tensor(rs.randn(B, H, W, C), dtype=torch.float32).cuda()           # producer output (sign = ReLU mask)
+    ypre = torch.tensor(rs.randn(B, H, W, C), dtype=torch.float32).cuda()            # its pre-normalisation tensor
+    mu, istd = torch.tensor(rs.randn(C) * 0.2, dtype=torch.float32).cuda(), torch.tensor(rs.rand(C) + 0.5, dtype=torch.float32).cuda()
+    for relu in (1, 0):
+        part = torch.full((rows, 2, C), float("nan"), device="cuda")
+        dx2 = torch.full((B, H, W, C), float("nan"), device="cuda")
+        L.spnet_patches_bwd_bnsums(dcol.data_ptr(), dx2.data_ptr(), B, H, W, C, kh, kw, stride, same, yprod.data_ptr(),
+                                   ypre.data_ptr(), mu.data_ptr(), istd.data_ptr(), relu, part.data_ptr(), rows, st)
+        want = dx * (yprod > 0) if relu else dx
+        assert torch.equal(dx2, want)
+        g64 = want.cpu().double().reshape(-1, C)
+        xh = (ypre.cpu().double().reshape(-1, C) - mu.cpu().double()) * istd.cpu().double()
+        sums = part.sum(0).cpu().double().numpy()
+        np.testing.assert_allclose(sums[0], g64.sum(0).numpy(), rtol=1e-4, atol=1e-4 * np.sqrt(B * H * W) * float(g64.abs().max()))
+        np.testing.assert_allclose(sums[1], (g64 * xh).sum(0).numpy(), rtol=1e-4,
+                                   atol=3e-4 * np.sqrt(B * H * W) * float(g64.abs().max()))
+    # ... and the Concatenate-backward form: a strided column block -> dense, same mask and sums
+    cat = torch.tensor(rs.randn(B * H * W, C + 32), dtype=torch.float32).cuda()
+    d = torch.full((B * H * W, C), float("nan"), device="cuda")
+    part = torch.full((rows, 2, C), float("nan"), device="cuda")
+    L.spnet_copy_cols_bnsums(cat.data_ptr() + 4 * 32, C + 32, d.data_ptr(), B * H * W, C, yprod.data_ptr(), ypre.data_ptr(),
+                             mu.data_ptr(), istd.data_ptr(), 1, part.data_ptr(), rows, st)
+    want = cat[:, 32:] * (yprod.reshape(-1, C) > 0)
+    assert torch.equal(d, want)
+    g64 = want.cpu().double()
+    xh = (ypre.cpu().double().reshape(-1, C) - mu.cpu().double()) * istd.cpu().double()
+    sums = part.sum(0).cpu().double().numpy()
+    np.testing.assert_allclose(sums[0], g64.sum(0).numpy(), rtol=1e-4, atol=1e-4 * np.sqrt(B * H * W) * 4)
+    np.testing.assert_allclose(sums[1], (g64 * xh).sum(0).numpy(), rtol=1e-4, atol=3e-4 * np.sqrt(B * H * W) * 4)
 
 
 def test_irv2_pools_and_block_glue():
