@@ -19,7 +19,7 @@ MAX_RECTS = 6
 
 
 def _stream():
-    return torch.cuda.current_stream().cuda_stream
+    return torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice())
 
 
 def cleanup_angle(angle):

@@ -141,9 +141,10 @@ __global__ __launch_bounds__(256) void grad_bnsums_kernel(const float* __restric
   }
 }
 
-// partial rows (= workgroup rows) for npix pixels: at most max_rows, at least four pixels per thread
+// partial rows (= workgroup rows) for npix pixels: at most max_rows, one pixel per thread or more (these tensors are
+// small: the rows are the parallelism)
 extern "C" long spnet_grad_bnsums_rows(long npix, int max_rows) {
-  long gy = (npix + 32L * 4 - 1) / (32L * 4);
+  long gy = (npix + 31) / 32;
   long cap = max_rows < 1 ? 1 : max_rows;
   if (gy > cap) gy = cap;
   return gy < 1 ? 1 : gy;

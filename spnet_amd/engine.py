@@ -43,8 +43,31 @@ WS_TOTAL = 68 * 1024 * 1024
 ALIGN = 64
 
 
+def _capture(fn):
+    """fn() captured as a hipGraph.  Python's cyclic garbage collector must not run while the stream is capturing: it
+    may finalise garbage of EARLIER plans (an engine's graph, streams, events -- reachable only through reference cycles
+    until then), and destroying a graph or an event is not a capturable operation: the process aborts inside the
+    destructor (seen once in the GPU suite: `Fatal Python error: Aborted ... Garbage-collecting` under predict_step).
+    Collect first, then keep the collector off until the capture has ended."""
+    import gc
+    torch.cuda.synchronize()
+    gc.collect()
+    was_enabled = gc.isenabled()
+    gc.disable()
+    try:
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            fn()
+    finally:
+        if was_enabled:
+            gc.enable()
+    return g
+
+
 def _stream():
-    return torch.cuda.current_stream().cuda_stream
+    """Raw handle of the current HIP stream of the current device.  (torch.cuda.current_stream().cuda_stream builds a
+    Stream object per call, ~2 us; a step is 330 ... 1,900 launches and this is called for each of them.)"""
+    return torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice())
 
 
 class KernelTimer:
@@ -618,11 +641,7 @@ class Engine:
         if self._coeff_ver != self._wver[0] or self._igraph is None:
             out = self.forward(None, training=False)          # eager: also recomputes scale|shift of every BatchNorm
             if self._igraph is None:
-                torch.cuda.synchronize()
-                g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g):
-                    self.forward(None, training=False)
-                self._igraph = g
+                self._igraph = _capture(lambda: self.forward(None, training=False))
             return out
         self._igraph.replay()
         return self.out
@@ -793,11 +812,7 @@ class Engine:
             # Single GPU: the step is a fixed sequence of ~500 launches on two streams -> captured ONCE as
             # a hipGraph and replayed (host enqueue 1.9 ms instead of 4.4 ms per step).
             if self._graph is None and self._graph_warm >= 1:
-                torch.cuda.synchronize()
-                g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g):
-                    self._step_body(None, 1.0)
-                self._graph = g
+                self._graph = _capture(lambda: self._step_body(None, 1.0))
             if self._graph is not None:
                 self._graph.replay()
                 # the host bookkeeping _step_body does outside the launches: weights, moving statistics and the
@@ -1626,7 +1641,8 @@ class IRv2Backbone(Node):
                     ok = (isinstance(p, _IRConv) and not p.bias and t.consumers == 1 and
                           ((isinstance(o, _IRConv) and not o.direct and not o.small) or isinstance(o, _IRConcat)))
                     if ok:
-                        p.sum_rows = int(L.spnet_grad_bnsums_rows(p.M, 128))
+                        # (up to 512 rows where the one-launch BatchNorm backward takes them: bn_fuse_ok in bn.hip)
+                        p.sum_rows = int(L.spnet_grad_bnsums_rows(p.M, 512 if p.M * p.cout <= (4 << 20) else 128))
                         p.sum_part = eng.new(p.sum_rows * 2 * p.cout)
         # one scratch for every conv's patch-matrix gradient (used and consumed on the main stream, op by op)
         self.dcol = eng.new(max_dcol) if (eng.train_capable and max_dcol) else None

@@ -67,8 +67,8 @@ def test_general_convolution_through_patches_and_gemm(B, H, W, C, kh, kw, stride
                      ws.numel(), None, 0, st)
     np.testing.assert_allclose(gw.cpu().numpy().reshape(w.shape), w.grad.numpy(), rtol=1e-4, atol=1e-4 * np.sqrt(M))
     # the adjoint gather that also masks with the producer's ReLU and leaves its BatchNorm-backward sums
-    rows = int(L.spnet_grad_bnsums_rows(B * H * W, 128))
-    assert 1 <= rows <= 128
+    rows = int(L.spnet_grad_bnsums_rows(B * H * W, 512))
+    assert 1 <= rows <= 512
     yprod = torch.tensor(rs.randn(B, H, W, C), dtype=torch.float32).cuda()           # producer output (sign = ReLU mask)
     ypre = torch.tensor(rs.randn(B, H, W, C), dtype=torch.float32).cuda()            # its pre-normalisation tensor
     mu, istd = torch.tensor(rs.randn(C) * 0.2, dtype=torch.float32).cuda(), torch.tensor(rs.rand(C) + 0.5, dtype=torch.float32).cuda()
