@@ -33,6 +33,10 @@ extern "C" {
 int spnet_gemm_f32(const float* A, int a_major, int lda, const float* B, int b_major, int ldb, float* C,
                    int ldc, int M, int N, int K, int split_k, float* workspace, long ws_floats,
                    const float* bias, int tile, void* stream);
+/* C += A B, formed in the epilogue (no K split): a data gradient added onto what another consumer of the same tensor
+ * has already left in C (the branch convolutions of an inception block; call site spnet/models.py:357-359). */
+int spnet_gemm_f32_accumulate(const float* A, int a_major, int lda, const float* B, int b_major, int ldb, float* C,
+                              int ldc, int M, int N, int K, int tile, void* stream);
 /* Same contraction (no split-K, no bias) that also emits BatchNorm column statistics of C from the
  * accumulators: colstats[rows][2][N] per row-tile (sum, sum of squares), *stat_rows (HOST int) = rows.
  * colstats must hold ceil(M/32)*2*N floats. */

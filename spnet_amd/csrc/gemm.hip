@@ -123,7 +123,7 @@ __global__ __launch_bounds__(256, (AX && BM * BN <= 96 * 64) ? 3 : 2) void gemm_
                                                        const long long* __restrict__ batch,
                                                        const float* __restrict__ X2,
                                                        const float* __restrict__ coef, int cld,
-                                                       float* __restrict__ dy_out, int kslices) {
+                                                       float* __restrict__ dy_out, int kslices, int accumulate) {
   static_assert(WM * WN == 4, "4 waves per workgroup");
   static_assert(!AX || AMAJ == SP_K_MAJOR, "blended A operands are K-major");
   constexpr int TM = BM / WM / 16, TN = BN / WN / 16;
@@ -428,7 +428,7 @@ __global__ __launch_bounds__(256, (AX && BM * BN <= 96 * 64) ? 3 : 2) void gemm_
 
   SP_STAMP(2);
   gemm_epilogue<SA, SB, BM, BN, WM, WN, TM, TN>(acc, smem, C, ldc, M, N, m0, n0, tm, zs, slab_stride, bias, colstats,
-                                                tid, lane, wm, wn);
+                                                tid, lane, wm, wn, accumulate);
 #ifdef SP_STAMPS
   SP_STAMP(3);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -502,7 +502,7 @@ static int launch_tile(const float* A, int amaj, int lda, const float* B, int bm
                        int ldc, int M, int N, int K, int nsplit, int k_chunk, long slab_stride,
                        const float* bias, float* colstats, const long long* batch, hipStream_t st,
                        int xf = 0, const float* X2 = nullptr, const float* coef = nullptr, int cld = 0,
-                       float* dy_out = nullptr, int kslices = 1) {
+                       float* dy_out = nullptr, int kslices = 1, int accumulate = 0) {
   const int tm = spnet_cdiv(M, BM), tn = spnet_cdiv(N, BN);
   dim3 grid(tm * tn * nsplit), block(256);
 #ifdef SP_DWMOCK
@@ -511,7 +511,7 @@ static int launch_tile(const float* A, int amaj, int lda, const float* B, int bm
   // the pipelined main loop from 32 K tiles per workgroup (see the kernel's header comment)
   constexpr bool CAN_PIPE = SP_PIPE && (BM / WM / 16) * (BN / WN / 16) < 16;
   const bool pipe = CAN_PIPE && !xf && spnet_cdiv(K < k_chunk ? K : k_chunk, SP_BK) >= SP_PIPE_MIN_TILES;
-#define SP_ARGS A, lda, B, ldb, C, ldc, M, N, K, k_chunk, slab_stride, tm, tn, nsplit, bias, colstats, batch, X2, coef, cld, dy_out, kslices
+#define SP_ARGS A, lda, B, ldb, C, ldc, M, N, K, k_chunk, slab_stride, tm, tn, nsplit, bias, colstats, batch, X2, coef, cld, dy_out, kslices, accumulate
 #define SP_LAUNCH(BKV, AM, BMJ, AXV, PV) \
   hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, BKV, WM, WN, AM, BMJ, AXV, PV>), grid, block, 0, st, SP_ARGS)
 #define SP_LAUNCH_P(AM, BMJ)                                          \
@@ -618,8 +618,12 @@ static int gemm_impl(const float* A, int a_major, int lda, const float* B, int b
                      int ldc, int M, int N, int K, int split_k, float* workspace, long ws_floats,
                      const float* bias, int tile, float* colstats, int* stat_rows, void* stream,
                      const long long* batch = nullptr, int nbatch = 0, int xf = 0, const float* X2 = nullptr,
-                     const float* coef = nullptr, int cld = 0, float* dy_out = nullptr) {
+                     const float* coef = nullptr, int cld = 0, float* dy_out = nullptr, int accumulate = 0) {
   hipStream_t st = (hipStream_t)stream;
+  if (accumulate) {                  // C += A B in the epilogue: whole dot products only (no slabs), one problem
+    if (batch || colstats || xf) return (int)hipErrorInvalidValue;
+    split_k = 1;
+  }
   if (batch) {                       // nbatch whole problems side by side; a K split only when the caller asks for one
     if (nbatch < 1 || bias || colstats) return (int)hipErrorInvalidValue;
     if (split_k <= 1 || !workspace) {
@@ -674,14 +678,14 @@ static int gemm_impl(const float* A, int a_major, int lda, const float* B, int b
   if (batch) nsplit = nbatch * kslices;      // the kernel's slice index selects (problem, K slice)
   int rc;
   switch (tile) {
-    case 1: rc = launch_tile<128, 128, 2, 2>(A, a_major, lda, B, b_major, ldb, out, out_ld, M, N, K, nsplit, k_chunk, slab, kbias, colstats, batch, st, xf, X2, coef, cld, dy_out, kslices); break;
-    case 2: rc = launch_tile<128, 64, 2, 2>(A, a_major, lda, B, b_major, ldb, out, out_ld, M, N, K, nsplit, k_chunk, slab, kbias, colstats, batch, st, xf, X2, coef, cld, dy_out, kslices); break;
-    case 3: rc = launch_tile<64, 64, 2, 2>(A, a_major, lda, B, b_major, ldb, out, out_ld, M, N, K, nsplit, k_chunk, slab, kbias, colstats, batch, st, xf, X2, coef, cld, dy_out, kslices); break;
-    case 5: rc = launch_tile<96, 96, 2, 2>(A, a_major, lda, B, b_major, ldb, out, out_ld, M, N, K, nsplit, k_chunk, slab, kbias, colstats, batch, st, xf, X2, coef, cld, dy_out, kslices); break;
-    case 6: rc = launch_tile<96, 64, 2, 2>(A, a_major, lda, B, b_major, ldb, out, out_ld, M, N, K, nsplit, k_chunk, slab, kbias, colstats, batch, st, xf, X2, coef, cld, dy_out, kslices); break;
-    case 7: rc = launch_tile<64, 128, 2, 2>(A, a_major, lda, B, b_major, ldb, out, out_ld, M, N, K, nsplit, k_chunk, slab, kbias, colstats, batch, st, xf, X2, coef, cld, dy_out, kslices); break;
-    case 8: rc = launch_tile<128, 96, 2, 2>(A, a_major, lda, B, b_major, ldb, out, out_ld, M, N, K, nsplit, k_chunk, slab, kbias, colstats, batch, st, xf, X2, coef, cld, dy_out, kslices); break;
-    default: rc = launch_tile<32, 128, 1, 4>(A, a_major, lda, B, b_major, ldb, out, out_ld, M, N, K, nsplit, k_chunk, slab, kbias, colstats, batch, st, xf, X2, coef, cld, dy_out, kslices); break;
+    case 1: rc = launch_tile<128, 128, 2, 2>(A, a_major, lda, B, b_major, ldb, out, out_ld, M, N, K, nsplit, k_chunk, slab, kbias, colstats, batch, st, xf, X2, coef, cld, dy_out, kslices, accumulate); break;
+    case 2: rc = launch_tile<128, 64, 2, 2>(A, a_major, lda, B, b_major, ldb, out, out_ld, M, N, K, nsplit, k_chunk, slab, kbias, colstats, batch, st, xf, X2, coef, cld, dy_out, kslices, accumulate); break;
+    case 3: rc = launch_tile<64, 64, 2, 2>(A, a_major, lda, B, b_major, ldb, out, out_ld, M, N, K, nsplit, k_chunk, slab, kbias, colstats, batch, st, xf, X2, coef, cld, dy_out, kslices, accumulate); break;
+    case 5: rc = launch_tile<96, 96, 2, 2>(A, a_major, lda, B, b_major, ldb, out, out_ld, M, N, K, nsplit, k_chunk, slab, kbias, colstats, batch, st, xf, X2, coef, cld, dy_out, kslices, accumulate); break;
+    case 6: rc = launch_tile<96, 64, 2, 2>(A, a_major, lda, B, b_major, ldb, out, out_ld, M, N, K, nsplit, k_chunk, slab, kbias, colstats, batch, st, xf, X2, coef, cld, dy_out, kslices, accumulate); break;
+    case 7: rc = launch_tile<64, 128, 2, 2>(A, a_major, lda, B, b_major, ldb, out, out_ld, M, N, K, nsplit, k_chunk, slab, kbias, colstats, batch, st, xf, X2, coef, cld, dy_out, kslices, accumulate); break;
+    case 8: rc = launch_tile<128, 96, 2, 2>(A, a_major, lda, B, b_major, ldb, out, out_ld, M, N, K, nsplit, k_chunk, slab, kbias, colstats, batch, st, xf, X2, coef, cld, dy_out, kslices, accumulate); break;
+    default: rc = launch_tile<32, 128, 1, 4>(A, a_major, lda, B, b_major, ldb, out, out_ld, M, N, K, nsplit, k_chunk, slab, kbias, colstats, batch, st, xf, X2, coef, cld, dy_out, kslices, accumulate); break;
   }
   if (rc) return rc;
   if (nsplit > 1 && !batch) {
@@ -702,6 +706,16 @@ extern "C" int spnet_gemm_f32(const float* A, int a_major, int lda, const float*
                               void* stream) {
   return gemm_impl(A, a_major, lda, B, b_major, ldb, C, ldc, M, N, K, split_k, workspace, ws_floats, bias,
                    tile, nullptr, nullptr, stream);
+}
+
+// C += A B (no K split: the sum is formed in the epilogue, read-modify-write of C by the workgroup that owns the tile):
+// a data gradient added straight onto the gradient another consumer of the same tensor has already left in C, instead
+// of a GEMM into a scratch tensor + an accumulation pass (the branch convolutions of an inception block all read the
+// block input).
+extern "C" int spnet_gemm_f32_accumulate(const float* A, int a_major, int lda, const float* B, int b_major, int ldb,
+                                         float* C, int ldc, int M, int N, int K, int tile, void* stream) {
+  return gemm_impl(A, a_major, lda, B, b_major, ldb, C, ldc, M, N, K, 1, nullptr, 0, nullptr, tile, nullptr, nullptr,
+                   stream, nullptr, 0, 0, nullptr, nullptr, 0, nullptr, 1);
 }
 
 // nbatch independent problems of one shape in ONE launch (no K split).  A0/B0/C0: operands of problem 0;

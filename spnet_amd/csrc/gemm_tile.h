@@ -235,7 +235,8 @@ template <class SA, class SB, int BM, int BN, int WM, int WN, int TM, int TN>
 __device__ __forceinline__ void gemm_epilogue(f32x4 (&acc)[TM][TN], float* __restrict__ smem,
                                               float* __restrict__ C, int ldc, int M, int N, int m0, int n0,
                                               int tm, int z, long slab_stride, const float* __restrict__ bias,
-                                              float* __restrict__ colstats, int tid, int lane, int wm, int wn) {
+                                              float* __restrict__ colstats, int tid, int lane, int wm, int wn,
+                                              int accumulate = 0) {
   const int p = lane & 15, jq = lane >> 4;
   const int mw = m0 + wm * (TM * 16), nw = n0 + wn * (TN * 16);
   if (colstats) {
@@ -290,6 +291,11 @@ __device__ __forceinline__ void gemm_epilogue(f32x4 (&acc)[TM][TN], float* __res
           float o[VW];
 #pragma unroll
           for (int u = 0; u < VW; ++u) o[u] = acc[i][g * VW + u][r] + (bias && col + u < N ? bias[col + u] : 0.f);
+          if (accumulate) {   // C += A B: what is there is read with the vector the store will write
+#pragma unroll
+            for (int u = 0; u < VW; ++u)
+              if (col + u < N) o[u] += crow[col + u];
+          }
           // N % 4 == 0 and ldc % 4 == 0: an aligned 2- or 4-vector is inside or outside as a whole
           if (VW == 4) {
             if (col < N) *reinterpret_cast<float4*>(crow + col) = make_float4(o[0], o[VW > 1 ? 1 : 0], o[VW > 2 ? 2 : 0], o[VW > 3 ? 3 : 0]);

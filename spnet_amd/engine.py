@@ -357,6 +357,8 @@ class Engine:
         self.defer_mid_wgrad = os.environ.get("SPNET_DEFER_WGRAD", "1") != "0"
         # BatchNorm finalize kernels folded into their consumers where the statistics arrive as <= 128 partial rows
         self.bn_fold = os.environ.get("SPNET_BN_FOLD", "1") != "0"
+        # dev toggle: Inception-ResNet-v2 data gradients of 1x1 convolutions added onto the accumulator in the GEMM epilogue
+        self.ir_acc_epilogue = os.environ.get("SPNET_IR_ACC_EPILOGUE", "1") != "0"
         # dev toggle: BatchNorm backward sums from the max-pool backward pass (StridedBlock) instead of a reduction pass
         self.pool_stats = os.environ.get("SPNET_POOL_STATS", "1") != "0"
         # pointwise weight gradients on a side stream (joined before Adam); SPNET_OVERLAP_WGRAD=0: one stream
@@ -1838,6 +1840,16 @@ class _IRConv:
         if self.small:
             L.spnet_conv3x3_small(1, 3, C, self.stride, 0, L.ptr(g), L.ptr(self.w), L.ptr(self.dx), e.B, self.H, self.W,
                                   e.ws_ptr(WS_MISC), WS_MISC[1], _stream())
+        elif self.direct and self.src.g is not None and e.ir_acc_epilogue:
+            # another consumer of my input has already left its gradient in the accumulator: add mine in the GEMM's
+            # epilogue (C += dY W^T) instead of a GEMM into dx + an accumulation pass -- same sum, same rounding
+            prof = e.prof
+            t0 = prof.start() if prof is not None else None
+            L.spnet_gemm_f32_accumulate(L.ptr(g), K_MAJOR, C, L.ptr(self.w), K_MAJOR, C, L.ptr(self.src.g), self.K, self.M,
+                                        self.K, C, _tile_for(K_MAJOR, K_MAJOR, 0, self.M, self.K, C, 0), _stream())
+            if prof is not None:
+                prof.stop("gemm", t0, 2.0 * self.M * self.K * C, ("aA+=", self.M, self.K, C))
+            return
         elif self.direct:
             _gemm(g, K_MAJOR, C, self.w, K_MAJOR, C, self.dx, self.K, self.M, self.K, C, e)
         else:

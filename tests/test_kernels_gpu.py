@@ -125,6 +125,27 @@ def test_gemm_long_k_takes_the_pipelined_main_loop(L, form, tile, split):
     close(c, want, rtol=2e-5, atol=3e-5 * np.sqrt(K))
 
 
+@pytest.mark.parametrize("M,N,K,form", [(9744, 320, 32, "dgrad"), (2240, 1088, 192, "dgrad"), (100, 72, 40, "fwd"),
+                                        (384, 2080, 192, "dgrad"), (37, 64, 288, "fwd")])
+@pytest.mark.parametrize("tile", [0, 3, 6])
+def test_gemm_accumulate_into_c(L, M, N, K, form, tile):
+    """spnet_gemm_f32_accumulate: C += A B in the epilogue == the GEMM into a scratch tensor followed by an elementwise
+    add, bit for bit (one rounding of the product sum, one of the addition, either way)."""
+    rs = np.random.RandomState(M + N + K)
+    A = dev(rs.randn(M, K))
+    if form == "fwd":
+        B, bmaj, ldb = dev(rs.randn(K, N) * 0.1), 1, N
+    else:
+        B, bmaj, ldb = dev(rs.randn(N, K) * 0.1), 0, K
+    C0 = dev(rs.randn(M, N))
+    scratch = torch.empty(M, N, device="cuda")
+    L.spnet_gemm_f32(A.data_ptr(), 0, K, B.data_ptr(), bmaj, ldb, scratch.data_ptr(), N, M, N, K, 1, None, 0, None, tile, st())
+    want = scratch + C0
+    C = C0.clone()
+    L.spnet_gemm_f32_accumulate(A.data_ptr(), 0, K, B.data_ptr(), bmaj, ldb, C.data_ptr(), N, M, N, K, tile, st())
+    assert torch.equal(C, want)
+
+
 @pytest.mark.parametrize("tile", [0, 3, 5, 6])
 def test_gemm_batched_wgrad_form(L, tile):
     """Several weight-gradient problems of one shape in one launch == the same problems one by one."""
