@@ -3,7 +3,10 @@
 For every distinct plain GEMM launch (operand form, BatchNorm statistics or not, M, N, K) each tile id is forced in turn
 (engine.TILE_PROBE) for a few whole train steps and that shape's launches are timed with HIP events; a tile is recorded
 only where it beats the library's own choice by more than 3 % in BOTH of two alternating passes.
-writes spnet_amd/gemm_tiles.json      usage: autotune_gemm.py [steps per probe]"""
+MERGES into spnet_amd/gemm_tiles.json (keys carry the shape, so geometries do not collide).
+usage: autotune_gemm.py [steps per probe] [out.json] [H W B] [train|predict]
+       (default 384 512 32 train = the benchmark step; 331 331 16 train = the reference's own layout;
+        384 512 128 predict = BASELINE configs[4])"""
 import json, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 os.environ["SPNET_OVERLAP_WGRAD"] = "0"
@@ -12,18 +15,26 @@ import torch
 from spnet_amd import engine as E
 
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 4
-B = 32
-eng = E.Engine(384, 512, B, device="cuda:0", seed=0, train=True)
-X = torch.rand(B, 384, 512, 1, device="cuda") * 2 - 1
+H, W, B = (int(v) for v in sys.argv[3:6]) if len(sys.argv) > 5 else (384, 512, 32)
+MODE = sys.argv[6] if len(sys.argv) > 6 else "train"
+eng = E.Engine(H, W, B, device="cuda:0", seed=0, train=(MODE == "train"))
+X = torch.rand(B, H, W, 1, device="cuda") * 2 - 1
 Y = torch.rand(B, 576, device="cuda")
 
 
+def one_step():
+    if MODE == "train":
+        eng.train_step(X, Y, 1e-5)
+    else:
+        eng.forward(X, training=False)
+
+
 def measure():
-    """{key: us per launch} over `steps` train steps."""
+    """{key: us per launch} over `steps` steps."""
     t = E.KernelTimer()
     eng.prof = t
     for _ in range(steps):
-        eng.train_step(X, Y, 1e-5)
+        one_step()
     torch.cuda.synchronize()
     eng.prof = None
     acc = {}
@@ -35,7 +46,7 @@ def measure():
 
 
 for _ in range(3):
-    eng.train_step(X, Y, 1e-5)
+    one_step()
 base1, count = measure()
 base2, _ = measure()
 keys = sorted(base1, key=lambda k: -base1[k] * count[k])
@@ -69,9 +80,15 @@ for key in keys:
         mark = "  -> tile %d (%.1f us x %d per step saved)" % (best[1], base - best[0], count[key])
     print("form %d stats %d M=%-6d N=%-5d K=%-6d x%-2d | auto %6.1f us | %s%s" % (form, stats, M, N, K, count[key], base, "  ".join(res), mark), flush=True)
 out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "spnet_amd", "gemm_tiles.json")
-if len(sys.argv) > 2:
+if len(sys.argv) > 2 and sys.argv[2] not in ("", "-"):
     out = sys.argv[2]
+tiles = {}
+src = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "spnet_amd", "gemm_tiles.json")
+if os.path.exists(src):
+    tiles = dict(json.load(open(src)).get("tiles", {}))
+tiles.update(chosen)
 with open(out, "w") as f:
-    json.dump({"note": "tools/autotune_gemm.py on MI355X: tile ids measured inside the 384x512 batch-32 train step; key = a_major,b_major,stats,M,N,K",
-               "tiles": chosen}, f, indent=1, sort_keys=True)
-print("wrote %s: %d shapes" % (out, len(chosen)))
+    json.dump({"note": "tools/autotune_gemm.py on MI355X: tile ids measured inside the step of each geometry (384x512 batch 32 "
+                       "train, 331x331 batch 16 train, 384x512 batch 128 predict); key = a_major,b_major,stats,M,N,K",
+               "tiles": tiles}, f, indent=1, sort_keys=True)
+print("wrote %s: %d new shapes for %dx%d batch %d %s, %d in all" % (out, len(chosen), H, W, B, MODE, len(tiles)))
