@@ -2,7 +2,7 @@
 """Dev tool: worst per-tensor gradient mismatch (engine vs torch-CPU oracle) for one geometry and several seeds
 -- separates a systematic error (same tensors every seed) from ReLU / max-pool ties flipped by rounding."""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 from oracle import torch_ref as T
 from tests.test_engine_gpu import dropout_mask

@@ -13,7 +13,7 @@ seed (tiny BatchNorm populations, ReLU / max-pool near-ties) and says nothing ab
 import os
 import sys
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 import torch
 
