@@ -8,7 +8,7 @@ oracle evaluated in DOUBLE precision of
 A tensor where (b) >> (a) is a kernel bug; a tensor where both are large is ill-conditioned at this
 seed (tiny BatchNorm populations, ReLU / max-pool near-ties) and says nothing about the kernels.
 
-  python tools/parity_probe.py H W B [seed ...]
+  python tests/helpers/parity_probe.py H W B [seed ...]
 """
 import os
 import sys

@@ -5,7 +5,7 @@ batch sizes 1 / 3.
 Gradients are compared with the fp64 oracle evaluated ON THE DEVICE'S OWN DISCRETE DECISIONS (ReLU / LeakyReLU
 signs, max-pool arg-max taps; oracle.torch_ref.Decisions).  Why: the network is piecewise linear, and an input
 that sits within fp32 rounding of a kink is legitimately rounded to either side by two correct fp32 programs;
-the gradients then differ by whole terms.  Measured with tools/parity_probe.py over 18 (geometry, seed) pairs:
+the gradients then differ by whole terms.  Measured with tests/helpers/parity_probe.py over 18 (geometry, seed) pairs:
 the fp32 CPU evaluation of the oracle deviates from its own fp64 evaluation by 2.5e-2 / 2.4e-1 on two of them and
 the device by 5e-2 .. 2e-1 on three OTHER ones, while on all remaining pairs both sit at 1e-5; which pairs are hit
 changes with the summation order.  On shared decisions the comparison is deterministic and tight: every tensor
