@@ -159,6 +159,20 @@ int spnet_bn_finalize_apply(const float* partial, int P, const float* x, long M,
                             const float* beta, float* moving_mean, float* moving_var, float* save_mean,
                             float* save_invstd, float* scale_shift, int act, const float* residual, float* y, float eps,
                             float momentum, void* stream);
+/* The `_ld` forms of the three forward entries write y with a row stride of ldy floats (>= C, multiples of 4): the output
+ * is a column block of a wider tensor -- a conv2d_bn branch of keras InceptionResNetV2 written straight into the buffer
+ * of its Concatenate (call site spnet/models.py:357-359), so that no copy pass follows. */
+int spnet_bn_finalize_apply_ld(const float* partial, int P, const float* x, long M, int C, const float* gamma,
+                               const float* beta, float* moving_mean, float* moving_var, float* save_mean,
+                               float* save_invstd, float* scale_shift, int act, const float* residual, float* y, long ldy,
+                               float eps, float momentum, void* stream);
+int spnet_bn_fwd_train_ld(const float* x, long M, int C, const float* gamma, const float* beta, float* moving_mean,
+                          float* moving_var, float* save_mean, float* save_invstd, float* scale_shift, int act,
+                          const float* residual, int res_bcast, float* y, long ldy, float eps, float momentum,
+                          float* workspace, void* stream);
+int spnet_bn_fwd_infer_ld(const float* x, long M, int C, const float* gamma, const float* beta, const float* moving_mean,
+                          const float* moving_var, float* scale_shift, int act, const float* residual, int res_bcast,
+                          float* y, long ldy, float eps, void* stream);
 int spnet_bn_bwd_from_partials(const float* x, const float* dy, long M, int C, const float* gamma,
                                const float* beta, const float* save_mean, const float* save_invstd, int P,
                                const float* partial, float* dx, float* dgamma, float* dbeta, float* coeffs,
@@ -203,6 +217,13 @@ int spnet_avgpool3x3s1_same(const float* in, float* out, int B, int H, int W, in
  * spnet_gemm_f32 on col and the flattened HWIO kernel (1x1 convs skip the patch matrix). */
 int spnet_patches(const float* in, float* out, int B, int H, int W, int C, int KH, int KW, int stride, int same, int backward,
                   void* stream);
+/* The forward convolution itself as an implicit GEMM: A tiles gathered from x tap by tap (no patch matrix written or
+ * read), same k order as spnet_patches + spnet_gemm_f32.  x [B][H][W][cin], w HWIO [KH][KW][cin][cout] -> y
+ * [B][OH][OW][cout] (+ bias); cin % 16 == 0, cout % 4 == 0, KH*KW <= 32, stride 1 | 2.  colstats (or NULL): BatchNorm
+ * column sums of y as [*stat_rows][2][cout] partial rows (64-row tiles), as spnet_gemm_f32_colstats leaves them. */
+int spnet_conv_fwd_implicit(const float* x, const float* w, float* y, int B, int H, int W, int cin, int cout, int KH,
+                            int KW, int stride, int same, const float* bias, float* colstats, int* stat_rows,
+                            void* stream);
 /* Gradient producers that also leave the BatchNorm-backward sums (sum g, sum g*xhat) of the conv2d_bn layer whose output
  * y = relu(BN(yp)) they differentiate, g masked with y > 0 when relu != 0: partial[rows][2][C], rows <=
  * spnet_grad_bnsums_rows(pixels, max_rows).  spnet_patches_bwd_bnsums = spnet_patches(backward = 1) + mask + sums (the
@@ -213,7 +234,7 @@ long spnet_grad_bnsums_rows(long npix, int max_rows);
 int spnet_patches_bwd_bnsums(const float* dcol, float* dx, int B, int H, int W, int C, int KH, int KW, int stride, int same,
                              const float* y, const float* yp, const float* mean, const float* invstd, int relu,
                              float* partial, int rows, void* stream);
-int spnet_copy_cols_bnsums(const float* src, int lds, float* dst, long M, int C, const float* y, const float* yp,
+int spnet_copy_cols_bnsums(const float* src, int lds, float* dst, long M, int C, const float* y, long ldy, const float* yp,
                            const float* mean, const float* invstd, int relu, float* partial, int rows, void* stream);
 /* inception_resnet_block: y = x + scale*up (+ ReLU); backward: dx = g*(y>0 if relu), dup = scale*dx. */
 int spnet_resadd(const float* x, const float* up, float* y, long n, float scale, int relu, void* stream);

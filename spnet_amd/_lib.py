@@ -50,6 +50,7 @@ _SIGS = {
     "spnet_bn_infer_coeffs": (c_int, [c_int, P, P, P, P, P, c_float, P]),
     "spnet_bn_apply": (c_int, [P, c_long, c_int, P, c_int, P, c_int, P, P]),
     "spnet_bn_finalize_apply": (c_int, [P, c_int, P, c_long, c_int, P, P, P, P, P, P, P, c_int, P, P, c_float, c_float, P]),
+    "spnet_bn_finalize_apply_ld": (c_int, [P, c_int, P, c_long, c_int, P, P, P, P, P, P, P, c_int, P, P, c_long, c_float, c_float, P]),
     "spnet_bn_bwd_from_partials": (c_int, [P, P, c_long, c_int, P, P, P, P, c_int, P, P, P, P, P, P]),
     "spnet_gemm_f32_colstats": (c_int, [P, c_int, c_int, P, c_int, c_int, P, c_int, c_int, c_int, c_int, c_int, P, P, P]),
     "spnet_gemm_f32_bnblend": (c_int, [P, P, P, c_int, c_int, P, c_int, P, c_int, c_int, c_int, c_int, c_int, P, P]),
@@ -62,6 +63,8 @@ _SIGS = {
     "spnet_bn_ws": (c_long, [c_long, c_int]),
     "spnet_bn_fwd_train": (c_int, [P, c_long, c_int, P, P, P, P, P, P, P, c_int, P, c_int, P, c_float, c_float, P, P]),
     "spnet_bn_fwd_infer": (c_int, [P, c_long, c_int, P, P, P, P, P, c_int, P, c_int, P, c_float, P]),
+    "spnet_bn_fwd_train_ld": (c_int, [P, c_long, c_int, P, P, P, P, P, P, P, c_int, P, c_int, P, c_long, c_float, c_float, P, P]),
+    "spnet_bn_fwd_infer_ld": (c_int, [P, c_long, c_int, P, P, P, P, P, c_int, P, c_int, P, c_long, c_float, P]),
     "spnet_bn_bwd": (c_int, [P, P, c_long, c_int, P, P, P, P, c_int, P, P, P, P, P, P]),
     "spnet_maxpool3x3s2_add_fwd": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, P, P, P]),
     "spnet_maxpool3x3s2_bwd": (c_int, [P, P, P, c_int, c_int, c_int, c_int, P]),
@@ -71,10 +74,11 @@ _SIGS = {
     "spnet_maxpool3x3s2_valid_bwd": (c_int, [P, P, P, c_int, c_int, c_int, c_int, P]),
     "spnet_avgpool3x3s1_same": (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, P]),
     "spnet_patches": (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P]),
+    "spnet_conv_fwd_implicit": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P, P, P]),
     "spnet_grad_bnsums_rows": (c_long, [c_long, c_int]),
     "spnet_patches_bwd_bnsums": (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P, P, P, c_int, P,
                                          c_int, P]),
-    "spnet_copy_cols_bnsums": (c_int, [P, c_int, P, c_long, c_int, P, P, P, P, c_int, P, c_int, P]),
+    "spnet_copy_cols_bnsums": (c_int, [P, c_int, P, c_long, c_int, P, c_long, P, P, P, c_int, P, c_int, P]),
     "spnet_resadd": (c_int, [P, P, P, c_long, c_float, c_int, P]),
     "spnet_resadd_bwd": (c_int, [P, P, P, P, c_long, c_float, c_int, P]),
     "spnet_copy_cols": (c_int, [P, c_int, P, c_int, c_long, c_int, c_int, P]),

@@ -344,7 +344,7 @@ __global__ __launch_bounds__(256) void bn_apply_vec_kernel(const float* __restri
                                                            const float* __restrict__ scale,
                                                            const float* __restrict__ shift, int act,
                                                            const float* __restrict__ residual,
-                                                           float* __restrict__ y) {
+                                                           float* __restrict__ y, long ldy) {
   const int c4n = C >> 2;
   const long total = M * c4n;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
@@ -362,7 +362,8 @@ __global__ __launch_bounds__(256) void bn_apply_vec_kernel(const float* __restri
       const float4 r = *reinterpret_cast<const float4*>(residual + i * 4);
       o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
     }
-    *reinterpret_cast<float4*>(y + i * 4) = o;
+    // (ldy != C: the output is a column block of a wider tensor -- a branch written straight into its Concatenate)
+    *reinterpret_cast<float4*>(y + (ldy == C ? i * 4 : (i / c4n) * ldy + c)) = o;
   }
 }
 
@@ -475,7 +476,7 @@ __global__ __launch_bounds__(256) void bn_fwd_fused_vec_kernel(
     const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ moving_mean,
     float* __restrict__ moving_var, float* __restrict__ save_mean, float* __restrict__ save_invstd,
     float* __restrict__ scale, float* __restrict__ shift, float eps, float momentum, int act,
-    const float* __restrict__ residual, float* __restrict__ y, int rows_per_slab, int chunks) {
+    const float* __restrict__ residual, float* __restrict__ y, int rows_per_slab, int chunks, long ldy) {
   __shared__ double dred[2 * 16 * BN_FUSE_CH];
   __shared__ __attribute__((aligned(16))) float cf[2][BN_FUSE_CH];
   // XCD-aware order: a row of C floats is not a whole number of 128-byte lines (C = 728), so neighbouring channel
@@ -525,7 +526,7 @@ __global__ __launch_bounds__(256) void bn_fwd_fused_vec_kernel(
     o.z = act_fwd(fmaf(v.z, sc.z, sh.z), act);
     o.w = act_fwd(fmaf(v.w, sc.w, sh.w), act);
     if (residual) { o.x += rr.x; o.y += rr.y; o.z += rr.z; o.w += rr.w; }
-    *reinterpret_cast<float4*>(y + r * C + c) = o;
+    *reinterpret_cast<float4*>(y + r * ldy + c) = o;
   };
 #pragma unroll
   for (int u = 0; u < BN_FUSE_AHEAD; ++u) {
@@ -689,7 +690,8 @@ static void launch_partial(const float* x, const float* dy, long M, int C, const
 }
 
 static void launch_apply(const float* x, long M, int C, const float* scale, const float* shift,
-                         int act, const float* residual, int res_bcast, float* y, hipStream_t st) {
+                         int act, const float* residual, int res_bcast, float* y, hipStream_t st, long ldy = 0) {
+  if (ldy <= 0) ldy = C;
   if (C & 3) {
     const long n = M * C;
     hipLaunchKernelGGL(bn_apply_scalar_kernel, dim3(spnet_ew_grid(n, 256)), dim3(256), 0, st, x, n, C,
@@ -697,41 +699,60 @@ static void launch_apply(const float* x, long M, int C, const float* scale, cons
   } else {
     const long n4 = M * (C / 4);
     hipLaunchKernelGGL(bn_apply_vec_kernel, dim3(spnet_ew_grid(n4, 256)), dim3(256), 0, st, x, M, C,
-                       scale, shift, act, residual, y);
+                       scale, shift, act, residual, y, ldy);
   }
 }
 
 // Training forward.  Outputs: y, save_mean[C], save_invstd[C] (for backward), moving stats updated
 // in place.  scale_shift: 2*C floats of scratch.  workspace: spnet_bn_ws(M,C) floats.
-extern "C" int spnet_bn_fwd_train(const float* x, long M, int C, const float* gamma,
-                                  const float* beta, float* moving_mean, float* moving_var,
-                                  float* save_mean, float* save_invstd, float* scale_shift, int act,
-                                  const float* residual, int res_bcast, float* y, float eps,
-                                  float momentum, float* workspace, void* stream) {
+// The `_ld` forms write y with a row stride of ldy floats (>= C, a multiple of 4; C % 4 == 0): the output is a column
+// block of a wider tensor -- an inception branch written straight into its Concatenate.
+extern "C" int spnet_bn_fwd_train_ld(const float* x, long M, int C, const float* gamma,
+                                     const float* beta, float* moving_mean, float* moving_var,
+                                     float* save_mean, float* save_invstd, float* scale_shift, int act,
+                                     const float* residual, int res_bcast, float* y, long ldy, float eps,
+                                     float momentum, float* workspace, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   if ((C & 3) && C > 4) return (int)hipErrorInvalidValue;
+  if (ldy != C && ((C & 3) || (ldy & 3) || ldy < C)) return (int)hipErrorInvalidValue;
   if (res_bcast && !(C & 3)) return (int)hipErrorInvalidValue;
   const int parts = bn_parts(M, C);
   launch_partial<0>(x, nullptr, M, C, nullptr, nullptr, nullptr, nullptr, 0, workspace, parts, st);
   hipLaunchKernelGGL(bn_fwd_finalize_kernel, dim3((C + BN_FIN_CH - 1) / BN_FIN_CH), dim3(256), 0, st, workspace, parts,
                      C, M, gamma, beta, moving_mean, moving_var, save_mean, save_invstd, scale_shift,
                      scale_shift + C, eps, momentum, 0);
-  launch_apply(x, M, C, scale_shift, scale_shift + C, act, residual, res_bcast, y, st);
+  launch_apply(x, M, C, scale_shift, scale_shift + C, act, residual, res_bcast, y, st, ldy);
   SPNET_RETURN_LAUNCH_STATUS();
+}
+extern "C" int spnet_bn_fwd_train(const float* x, long M, int C, const float* gamma,
+                                  const float* beta, float* moving_mean, float* moving_var,
+                                  float* save_mean, float* save_invstd, float* scale_shift, int act,
+                                  const float* residual, int res_bcast, float* y, float eps,
+                                  float momentum, float* workspace, void* stream) {
+  return spnet_bn_fwd_train_ld(x, M, C, gamma, beta, moving_mean, moving_var, save_mean, save_invstd, scale_shift, act,
+                               residual, res_bcast, y, C, eps, momentum, workspace, stream);
 }
 
 // Inference forward from the moving statistics.
+extern "C" int spnet_bn_fwd_infer_ld(const float* x, long M, int C, const float* gamma, const float* beta,
+                                     const float* moving_mean, const float* moving_var,
+                                     float* scale_shift, int act, const float* residual, int res_bcast,
+                                     float* y, long ldy, float eps, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  if ((C & 3) && C > 4) return (int)hipErrorInvalidValue;
+  if (res_bcast && !(C & 3)) return (int)hipErrorInvalidValue;
+  if (ldy != C && ((C & 3) || (ldy & 3) || ldy < C)) return (int)hipErrorInvalidValue;
+  hipLaunchKernelGGL(bn_infer_coeffs_kernel, dim3((C + 255) / 256), dim3(256), 0, st, C, gamma, beta,
+                     moving_mean, moving_var, scale_shift, scale_shift + C, eps);
+  launch_apply(x, M, C, scale_shift, scale_shift + C, act, residual, res_bcast, y, st, ldy);
+  SPNET_RETURN_LAUNCH_STATUS();
+}
 extern "C" int spnet_bn_fwd_infer(const float* x, long M, int C, const float* gamma, const float* beta,
                                   const float* moving_mean, const float* moving_var,
                                   float* scale_shift, int act, const float* residual, int res_bcast,
                                   float* y, float eps, void* stream) {
-  hipStream_t st = (hipStream_t)stream;
-  if ((C & 3) && C > 4) return (int)hipErrorInvalidValue;
-  if (res_bcast && !(C & 3)) return (int)hipErrorInvalidValue;
-  hipLaunchKernelGGL(bn_infer_coeffs_kernel, dim3((C + 255) / 256), dim3(256), 0, st, C, gamma, beta,
-                     moving_mean, moving_var, scale_shift, scale_shift + C, eps);
-  launch_apply(x, M, C, scale_shift, scale_shift + C, act, residual, res_bcast, y, st);
-  SPNET_RETURN_LAUNCH_STATUS();
+  return spnet_bn_fwd_infer_ld(x, M, C, gamma, beta, moving_mean, moving_var, scale_shift, act, residual, res_bcast, y, C,
+                               eps, stream);
 }
 
 // Backward of y = act(BN(x)): dx, dgamma[C], dbeta[C].  x is the BN *input* saved by the forward.
@@ -812,19 +833,19 @@ extern "C" int spnet_bn_apply(const float* x, long M, int C, const float* scale_
 
 // spnet_bn_finalize_fwd + spnet_bn_apply in ONE launch where the statistics arrive as at most 128 partial rows (the
 // closing BatchNorm of an Xception middle block, whose output x + BN(.) is materialised); otherwise the two launches.
-extern "C" int spnet_bn_finalize_apply(const float* partial, int P, const float* x, long M, int C, const float* gamma,
-                                       const float* beta, float* moving_mean, float* moving_var, float* save_mean,
-                                       float* save_invstd, float* scale_shift, int act, const float* residual, float* y,
-                                       float eps, float momentum, void* stream) {
+extern "C" int spnet_bn_finalize_apply_ld(const float* partial, int P, const float* x, long M, int C, const float* gamma,
+                                          const float* beta, float* moving_mean, float* moving_var, float* save_mean,
+                                          float* save_invstd, float* scale_shift, int act, const float* residual, float* y,
+                                          long ldy, float eps, float momentum, void* stream) {
   hipStream_t st = (hipStream_t)stream;
-  if ((C & 3) || P < 1) return (int)hipErrorInvalidValue;
+  if ((C & 3) || P < 1 || (ldy & 3) || ldy < C) return (int)hipErrorInvalidValue;
   if (bn_fuse_ok(P, M, C)) {
     const int rps = bn_fuse_rows_per_slab(M, C);
     const int chunks = (C + BN_FUSE_CH - 1) / BN_FUSE_CH;
     dim3 grid((unsigned)(chunks * ((M + rps - 1) / rps)));
     hipLaunchKernelGGL(bn_fwd_fused_vec_kernel, grid, dim3(256), 0, st, x, M, C, partial, P, gamma, beta, moving_mean,
                        moving_var, save_mean, save_invstd, scale_shift, scale_shift + C, eps, momentum, act, residual, y,
-                       rps, chunks);
+                       rps, chunks, ldy);
     SPNET_RETURN_LAUNCH_STATUS();
   }
   {     // many partial rows: the two-stage finalize of spnet_bn_finalize_fwd
@@ -832,8 +853,15 @@ extern "C" int spnet_bn_finalize_apply(const float* partial, int P, const float*
                                          scale_shift, eps, momentum, stream);
     if (rc) return rc;
   }
-  launch_apply(x, M, C, scale_shift, scale_shift + C, act, residual, 0, y, st);
+  launch_apply(x, M, C, scale_shift, scale_shift + C, act, residual, 0, y, st, ldy);
   SPNET_RETURN_LAUNCH_STATUS();
+}
+extern "C" int spnet_bn_finalize_apply(const float* partial, int P, const float* x, long M, int C, const float* gamma,
+                                       const float* beta, float* moving_mean, float* moving_var, float* save_mean,
+                                       float* save_invstd, float* scale_shift, int act, const float* residual, float* y,
+                                       float eps, float momentum, void* stream) {
+  return spnet_bn_finalize_apply_ld(partial, P, x, M, C, gamma, beta, moving_mean, moving_var, save_mean, save_invstd,
+                                    scale_shift, act, residual, y, C, eps, momentum, stream);
 }
 
 // Backward given the two per-channel sums as partial[P][2][C] (sum g, sum g*xhat; g already includes

@@ -75,7 +75,7 @@ __global__ __launch_bounds__(256) void col2im_kernel(const float* __restrict__ d
 template <int MODE>
 __global__ __launch_bounds__(256) void grad_bnsums_kernel(const float* __restrict__ src, int lds, float* __restrict__ dx,
                                                           int Bn, int H, int W, int C, int KH, int KW, int s, int pt, int pl,
-                                                          int OH, int OW, const float* __restrict__ y,
+                                                          int OH, int OW, const float* __restrict__ y, long ldy,
                                                           const float* __restrict__ yp, const float* __restrict__ mean,
                                                           const float* __restrict__ invstd, int relu,
                                                           float* __restrict__ partial) {
@@ -116,7 +116,7 @@ __global__ __launch_bounds__(256) void grad_bnsums_kernel(const float* __restric
       }
       const float4 xv = *reinterpret_cast<const float4*>(yp + r * C + c4 * 4);
       if (relu) {
-        const float4 yv = *reinterpret_cast<const float4*>(y + r * C + c4 * 4);
+        const float4 yv = *reinterpret_cast<const float4*>(y + r * ldy + c4 * 4);
         g.x = yv.x > 0.f ? g.x : 0.f; g.y = yv.y > 0.f ? g.y : 0.f;
         g.z = yv.z > 0.f ? g.z : 0.f; g.w = yv.w > 0.f ? g.w : 0.f;
       }
@@ -195,20 +195,21 @@ extern "C" int spnet_patches_bwd_bnsums(const float* dcol, float* dx, int B, int
   if (OH < 1 || OW < 1 || rows < 1 || rows > spnet_grad_bnsums_rows((long)B * H * W, rows)) return (int)hipErrorInvalidValue;
   dim3 grid((C / 4 + GS_CL - 1) / GS_CL, (unsigned)rows), block(GS_CL, 32);
   hipLaunchKernelGGL(grad_bnsums_kernel<0>, grid, block, 0, (hipStream_t)stream, dcol, 0, dx, B, H, W, C, KH, KW, stride, pt,
-                     pl, OH, OW, y, yp, mean, invstd, relu ? 1 : 0, partial);
+                     pl, OH, OW, y, (long)C, yp, mean, invstd, relu ? 1 : 0, partial);
   SPNET_RETURN_LAUNCH_STATUS();
 }
 
 // dst[r][c] = src[r * lds + c] (* ReLU mask), c < C, dense dst -- the Concatenate backward of one branch -- with the same
 // BatchNorm-backward sums of the branch's last layer.
-extern "C" int spnet_copy_cols_bnsums(const float* src, int lds, float* dst, long M, int C, const float* y, const float* yp,
-                                      const float* mean, const float* invstd, int relu, float* partial, int rows,
-                                      void* stream) {
+extern "C" int spnet_copy_cols_bnsums(const float* src, int lds, float* dst, long M, int C, const float* y, long ldy,
+                                      const float* yp, const float* mean, const float* invstd, int relu, float* partial,
+                                      int rows, void* stream) {
   if ((C & 3) || (lds & 3) || M < 1 || !yp || !mean || !invstd || !partial || (relu && !y)) return (int)hipErrorInvalidValue;
+  if (ldy < C || (ldy & 3)) return (int)hipErrorInvalidValue;      // y may itself be a column block (row stride ldy)
   if (rows < 1 || rows > spnet_grad_bnsums_rows(M, rows)) return (int)hipErrorInvalidValue;
   dim3 grid((C / 4 + GS_CL - 1) / GS_CL, (unsigned)rows), block(GS_CL, 32);
   hipLaunchKernelGGL(grad_bnsums_kernel<1>, grid, block, 0, (hipStream_t)stream, src, lds, dst, 1, 1, (int)M, C, 1, 1, 1, 0, 0,
-                     1, (int)M, y, yp, mean, invstd, relu ? 1 : 0, partial);
+                     1, (int)M, y, ldy, yp, mean, invstd, relu ? 1 : 0, partial);
   SPNET_RETURN_LAUNCH_STATUS();
 }
 

@@ -1625,18 +1625,33 @@ class IRv2Backbone(Node):
                 _, xs, up, dst, scale, relu = op
                 o = _IRResAdd(eng, cur[xs], cur[up], scale, relu)
                 cur[dst] = o.out
+            o.out.owner = o
             self.ops.append(o)
         self.y = cur["x"].buf
         self.t_out = cur["x"]
+        for o in self.ops:
+            for t in o.srcs():
+                t.consumers += 1
+        # A conv2d_bn branch whose only consumer is a Concatenate writes its output straight into that buffer (its
+        # BatchNorm apply pass gets the row stride of the concatenated tensor): no copy pass in forward.  The tensor
+        # stays a strided view for everyone who looks at it (the Concatenate backward reads the ReLU mask from it).
+        # SPNET_IR_DIRECT_CONCAT=0: branch buffers + copies.
+        if os.environ.get("SPNET_IR_DIRECT_CONCAT", "1") != "0":
+            for o in self.ops:
+                if not isinstance(o, _IRConcat):
+                    continue
+                ct, off = sum(o.cs), 0
+                for i, (t, c) in enumerate(zip(o.srcs_, o.cs)):
+                    p = t.owner
+                    if isinstance(p, _IRConv) and not p.bias and not p.small and t.consumers == 1:
+                        t.buf = o.out.buf[..., off:off + c]
+                        p.ldy = ct
+                        o.direct[i] = True
+                    off += c
         # A conv2d_bn output with ONE consumer that is a k x k convolution or a Concatenate gets its BatchNorm-backward
         # sums from that consumer's gradient pass (spnet_patches_bwd_bnsums / spnet_copy_cols_bnsums) instead of a
         # reduction pass of its own (SPNET_IR_FUSE_BNSUMS=0: stand-alone reductions).
         if eng.train_capable and os.environ.get("SPNET_IR_FUSE_BNSUMS", "1") != "0":
-            for o in self.ops:
-                o.out.owner = o
-            for o in self.ops:
-                for t in o.srcs():
-                    t.consumers += 1
             for o in self.ops:
                 for t in o.srcs():
                     p = t.owner
@@ -1701,6 +1716,8 @@ class IRv2Backbone(Node):
         def run():
             for g in self.wg_groups:
                 ms = g["members"]
+                for o in ms:
+                    o.gather_patches()
                 a0, b0, c0 = ms[0]._A().data_ptr(), ms[0].out.g.data_ptr(), ms[0].gw.data_ptr()
                 offs = tuple(v for o in ms for v in ((o._A().data_ptr() - a0) // 4, (o.out.g.data_ptr() - b0) // 4,
                                                      (o.gw.data_ptr() - c0) // 4))
@@ -1749,8 +1766,18 @@ class _IRConv:
         self.small = (cin == 3)                      # the first conv: 3 -> 32, 3x3 / stride 2 / valid (stem.hip)
         self.deferred_wgrad = False                  # set by IRv2Backbone: dW comes out of a batched launch per shape
         self.sum_rows, self.sum_part = 0, None       # set by IRv2Backbone: my BatchNorm-backward sums come from my consumer
+        self.ldy = cout                              # row stride of my output (IRv2Backbone: the Concatenate's width)
+        # SPNET_IR_IMPLICIT_FWD=1: k x k convolutions forward as an implicit GEMM (spnet_conv_fwd_implicit: no patch
+        # matrix on the forward path; the one the weight-gradient GEMM reads is gathered in backward, on the
+        # weight-gradient stream).  Off by default: measured SLOWER at these sizes (training 756 -> 695 images/s,
+        # inference 2,145 -> 1,842 frames/s at batch 16) -- a patch gather of a 9,744 x 288 matrix is an 8 us launch, and
+        # the tuned GEMM behind it beats the gathered 64x64-tile kernel by more than that.
+        self.implicit = (not self.direct and not self.small and cin % 16 == 0 and self.kh * self.kw <= 32 and
+                         os.environ.get("SPNET_IR_IMPLICIT_FWD", "0") == "1")
         self.w = eng.P(cname + "/kernel")
-        self.col = None if (self.direct or self.small) else eng.new(self.M, self.K)
+        # (an inference plan whose convolution runs as an implicit GEMM never needs the patch matrix)
+        no_col = self.direct or self.small or (self.implicit and not eng.train_capable)
+        self.col = None if no_col else eng.new(self.M, self.K)
         self.col_floats = 0 if (self.direct or self.small) else self.M * self.K
         self.out = _T(eng.new(B, OH, OW, cout))
         tr = eng.train_capable
@@ -1776,6 +1803,12 @@ class _IRConv:
     def srcs(self):
         return [self.src]
 
+    def gather_patches(self):
+        """The patch matrix of my input, for the weight-gradient GEMM (implicit-forward convolutions skipped it in forward)."""
+        if self.implicit:
+            L.spnet_patches(L.ptr(self.src.buf), L.ptr(self.col), self.e.B, self.H, self.W, self.cin, self.kh, self.kw,
+                            self.stride, self.same, 0, _stream())
+
     def fwd(self, training):
         e, C = self.e, self.cout
         y = self.out.buf
@@ -1783,6 +1816,22 @@ class _IRConv:
         if self.small:
             L.spnet_conv3x3_small(0, 3, C, self.stride, 0, L.ptr(self.src.buf), L.ptr(self.w), L.ptr(dst), e.B, self.H,
                                   self.W, e.ws_ptr(WS_MISC), WS_MISC[1], _stream())
+        elif self.implicit:
+            stats = training and not self.bias and e.bn_fold
+            prof = e.prof
+            t0 = prof.start() if prof is not None else None
+            L.spnet_conv_fwd_implicit(L.ptr(self.src.buf), L.ptr(self.w), L.ptr(dst), e.B, self.H, self.W, self.cin, C,
+                                      self.kh, self.kw, self.stride, self.same, L.ptr(self.b) if self.bias else None,
+                                      e.ws_ptr(WS_BNP) if stats else None,
+                                      __import__("ctypes").addressof(_stat_rows) if stats else None, _stream())
+            if prof is not None:
+                prof.stop("gemm", t0, 2.0 * self.M * C * self.K, ("conv implicit", self.M, C, self.K))
+            if stats:
+                L.spnet_bn_finalize_apply_ld(e.ws_ptr(WS_BNP), _stat_rows.value, L.ptr(self.yp), self.M, C, L.ptr(self.ones),
+                                             L.ptr(self.beta), L.ptr(self.mm), L.ptr(self.mv), L.ptr(self.save),
+                                             self.save[C:].data_ptr(), L.ptr(self.ss), ACT_RELU if self.relu else ACT_NONE,
+                                             None, L.ptr(y), self.ldy, BN_EPS, BN_MOMENTUM, _stream())
+                return
         else:
             if not self.direct:
                 L.spnet_patches(L.ptr(self.src.buf), L.ptr(self.col), e.B, self.H, self.W, self.cin, self.kh, self.kw,
@@ -1791,10 +1840,10 @@ class _IRConv:
                 # BatchNorm statistics out of the GEMM accumulators, finalize + normalise + ReLU in one more launch
                 # (two when the GEMM leaves more than 128 partial rows): no reduction pass over yp
                 rows = _gemm_colstats(self._A(), self.K, self.w, C, dst, C, self.M, C, self.K, e)
-                L.spnet_bn_finalize_apply(e.ws_ptr(WS_BNP), rows, L.ptr(self.yp), self.M, C, L.ptr(self.ones),
-                                          L.ptr(self.beta), L.ptr(self.mm), L.ptr(self.mv), L.ptr(self.save),
-                                          self.save[C:].data_ptr(), L.ptr(self.ss), ACT_RELU if self.relu else ACT_NONE,
-                                          None, L.ptr(y), BN_EPS, BN_MOMENTUM, _stream())
+                L.spnet_bn_finalize_apply_ld(e.ws_ptr(WS_BNP), rows, L.ptr(self.yp), self.M, C, L.ptr(self.ones),
+                                             L.ptr(self.beta), L.ptr(self.mm), L.ptr(self.mv), L.ptr(self.save),
+                                             self.save[C:].data_ptr(), L.ptr(self.ss), ACT_RELU if self.relu else ACT_NONE,
+                                             None, L.ptr(y), self.ldy, BN_EPS, BN_MOMENTUM, _stream())
                 return
             _gemm(self._A(), K_MAJOR, self.K, self.w, OUT_MAJOR, C, dst, C, self.M, C, self.K, e,
                   bias=self.b if self.bias else None)
@@ -1802,12 +1851,12 @@ class _IRConv:
             return
         act = ACT_RELU if self.relu else ACT_NONE
         if training:
-            L.spnet_bn_fwd_train(L.ptr(self.yp), self.M, C, L.ptr(self.ones), L.ptr(self.beta), L.ptr(self.mm), L.ptr(self.mv),
-                                 L.ptr(self.save), self.save[C:].data_ptr(), L.ptr(self.ss), act, None, 0, L.ptr(y), BN_EPS,
-                                 BN_MOMENTUM, e.ws_ptr(WS_MISC), _stream())
+            L.spnet_bn_fwd_train_ld(L.ptr(self.yp), self.M, C, L.ptr(self.ones), L.ptr(self.beta), L.ptr(self.mm),
+                                    L.ptr(self.mv), L.ptr(self.save), self.save[C:].data_ptr(), L.ptr(self.ss), act, None, 0,
+                                    L.ptr(y), self.ldy, BN_EPS, BN_MOMENTUM, e.ws_ptr(WS_MISC), _stream())
         else:
-            L.spnet_bn_fwd_infer(L.ptr(self.yp), self.M, C, L.ptr(self.ones), L.ptr(self.beta), L.ptr(self.mm),
-                                 L.ptr(self.mv), L.ptr(self.ss), act, None, 0, L.ptr(y), BN_EPS, _stream())
+            L.spnet_bn_fwd_infer_ld(L.ptr(self.yp), self.M, C, L.ptr(self.ones), L.ptr(self.beta), L.ptr(self.mm),
+                                    L.ptr(self.mv), L.ptr(self.ss), act, None, 0, L.ptr(y), self.ldy, BN_EPS, _stream())
 
     def bwd(self, net):
         e, C, g = self.e, self.cout, self.out.g
@@ -1828,6 +1877,7 @@ class _IRConv:
                                       self.W, e.ws_ptr(region), region[1], _stream())
         else:
             def wgrad(region):
+                self.gather_patches()
                 _gemm(self._A(), OUT_MAJOR, self.K, g, OUT_MAJOR, C, self.gw, C, self.K, C, self.M, e, region=region)
         if self.deferred_wgrad:
             pass                                     # IRv2Backbone.flush_wgrads: g (= dy now) stays as it is until then
@@ -1906,14 +1956,16 @@ class _IRConcat:
         self.rows = B * H * W
         self.out = _T(eng.new(B, H, W, sum(self.cs)))
         self.dparts = [eng.new(*t.buf.shape) for t in srcs] if eng.train_capable else None
+        self.direct = [False] * len(srcs)            # IRv2Backbone: this branch writes into my buffer itself
 
     def srcs(self):
         return self.srcs_
 
     def fwd(self, training):
         ct, off = sum(self.cs), 0
-        for t, c in zip(self.srcs_, self.cs):
-            L.spnet_copy_cols(L.ptr(t.buf), c, self.out.buf.data_ptr() + 4 * off, ct, self.rows, c, 0, _stream())
+        for t, c, direct in zip(self.srcs_, self.cs, self.direct):
+            if not direct:
+                L.spnet_copy_cols(L.ptr(t.buf), c, self.out.buf.data_ptr() + 4 * off, ct, self.rows, c, 0, _stream())
             off += c
 
     def bwd(self, net):
@@ -1921,9 +1973,9 @@ class _IRConcat:
         for t, c, d in zip(self.srcs_, self.cs, self.dparts):
             p = t.owner
             if p is not None and getattr(p, "sum_rows", 0):      # + ReLU mask and BatchNorm sums of the branch's last layer
-                L.spnet_copy_cols_bnsums(g.data_ptr() + 4 * off, ct, L.ptr(d), self.rows, c, L.ptr(t.buf), L.ptr(p.yp),
-                                         L.ptr(p.save), p.save[c:].data_ptr(), int(p.relu), L.ptr(p.sum_part), p.sum_rows,
-                                         _stream())
+                L.spnet_copy_cols_bnsums(g.data_ptr() + 4 * off, ct, L.ptr(d), self.rows, c, L.ptr(t.buf), p.ldy,
+                                         L.ptr(p.yp), L.ptr(p.save), p.save[c:].data_ptr(), int(p.relu), L.ptr(p.sum_part),
+                                         p.sum_rows, _stream())
             else:
                 L.spnet_copy_cols(g.data_ptr() + 4 * off, ct, L.ptr(d), c, self.rows, c, 0, _stream())
             _ir_acc(t, d, self.e)

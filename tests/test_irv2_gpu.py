@@ -35,13 +35,14 @@ def test_structure_matches_keras_inception_resnet_v2():
 @pytest.mark.parametrize("B,H,W,C,kh,kw,stride,same", [(2, 9, 11, 32, 3, 3, 1, 1), (2, 10, 14, 128, 1, 7, 1, 1),
                                                        (2, 10, 14, 160, 7, 1, 1, 1), (1, 21, 29, 48, 5, 5, 1, 1),
                                                        (2, 21, 29, 320, 3, 3, 2, 0), (3, 13, 12, 64, 3, 3, 1, 0),
-                                                       (2, 6, 4, 192, 1, 3, 1, 1), (2, 6, 4, 224, 3, 1, 1, 1)])
+                                                       (2, 6, 4, 192, 1, 3, 1, 1), (2, 6, 4, 224, 3, 1, 1, 1),
+                                                       (2, 21, 29, 32, 3, 3, 1, 1), (1, 9, 11, 288, 3, 3, 2, 0)])
 def test_general_convolution_through_patches_and_gemm(B, H, W, C, kh, kw, stride, same):
     _need_gpu()
     from spnet_amd import _lib as L
     st = torch.cuda.current_stream().cuda_stream
     rs = np.random.RandomState(C + kh * 7 + kw)
-    cout = 64
+    cout = {288: 48, 160: 96, 224: 160, 48: 36}.get(C, 64)       # (also widths that are not whole 64-column tiles)
     x = torch.tensor(rs.randn(B, H, W, C), dtype=torch.float64, requires_grad=True)
     w = torch.tensor(rs.randn(kh, kw, C, cout) / np.sqrt(kh * kw * C), dtype=torch.float64, requires_grad=True)
     y = T.conv2d_general(x, w, stride, "same" if same else "valid")
@@ -66,6 +67,28 @@ def test_general_convolution_through_patches_and_gemm(B, H, W, C, kh, kw, stride
     L.spnet_gemm_f32(col.data_ptr(), 1, K, dyd.data_ptr(), 1, cout, gw.data_ptr(), cout, K, cout, M, 0, ws.data_ptr(),
                      ws.numel(), None, 0, st)
     np.testing.assert_allclose(gw.cpu().numpy().reshape(w.shape), w.grad.numpy(), rtol=1e-4, atol=1e-4 * np.sqrt(M))
+    # the forward convolution as an implicit GEMM (no patch matrix): same result as patches + GEMM on the 64x64 tile
+    # bit for bit, BatchNorm column sums from the epilogue, bias
+    if C % 16 == 0:
+        import ctypes
+        y64 = torch.empty(M, cout, device="cuda")
+        L.spnet_gemm_f32(col.data_ptr(), 0, K, wd.data_ptr(), 1, cout, y64.data_ptr(), cout, M, cout, K, 1, None, 0, None, 3, st)
+        yi = torch.full((M, cout), float("nan"), device="cuda")
+        cs = torch.full(((M + 31) // 32 * 2 * cout,), float("nan"), device="cuda")
+        nrows = ctypes.c_int(0)
+        L.spnet_conv_fwd_implicit(xd.data_ptr(), wd.data_ptr(), yi.data_ptr(), B, H, W, C, cout, kh, kw, stride, same, None,
+                                  cs.data_ptr(), ctypes.addressof(nrows), st)
+        assert torch.equal(yi, y64)
+        assert nrows.value == (M + 63) // 64
+        ps = cs[:nrows.value * 2 * cout].reshape(nrows.value, 2, cout).sum(0).cpu().double().numpy()
+        y_np = y.detach().numpy().reshape(M, cout)
+        np.testing.assert_allclose(ps[0], y_np.sum(0), rtol=1e-4, atol=1e-3 * np.sqrt(M))
+        np.testing.assert_allclose(ps[1], (y_np ** 2).sum(0), rtol=1e-4, atol=1e-3)
+        bias = torch.tensor(rs.randn(cout), dtype=torch.float32).cuda()
+        yb = torch.empty(M, cout, device="cuda")
+        L.spnet_conv_fwd_implicit(xd.data_ptr(), wd.data_ptr(), yb.data_ptr(), B, H, W, C, cout, kh, kw, stride, same,
+                                  bias.data_ptr(), None, None, st)
+        assert torch.equal(yb, yi + bias)
     # the adjoint gather that also masks with the producer's ReLU and leaves its BatchNorm-backward sums
     rows = int(L.spnet_grad_bnsums_rows(B * H * W, 512))
     assert 1 <= rows <= 512
@@ -89,10 +112,17 @@ def test_general_convolution_through_patches_and_gemm(B, H, W, C, kh, kw, stride
     cat = torch.tensor(rs.randn(B * H * W, C + 32), dtype=torch.float32).cuda()
     d = torch.full((B * H * W, C), float("nan"), device="cuda")
     part = torch.full((rows, 2, C), float("nan"), device="cuda")
-    L.spnet_copy_cols_bnsums(cat.data_ptr() + 4 * 32, C + 32, d.data_ptr(), B * H * W, C, yprod.data_ptr(), ypre.data_ptr(),
+    L.spnet_copy_cols_bnsums(cat.data_ptr() + 4 * 32, C + 32, d.data_ptr(), B * H * W, C, yprod.data_ptr(), C, ypre.data_ptr(),
                              mu.data_ptr(), istd.data_ptr(), 1, part.data_ptr(), rows, st)
     want = cat[:, 32:] * (yprod.reshape(-1, C) > 0)
     assert torch.equal(d, want)
+    # the mask tensor may itself be a column block of the concatenated activation (row stride C + 32)
+    ywide = torch.tensor(rs.randn(B * H * W, C + 32), dtype=torch.float32).cuda()
+    ywide[:, 32:] = yprod.reshape(-1, C)
+    d2, part2 = torch.full_like(d, float("nan")), torch.full_like(part, float("nan"))
+    L.spnet_copy_cols_bnsums(cat.data_ptr() + 4 * 32, C + 32, d2.data_ptr(), B * H * W, C, ywide.data_ptr() + 4 * 32, C + 32,
+                             ypre.data_ptr(), mu.data_ptr(), istd.data_ptr(), 1, part2.data_ptr(), rows, st)
+    assert torch.equal(d2, d) and torch.equal(part2, part)
     g64 = want.cpu().double()
     xh = (ypre.cpu().double().reshape(-1, C) - mu.cpu().double()) * istd.cpu().double()
     sums = part.sum(0).cpu().double().numpy()

@@ -397,6 +397,49 @@ def test_batchnorm_finalize_from_many_partial_rows(L, P, C):
         assert torch.equal(a, b)
 
 
+@pytest.mark.parametrize("M,C,P", [(9744, 32, 153), (2240, 192, 24), (384, 256, 4), (9744, 96, 300)])
+def test_batchnorm_forward_into_a_column_block(L, M, C, P):
+    """The `_ld` forms (finalize + apply, stand-alone training forward, inference forward) with the output a column block
+    of a wider tensor == the dense forms, bit for bit, and nothing outside the block is touched."""
+    rs = np.random.RandomState(M + C)
+    x = dev(rs.randn(M, C))
+    part = dev(rs.randn(P, 2, C) * 3)
+    part[:, 1] = part[:, 1].abs() * 40 + 10
+    gamma, beta = dev(rs.rand(C) + 0.5), dev(rs.randn(C) * 0.3)
+    wide, off = C + 64, 32
+
+    def fresh():
+        return (dev(np.full(C, 0.25)), dev(np.full(C, 0.75)), torch.full((2 * C,), float("nan"), device="cuda"),
+                torch.full((2 * C,), float("nan"), device="cuda"))
+
+    ws = torch.empty(L.spnet_bn_ws(M, C) + 16, device="cuda")
+    for kind in ("finalize_apply", "train", "infer"):
+        outs = []
+        for ld in (C, wide):
+            mm, mv, save, ss = fresh()
+            buf = torch.full((M, ld), -7.0, device="cuda")
+            y = buf.data_ptr() + (4 * off if ld != C else 0)
+            if kind == "finalize_apply":
+                L.spnet_bn_finalize_apply_ld(part.clone().data_ptr(), P, x.data_ptr(), M, C, gamma.data_ptr(), beta.data_ptr(),
+                                             mm.data_ptr(), mv.data_ptr(), save.data_ptr(), save[C:].data_ptr(), ss.data_ptr(), 1,
+                                             None, y, ld, 1e-3, 0.99, st())
+            elif kind == "train":
+                L.spnet_bn_fwd_train_ld(x.data_ptr(), M, C, gamma.data_ptr(), beta.data_ptr(), mm.data_ptr(), mv.data_ptr(),
+                                        save.data_ptr(), save[C:].data_ptr(), ss.data_ptr(), 1, None, 0, y, ld, 1e-3, 0.99,
+                                        ws.data_ptr(), st())
+            else:
+                L.spnet_bn_fwd_infer_ld(x.data_ptr(), M, C, gamma.data_ptr(), beta.data_ptr(), mm.data_ptr(), mv.data_ptr(),
+                                        ss.data_ptr(), 1, None, 0, y, ld, 1e-3, st())
+            torch.cuda.synchronize()
+            outs.append((buf, ss))
+        dense, blocked = outs[0][0], outs[1][0]
+        assert torch.equal(blocked[:, off:off + C], dense) and torch.equal(outs[0][1], outs[1][1])
+        assert float((blocked[:, :off] + 7.0).abs().max()) == 0.0 and float((blocked[:, off + C:] + 7.0).abs().max()) == 0.0
+    with pytest.raises(L.HipError):                     # stride narrower than the block
+        L.spnet_bn_fwd_infer_ld(x.data_ptr(), M, C, gamma.data_ptr(), beta.data_ptr(), mm.data_ptr(), mv.data_ptr(),
+                                ss.data_ptr(), 1, None, 0, buf.data_ptr(), C - 4, 1e-3, st())
+
+
 @pytest.mark.parametrize("M,C", [(6144, 728), (1536, 1536), (500, 36)])
 def test_batchnorm_backward_from_partial_sums(L, M, C):
     """spnet_bn_bwd_from_partials against the closed form (float64), through BOTH of its paths: the one-launch form
