@@ -217,6 +217,9 @@ int spnet_avgpool3x3s1_same(const float* in, float* out, int B, int H, int W, in
  * spnet_gemm_f32 on col and the flattened HWIO kernel (1x1 convs skip the patch matrix). */
 int spnet_patches(const float* in, float* out, int B, int H, int W, int C, int KH, int KW, int stride, int same, int backward,
                   void* stream);
+/* The forward gather of an input whose pixels are ldx floats apart (a column block of a wider tensor). */
+int spnet_patches_ld(const float* in, long ldx, float* out, int B, int H, int W, int C, int KH, int KW, int stride, int same,
+                     void* stream);
 /* The forward convolution itself as an implicit GEMM: A tiles gathered from x tap by tap (no patch matrix written or
  * read), same k order as spnet_patches + spnet_gemm_f32.  x [B][H][W][cin], w HWIO [KH][KW][cin][cout] -> y
  * [B][OH][OW][cout] (+ bias); cin % 16 == 0, cout % 4 == 0, KH*KW <= 32, stride 1 | 2.  colstats (or NULL): BatchNorm
@@ -236,6 +239,19 @@ int spnet_patches_bwd_bnsums(const float* dcol, float* dx, int B, int H, int W, 
                              float* partial, int rows, void* stream);
 int spnet_copy_cols_bnsums(const float* src, int lds, float* dst, long M, int C, const float* y, long ldy, const float* yp,
                            const float* mean, const float* invstd, int relu, float* partial, int rows, void* stream);
+/* `_ld` forms: row strides for dx (lddx / ldd), yp (ldyp) and the partial rows (ldp floats per half-row) -- the layer may be one
+ * member of a group of sibling 1x1 convolutions that share a concatenated pre-normalisation tensor, gradient buffer and
+ * partial rows (column blocks of [.][Ct] tensors; IRv2Backbone runs such a group as one GEMM + one BatchNormalization). */
+int spnet_patches_bwd_bnsums_ld(const float* dcol, float* dx, long lddx, int B, int H, int W, int C, int KH, int KW, int stride,
+                                int same, const float* y, long ldy, const float* yp, long ldyp, const float* mean,
+                                const float* invstd, int relu, float* partial, long ldp, int rows, void* stream);
+int spnet_copy_cols_bnsums_ld(const float* src, int lds, float* dst, long ldd, long M, int C, const float* y, long ldy,
+                              const float* yp, long ldyp, const float* mean, const float* invstd, int relu, float* partial,
+                              long ldp, int rows, void* stream);
+/* Many strided column-block copies in one launch: jobs (device memory) = njobs x {src, dst, rows, cols, lds, ldd} as six
+ * 64-bit words; max_elems = the largest rows*cols (sizes the grid).  The kernels of sibling convolutions gathered into
+ * their concatenated GEMM operand after every optimizer step. */
+int spnet_copy_cols_batched(const void* jobs, int njobs, long max_elems, void* stream);
 /* inception_resnet_block: y = x + scale*up (+ ReLU); backward: dx = g*(y>0 if relu), dup = scale*dx. */
 int spnet_resadd(const float* x, const float* up, float* y, long n, float scale, int relu, void* stream);
 int spnet_resadd_bwd(const float* y, const float* g, float* dx, float* dup, long n, float scale, int relu, void* stream);

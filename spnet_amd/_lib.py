@@ -74,11 +74,17 @@ _SIGS = {
     "spnet_maxpool3x3s2_valid_bwd": (c_int, [P, P, P, c_int, c_int, c_int, c_int, P]),
     "spnet_avgpool3x3s1_same": (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, P]),
     "spnet_patches": (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P]),
+    "spnet_patches_ld": (c_int, [P, c_long, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P]),
     "spnet_conv_fwd_implicit": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P, P, P]),
     "spnet_grad_bnsums_rows": (c_long, [c_long, c_int]),
     "spnet_patches_bwd_bnsums": (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P, P, P, c_int, P,
                                          c_int, P]),
     "spnet_copy_cols_bnsums": (c_int, [P, c_int, P, c_long, c_int, P, c_long, P, P, P, c_int, P, c_int, P]),
+    "spnet_patches_bwd_bnsums_ld": (c_int, [P, P, c_long, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, c_long, P,
+                                            c_long, P, P, c_int, P, c_long, c_int, P]),
+    "spnet_copy_cols_bnsums_ld": (c_int, [P, c_int, P, c_long, c_long, c_int, P, c_long, P, c_long, P, P, c_int, P, c_long,
+                                          c_int, P]),
+    "spnet_copy_cols_batched": (c_int, [P, c_int, c_long, P]),
     "spnet_resadd": (c_int, [P, P, P, c_long, c_float, c_int, P]),
     "spnet_resadd_bwd": (c_int, [P, P, P, P, c_long, c_float, c_int, P]),
     "spnet_copy_cols": (c_int, [P, c_int, P, c_int, c_long, c_int, c_int, P]),

@@ -8,7 +8,8 @@
 
 // col[(b,oh,ow)][(kh,kw,c)] = x[b, oh*s - pt + kh, ow*s - pl + kw, c]  (zero outside the image)
 __global__ __launch_bounds__(256) void im2col_kernel(const float* __restrict__ x, float* __restrict__ col, int Bn, int H,
-                                                     int W, int C, int KH, int KW, int s, int pt, int pl, int OH, int OW) {
+                                                     int W, int C, int KH, int KW, int s, int pt, int pl, int OH, int OW,
+                                                     long ldx) {
   const int c4n = C >> 2;
   const long total = (long)Bn * OH * OW * KH * KW * c4n;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
@@ -24,7 +25,7 @@ __global__ __launch_bounds__(256) void im2col_kernel(const float* __restrict__ x
     const int b = (int)(t / OH);
     const int h = oh * s - pt + kh, w = ow * s - pl + kw;
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (h >= 0 && h < H && w >= 0 && w < W) v = *reinterpret_cast<const float4*>(x + (((long)b * H + h) * W + w) * C + c4 * 4);
+    if (h >= 0 && h < H && w >= 0 && w < W) v = *reinterpret_cast<const float4*>(x + (((long)b * H + h) * W + w) * ldx + c4 * 4);
     *reinterpret_cast<float4*>(col + i * 4) = v;
   }
 }
@@ -74,11 +75,12 @@ __global__ __launch_bounds__(256) void col2im_kernel(const float* __restrict__ d
 #define GS_CL 8
 template <int MODE>
 __global__ __launch_bounds__(256) void grad_bnsums_kernel(const float* __restrict__ src, int lds, float* __restrict__ dx,
-                                                          int Bn, int H, int W, int C, int KH, int KW, int s, int pt, int pl,
-                                                          int OH, int OW, const float* __restrict__ y, long ldy,
-                                                          const float* __restrict__ yp, const float* __restrict__ mean,
+                                                          long lddx, int Bn, int H, int W, int C, int KH, int KW, int s,
+                                                          int pt, int pl, int OH, int OW, const float* __restrict__ y,
+                                                          long ldy, const float* __restrict__ yp, long ldyp,
+                                                          const float* __restrict__ mean,
                                                           const float* __restrict__ invstd, int relu,
-                                                          float* __restrict__ partial) {
+                                                          float* __restrict__ partial, long ldp) {
   __shared__ __attribute__((aligned(16))) float4 red4[32 * 2 * GS_CL];
   const int c4n = C >> 2;
   const int c4 = blockIdx.x * GS_CL + threadIdx.x;
@@ -114,13 +116,13 @@ __global__ __launch_bounds__(256) void grad_bnsums_kernel(const float* __restric
           }
         }
       }
-      const float4 xv = *reinterpret_cast<const float4*>(yp + r * C + c4 * 4);
+      const float4 xv = *reinterpret_cast<const float4*>(yp + r * ldyp + c4 * 4);
       if (relu) {
         const float4 yv = *reinterpret_cast<const float4*>(y + r * ldy + c4 * 4);
         g.x = yv.x > 0.f ? g.x : 0.f; g.y = yv.y > 0.f ? g.y : 0.f;
         g.z = yv.z > 0.f ? g.z : 0.f; g.w = yv.w > 0.f ? g.w : 0.f;
       }
-      *reinterpret_cast<float4*>(dx + r * C + c4 * 4) = g;
+      *reinterpret_cast<float4*>(dx + r * lddx + c4 * 4) = g;
       s0.x += g.x; s0.y += g.y; s0.z += g.z; s0.w += g.w;
       s1.x = fmaf(g.x, (xv.x - mu.x) * is.x, s1.x); s1.y = fmaf(g.y, (xv.y - mu.y) * is.y, s1.y);
       s1.z = fmaf(g.z, (xv.z - mu.z) * is.z, s1.z); s1.w = fmaf(g.w, (xv.w - mu.w) * is.w, s1.w);
@@ -136,7 +138,7 @@ __global__ __launch_bounds__(256) void grad_bnsums_kernel(const float* __restric
         const float4 u = red4[(yy * 2 + q) * GS_CL + threadIdx.x];
         sm.x += u.x; sm.y += u.y; sm.z += u.z; sm.w += u.w;
       }
-      *reinterpret_cast<float4*>(partial + ((long)blockIdx.y * 2 + q) * C + c4 * 4) = sm;
+      *reinterpret_cast<float4*>(partial + ((long)blockIdx.y * 2 + q) * ldp + c4 * 4) = sm;
     }
   }
 }
@@ -173,7 +175,7 @@ extern "C" int spnet_patches(const float* in, float* out, int B, int H, int W, i
   if (!backward) {
     const long total = (long)B * OH * OW * KH * KW * (C / 4);
     hipLaunchKernelGGL(im2col_kernel, dim3(spnet_ew_grid(total, 256)), dim3(256), 0, (hipStream_t)stream, in, out, B, H, W,
-                       C, KH, KW, stride, pt, pl, OH, OW);
+                       C, KH, KW, stride, pt, pl, OH, OW, (long)C);
   } else {
     const long total = (long)B * H * W * (C / 4);
     hipLaunchKernelGGL(col2im_kernel, dim3(spnet_ew_grid(total, 256)), dim3(256), 0, (hipStream_t)stream, in, out, B, H, W,
@@ -184,32 +186,91 @@ extern "C" int spnet_patches(const float* in, float* out, int B, int H, int W, i
 
 // spnet_patches(backward = 1) that also masks the gradient with the ReLU of the layer that produced x (y = its output,
 // relu != 0) and leaves that layer's BatchNorm-backward sums: partial[rows][2][C], rows <= spnet_grad_bnsums_rows(B*H*W, .).
-extern "C" int spnet_patches_bwd_bnsums(const float* dcol, float* dx, int B, int H, int W, int C, int KH, int KW, int stride,
-                                        int same, const float* y, const float* yp, const float* mean, const float* invstd,
-                                        int relu, float* partial, int rows, void* stream) {
+// The `_ld` forms take row strides for every per-pixel tensor: dx (lddx), yp (ldyp) and the partial rows (ldp floats per
+// [sum | sum*xhat] half-row): the differentiated layer may be ONE MEMBER of a group of sibling convolutions that share a
+// concatenated pre-normalisation tensor, gradient buffer and partial-sum rows (column blocks of [.][Ct] tensors).
+extern "C" int spnet_patches_bwd_bnsums_ld(const float* dcol, float* dx, long lddx, int B, int H, int W, int C, int KH, int KW,
+                                           int stride, int same, const float* y, long ldy, const float* yp, long ldyp,
+                                           const float* mean, const float* invstd, int relu, float* partial, long ldp,
+                                           int rows, void* stream) {
   if ((C & 3) || KH < 1 || KW < 1 || (stride != 1 && stride != 2) || !yp || !mean || !invstd || !partial || (relu && !y))
     return (int)hipErrorInvalidValue;
+  if (lddx < C || ldy < C || ldyp < C || ldp < C || ((lddx | ldy | ldyp | ldp) & 3)) return (int)hipErrorInvalidValue;
   int OH, OW, pt, pl;
   conv_geom(H, KH, stride, same, &OH, &pt);
   conv_geom(W, KW, stride, same, &OW, &pl);
   if (OH < 1 || OW < 1 || rows < 1 || rows > spnet_grad_bnsums_rows((long)B * H * W, rows)) return (int)hipErrorInvalidValue;
   dim3 grid((C / 4 + GS_CL - 1) / GS_CL, (unsigned)rows), block(GS_CL, 32);
-  hipLaunchKernelGGL(grad_bnsums_kernel<0>, grid, block, 0, (hipStream_t)stream, dcol, 0, dx, B, H, W, C, KH, KW, stride, pt,
-                     pl, OH, OW, y, (long)C, yp, mean, invstd, relu ? 1 : 0, partial);
+  hipLaunchKernelGGL(grad_bnsums_kernel<0>, grid, block, 0, (hipStream_t)stream, dcol, 0, dx, lddx, B, H, W, C, KH, KW,
+                     stride, pt, pl, OH, OW, y, ldy, yp, ldyp, mean, invstd, relu ? 1 : 0, partial, ldp);
   SPNET_RETURN_LAUNCH_STATUS();
+}
+extern "C" int spnet_patches_bwd_bnsums(const float* dcol, float* dx, int B, int H, int W, int C, int KH, int KW, int stride,
+                                        int same, const float* y, const float* yp, const float* mean, const float* invstd,
+                                        int relu, float* partial, int rows, void* stream) {
+  return spnet_patches_bwd_bnsums_ld(dcol, dx, C, B, H, W, C, KH, KW, stride, same, y, C, yp, C, mean, invstd, relu, partial,
+                                     C, rows, stream);
 }
 
 // dst[r][c] = src[r * lds + c] (* ReLU mask), c < C, dense dst -- the Concatenate backward of one branch -- with the same
 // BatchNorm-backward sums of the branch's last layer.
+extern "C" int spnet_copy_cols_bnsums_ld(const float* src, int lds, float* dst, long ldd, long M, int C, const float* y,
+                                         long ldy, const float* yp, long ldyp, const float* mean, const float* invstd,
+                                         int relu, float* partial, long ldp, int rows, void* stream) {
+  if ((C & 3) || (lds & 3) || M < 1 || !yp || !mean || !invstd || !partial || (relu && !y)) return (int)hipErrorInvalidValue;
+  if (ldd < C || ldy < C || ldyp < C || ldp < C || ((ldd | ldy | ldyp | ldp) & 3)) return (int)hipErrorInvalidValue;
+  if (rows < 1 || rows > spnet_grad_bnsums_rows(M, rows)) return (int)hipErrorInvalidValue;
+  dim3 grid((C / 4 + GS_CL - 1) / GS_CL, (unsigned)rows), block(GS_CL, 32);
+  hipLaunchKernelGGL(grad_bnsums_kernel<1>, grid, block, 0, (hipStream_t)stream, src, lds, dst, ldd, 1, 1, (int)M, C, 1, 1, 1,
+                     0, 0, 1, (int)M, y, ldy, yp, ldyp, mean, invstd, relu ? 1 : 0, partial, ldp);
+  SPNET_RETURN_LAUNCH_STATUS();
+}
 extern "C" int spnet_copy_cols_bnsums(const float* src, int lds, float* dst, long M, int C, const float* y, long ldy,
                                       const float* yp, const float* mean, const float* invstd, int relu, float* partial,
                                       int rows, void* stream) {
-  if ((C & 3) || (lds & 3) || M < 1 || !yp || !mean || !invstd || !partial || (relu && !y)) return (int)hipErrorInvalidValue;
-  if (ldy < C || (ldy & 3)) return (int)hipErrorInvalidValue;      // y may itself be a column block (row stride ldy)
-  if (rows < 1 || rows > spnet_grad_bnsums_rows(M, rows)) return (int)hipErrorInvalidValue;
-  dim3 grid((C / 4 + GS_CL - 1) / GS_CL, (unsigned)rows), block(GS_CL, 32);
-  hipLaunchKernelGGL(grad_bnsums_kernel<1>, grid, block, 0, (hipStream_t)stream, src, lds, dst, 1, 1, (int)M, C, 1, 1, 1, 0, 0,
-                     1, (int)M, y, ldy, yp, mean, invstd, relu ? 1 : 0, partial);
+  return spnet_copy_cols_bnsums_ld(src, lds, dst, C, M, C, y, ldy, yp, C, mean, invstd, relu, partial, C, rows, stream);
+}
+
+// Many strided column-block copies in one launch: job j copies rows_j x cols_j floats, dst_j[r * ldd_j + c] =
+// src_j[r * lds_j + c].  jobs (device memory) = njobs x {src pointer, dst pointer, rows, cols, lds, ldd} as six 64-bit
+// words; cols, lds, ldd multiples of 4.  (The kernels of sibling convolutions gathered into their concatenated GEMM
+// operand after every optimizer step: one launch for the whole network.)
+__global__ __launch_bounds__(256) void copy_cols_batched_kernel(const long long* __restrict__ jobs) {
+  const long long* jb = jobs + 6 * blockIdx.y;
+  const float* __restrict__ src = reinterpret_cast<const float*>(jb[0]);
+  float* __restrict__ dst = reinterpret_cast<float*>(jb[1]);
+  const long rows = jb[2];
+  const int c4n = (int)(jb[3] >> 2);
+  const long lds = jb[4], ldd = jb[5];
+  const long total = rows * c4n;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const long r = i / c4n;
+    const int c = (int)(i % c4n) * 4;
+    *reinterpret_cast<float4*>(dst + r * ldd + c) = *reinterpret_cast<const float4*>(src + r * lds + c);
+  }
+}
+
+extern "C" int spnet_copy_cols_batched(const void* jobs, int njobs, long max_elems, void* stream) {
+  if (!jobs || njobs < 1 || max_elems < 4) return (int)hipErrorInvalidValue;
+  long gx = (max_elems / 4 + 255) / 256;
+  if (gx > 64) gx = 64;
+  hipLaunchKernelGGL(copy_cols_batched_kernel, dim3((unsigned)gx, njobs), dim3(256), 0, (hipStream_t)stream,
+                     reinterpret_cast<const long long*>(jobs));
+  SPNET_RETURN_LAUNCH_STATUS();
+}
+
+// The patch gather of an input whose pixels are ldx floats apart (ldx >= C): x is a column block of a wider tensor (the
+// output of one member of a sibling group, _IRGroup).
+extern "C" int spnet_patches_ld(const float* in, long ldx, float* out, int B, int H, int W, int C, int KH, int KW, int stride,
+                                int same, void* stream) {
+  if ((C & 3) || (ldx & 3) || ldx < C || KH < 1 || KW < 1 || (stride != 1 && stride != 2)) return (int)hipErrorInvalidValue;
+  int OH, OW, pt, pl;
+  conv_geom(H, KH, stride, same, &OH, &pt);
+  conv_geom(W, KW, stride, same, &OW, &pl);
+  if (OH < 1 || OW < 1) return (int)hipErrorInvalidValue;
+  const long total = (long)B * OH * OW * KH * KW * (C / 4);
+  hipLaunchKernelGGL(im2col_kernel, dim3(spnet_ew_grid(total, 256)), dim3(256), 0, (hipStream_t)stream, in, out, B, H, W, C,
+                     KH, KW, stride, pt, pl, OH, OW, ldx);
   SPNET_RETURN_LAUNCH_STATUS();
 }
 

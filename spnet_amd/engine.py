@@ -222,6 +222,40 @@ def irv2_program():
     return ops
 
 
+def irv2_sibling_groups():
+    """Groups of conv2d_bn layers of the program that are 1x1 / stride-1 convolutions of ONE tensor (the first layer of
+    every branch of an inception block reads the block input): [[conv names], ...] with their BatchNormalization names.
+    The executor runs such a group as one GEMM over the concatenated kernels and one BatchNormalization over the
+    concatenated channels (IRv2Backbone); the parameter layout keeps the group's beta / moving statistics adjacent."""
+    ver, readers = {}, {}
+    for op in irv2_program():
+        kind = op[0]
+        if kind == "conv":
+            _, cname, bname, src, dst, cin, cout, kk, stride, same, relu, bias = op
+            if kk == (1, 1) and stride == 1 and not bias:
+                readers.setdefault((src, ver.get(src, 0)), []).append((cname, bname, cout))
+            ver[dst] = ver.get(dst, 0) + 1
+        elif kind in ("maxpool", "avgpool"):
+            ver[op[2]] = ver.get(op[2], 0) + 1
+        elif kind == "concat":
+            ver[op[2]] = ver.get(op[2], 0) + 1
+        else:
+            ver[op[3]] = ver.get(op[3], 0) + 1
+    return [g for g in readers.values() if len(g) >= 2]
+
+
+def param_packs(backbone):
+    """Lists of parameter names that must sit back to back in the flat buffers (no alignment padding between them), so
+    that a slice over the first one's offset spans them all."""
+    if backbone != "InceptionResNetV2":
+        return []
+    packs = []
+    for g in irv2_sibling_groups():
+        for suffix in ("/beta", "/moving_mean", "/moving_variance"):
+            packs.append([bname + suffix for _, bname, _ in g])
+    return packs
+
+
 def irv2_out_hw(H, W):
     h, w = H // 2, W // 2
     for k, s_ in ((3, 2), (3, 1), (3, 2), (3, 1), (3, 2), (3, 2), (3, 2)):     # valid convs / pools that shrink the plane
@@ -422,12 +456,23 @@ class Engine:
         l2 = sorted((s for s in tr if s[3]), key=lambda s: s[0] != "FinalOutput/kernel")
         dwk = [s for s in tr if not s[3] and s[0].endswith("depthwise_kernel")]
         order = l2 + dwk + [s for s in tr if not s[3] and not s[0].endswith("depthwise_kernel")]
+        # (packs: names that sit back to back with no padding between them -- param_packs; a pack is placed where its
+        # first member comes up in `order` and starts on an aligned offset)
+        pack_of = {n: tuple(p) for p in param_packs(self.backbone) for n in p}
+        shape_of = {s[0]: s[1] for s in specs}
         off = 0
         self.p_off = OrderedDict()
         for name, shape, _, l2 in order:
-            n = int(np.prod(shape))
-            self.p_off[name] = (off, n, shape)
-            off += (n + ALIGN - 1) // ALIGN * ALIGN
+            if name in self.p_off:
+                continue                 # placed with its pack
+            for member in pack_of.get(name, (name,)):
+                mshape = shape_of[member]
+                n = int(np.prod(mshape))
+                if member in pack_of and (n & 3):
+                    raise ValueError("packed parameters must be multiples of 4 floats: %s" % member)
+                self.p_off[member] = (off, n, mshape)
+                off += n if member in pack_of else (n + ALIGN - 1) // ALIGN * ALIGN
+            off = (off + ALIGN - 1) // ALIGN * ALIGN
             if l2:
                 self.l2_n = off          # prefix (incl. alignment padding, which stays zero)
             if name.endswith("depthwise_kernel"):
@@ -438,10 +483,13 @@ class Engine:
         s_off = 0
         self.s_off = OrderedDict()
         for name, shape, tr, _ in specs:
-            if not tr:
-                n = int(np.prod(shape))
-                self.s_off[name] = (s_off, n, shape)
-                s_off += (n + ALIGN - 1) // ALIGN * ALIGN
+            if not tr and name not in self.s_off:
+                for member in pack_of.get(name, (name,)):
+                    mshape = shape_of[member]
+                    n = int(np.prod(mshape))
+                    self.s_off[member] = (s_off, n, mshape)
+                    s_off += n if member in pack_of else (n + ALIGN - 1) // ALIGN * ALIGN
+                s_off = (s_off + ALIGN - 1) // ALIGN * ALIGN
         z = lambda n: torch.zeros(n, device=self.dev, dtype=torch.float32)
         self.theta = z(self.n_theta)
         self.stats = z(s_off)
@@ -1632,6 +1680,33 @@ class IRv2Backbone(Node):
         for o in self.ops:
             for t in o.srcs():
                 t.consumers += 1
+        # Sibling 1x1 convolutions (the first layer of every branch of a block reads the block input) as ONE GEMM + ONE
+        # BatchNormalization (_IRGroup).  In training every member needs its one consumer to be a k x k convolution or a
+        # Concatenate (they leave the masked gradient and the BatchNorm sums in the group's blocks): true for every
+        # group of the network.  SPNET_IR_MERGE_SIBLINGS=0: layer by layer.
+        self.groups, self._wm_jobs, self._wm_ver = [], None, -1
+        fuse_sums = os.environ.get("SPNET_IR_FUSE_BNSUMS", "1") != "0"
+        if os.environ.get("SPNET_IR_MERGE_SIBLINGS", "1") != "0" and (fuse_sums or not eng.train_capable):
+            consumer = {}
+            for o in self.ops:
+                for t in o.srcs():
+                    consumer[id(t)] = o
+            by_src = OrderedDict()
+            for o in self.ops:
+                if isinstance(o, _IRConv) and o.direct and not o.bias and not o.small and o.relu:
+                    by_src.setdefault(id(o.src), []).append(o)
+            for ms in by_src.values():
+                ok = len(ms) >= 2
+                for m in ms:
+                    c = consumer.get(id(m.out))
+                    ok = ok and m.out.consumers == 1 and (isinstance(c, _IRConcat) or
+                                                          (isinstance(c, _IRConv) and not c.direct and not c.small))
+                if ok:
+                    self.groups.append(_IRGroup(eng, self, ms))
+            for o in self.ops:        # (a consumer that counted on the implicit forward now reads a column block: patch matrix)
+                if isinstance(o, _IRConv) and not o.direct and not o.small and o.col is None:
+                    if not o.src.buf.is_contiguous():
+                        o.col = eng.new(o.M, o.K)
         # A conv2d_bn branch whose only consumer is a Concatenate writes its output straight into that buffer (its
         # BatchNorm apply pass gets the row stride of the concatenated tensor): no copy pass in forward.  The tensor
         # stays a strided view for everyone who looks at it (the Concatenate backward reads the ReLU mask from it).
@@ -1643,7 +1718,7 @@ class IRv2Backbone(Node):
                 ct, off = sum(o.cs), 0
                 for i, (t, c) in enumerate(zip(o.srcs_, o.cs)):
                     p = t.owner
-                    if isinstance(p, _IRConv) and not p.bias and not p.small and t.consumers == 1:
+                    if isinstance(p, _IRConv) and not p.bias and not p.small and t.consumers == 1 and p.group is None:
                         t.buf = o.out.buf[..., off:off + c]
                         p.ldy = ct
                         o.direct[i] = True
@@ -1655,7 +1730,7 @@ class IRv2Backbone(Node):
             for o in self.ops:
                 for t in o.srcs():
                     p = t.owner
-                    ok = (isinstance(p, _IRConv) and not p.bias and t.consumers == 1 and
+                    ok = (isinstance(p, _IRConv) and not p.bias and t.consumers == 1 and p.group is None and
                           ((isinstance(o, _IRConv) and not o.direct and not o.small) or isinstance(o, _IRConcat)))
                     if ok:
                         # (up to 512 rows where the one-launch BatchNorm backward takes them: bn_fuse_ok in bn.hip)
@@ -1673,16 +1748,18 @@ class IRv2Backbone(Node):
             by_shape = {}
             for o in self.ops:
                 if isinstance(o, _IRConv) and not o.small:
-                    by_shape.setdefault((o.K, o.cout, o.M), []).append(o)
+                    ldb = o.group.Ct if o.group is not None else o.cout      # dy of a sibling-group member: a column block
+                    by_shape.setdefault((o.K, o.cout, o.M, ldb), []).append(o)
             need = 0
-            for (K, C, M), members in by_shape.items():
+            for (K, C, M, ldb), members in by_shape.items():
                 if len(members) < 2:
                     continue
                 tile = __import__("ctypes").c_int(0)
                 ksl = int(L.spnet_gemm_batched_ksplit(K, C, M, len(members), __import__("ctypes").addressof(tile)))
                 for o in members:
                     o.deferred_wgrad = True
-                self.wg_groups.append(dict(members=members, K=K, C=C, M=M, ksl=ksl, tile=tile.value, table=None, key=None))
+                self.wg_groups.append(dict(members=members, K=K, C=C, M=M, ldb=ldb, ksl=ksl, tile=tile.value, table=None,
+                                           key=None))
                 if ksl > 1:
                     need = max(need, len(members) * ksl * K * C)
             self.wg_ws = eng.new(need) if need else None
@@ -1692,13 +1769,33 @@ class IRv2Backbone(Node):
             self.ones[C] = (torch.ones(C, device=self.e.dev, dtype=torch.float32), self.e.new(C))
         return self.ones[C]
 
+    def refresh_wm(self):
+        """The kernels of every sibling group gathered side by side into its GEMM operand: one launch for the network."""
+        if not self.groups:
+            return
+        e = self.e
+        if self._wm_jobs is None:
+            flat, mx = [], 4
+            for G in self.groups:
+                for m in G.members:
+                    flat += [m.w.data_ptr(), G.Wm.data_ptr() + 4 * m.c0, G.cin, m.cout, m.cout, G.Ct]
+                    mx = max(mx, G.cin * m.cout)
+            self._wm_jobs = (torch.tensor(flat, dtype=torch.int64, device=e.dev), len(flat) // 6, mx)
+        table, nj, mx = self._wm_jobs
+        L.spnet_copy_cols_batched(table.data_ptr(), nj, mx, _stream())
+        self._wm_ver = e._tver[0]
+
     def fwd(self, training):
+        # (training: every step follows an optimizer step -- and a captured step replays without host code, so the gather
+        # is part of the step; inference: only when the weights changed since the last gather)
+        if training or self._wm_ver != self.e._tver[0]:
+            self.refresh_wm()
         for o in self.ops:
             o.fwd(training)
 
     def bwd(self, g):
         for o in self.ops:
-            o.out.g = None
+            o.out.g = getattr(o, "g_view", None)      # members of a sibling group: their block of the group's gradient
         self.t_in.g = None
         self.t_out.g = g
         for o in reversed(self.ops):
@@ -1727,7 +1824,7 @@ class IRv2Backbone(Node):
                 K, C, M, nb = g["K"], g["C"], g["M"], len(ms)
                 prof = e.prof
                 t0 = prof.start() if prof is not None else None
-                L.spnet_gemm_f32_batched_splitk(a0, b0, c0, g["table"].data_ptr(), nb, OUT_MAJOR, K, OUT_MAJOR, C, C, K, C, M,
+                L.spnet_gemm_f32_batched_splitk(a0, b0, c0, g["table"].data_ptr(), nb, OUT_MAJOR, K, OUT_MAJOR, g["ldb"], C, K, C, M,
                                                 g["tile"], g["ksl"], L.ptr(self.wg_ws),
                                                 self.wg_ws.numel() if self.wg_ws is not None else 0, _stream())
                 if prof is not None:
@@ -1751,10 +1848,109 @@ def _ir_acc(t, gbuf, eng):
         L.spnet_copy_cols(L.ptr(gbuf), C, L.ptr(t.g), C, gbuf.numel() // C, C, 1, _stream())
 
 
+class _IRGroup:
+    """The 1x1 / stride-1 conv2d_bn layers that read ONE tensor (the first layer of every branch of an inception block) as
+    one GEMM over their kernels side by side [cin][Ct] and one BatchNormalization over the Ct concatenated channels.
+    The members' beta / moving statistics sit back to back in the flat parameter buffers (param_packs), so the merged
+    arrays are plain slices; their kernels are gathered into Wm by IRv2Backbone.refresh_wm (one launch for the whole
+    network).  Members keep their identity: output / pre-normalisation tensor / gradient are column blocks of the
+    group's tensors, their consumers write the masked gradient and the BatchNorm sums into those blocks
+    (spnet_*_bnsums_ld), and their weight gradients run with the rest of their shape in the batched launches."""
+
+    def __init__(self, eng, net, members):
+        self.e, self.members = eng, members
+        m0 = members[0]
+        self.src, self.cin, self.M = m0.src, m0.cin, m0.M
+        self.Ct = Ct = sum(m.cout for m in members)
+        B, OH, OW = m0.out.buf.shape[:3]
+        self.yp, self.y = eng.new(B, OH, OW, Ct), eng.new(B, OH, OW, Ct)
+        self.Wm = eng.new(self.cin, Ct)
+        off, n, _ = eng.p_off[m0.bname + "/beta"]
+        self.beta = eng.theta[off:off + Ct]
+        so, _, _ = eng.s_off[m0.bname + "/moving_mean"]
+        sv, _, _ = eng.s_off[m0.bname + "/moving_variance"]
+        self.mm, self.mv = eng.stats[so:so + Ct], eng.stats[sv:sv + Ct]
+        self.ones, self.gscr = net.const_ones(Ct)
+        self.ss = eng.new(2 * Ct)
+        tr = eng.train_capable
+        if tr:
+            self.gbeta = eng.grad[off:off + Ct]
+            self.save = eng.new(2 * Ct)
+            self.g = eng.new(B, OH, OW, Ct)
+            self.rows = int(L.spnet_grad_bnsums_rows(self.M, 512 if self.M * Ct <= (4 << 20) else 128))
+            self.sum_part = eng.new(self.rows * 2 * Ct)
+            self.dx = eng.new(*self.src.buf.shape)
+        c0 = 0
+        for m in members:
+            if not m.relu or m.bias:
+                raise RuntimeError("sibling groups are conv2d_bn layers with a ReLU")
+            po = eng.p_off[m.bname + "/beta"][0]
+            if po != off + c0 or eng.s_off[m.bname + "/moving_mean"][0] != so + c0:
+                raise RuntimeError("parameters of %s are not packed behind its siblings'" % m.bname)
+            m.group, m.c0, m.ldy = self, c0, Ct
+            m.out.buf = self.y[..., c0:c0 + m.cout]
+            m.yp = self.yp[..., c0:c0 + m.cout]
+            if tr:
+                m.g_view = self.g[..., c0:c0 + m.cout]
+            c0 += m.cout
+
+    def fwd(self, training):
+        e, Ct, x = self.e, self.Ct, self.src.buf
+        act = ACT_RELU
+        if training and e.bn_fold:
+            rows = _gemm_colstats(x, self.cin, self.Wm, Ct, self.yp, Ct, self.M, Ct, self.cin, e)
+            L.spnet_bn_finalize_apply_ld(e.ws_ptr(WS_BNP), rows, L.ptr(self.yp), self.M, Ct, L.ptr(self.ones), L.ptr(self.beta),
+                                         L.ptr(self.mm), L.ptr(self.mv), L.ptr(self.save), self.save[Ct:].data_ptr(),
+                                         L.ptr(self.ss), act, None, L.ptr(self.y), Ct, BN_EPS, BN_MOMENTUM, _stream())
+            return
+        _gemm(x, K_MAJOR, self.cin, self.Wm, OUT_MAJOR, Ct, self.yp, Ct, self.M, Ct, self.cin, e)
+        if training:
+            L.spnet_bn_fwd_train_ld(L.ptr(self.yp), self.M, Ct, L.ptr(self.ones), L.ptr(self.beta), L.ptr(self.mm),
+                                    L.ptr(self.mv), L.ptr(self.save), self.save[Ct:].data_ptr(), L.ptr(self.ss), act, None, 0,
+                                    L.ptr(self.y), Ct, BN_EPS, BN_MOMENTUM, e.ws_ptr(WS_MISC), _stream())
+        else:
+            L.spnet_bn_fwd_infer_ld(L.ptr(self.yp), self.M, Ct, L.ptr(self.ones), L.ptr(self.beta), L.ptr(self.mm),
+                                    L.ptr(self.mv), L.ptr(self.ss), act, None, 0, L.ptr(self.y), Ct, BN_EPS, _stream())
+
+    def bwd(self, net):
+        """Runs where the group's FIRST member stands in the program, i.e. last of the block in backward order: every
+        member's consumer has left its masked gradient block in self.g and its two sums in self.sum_part by then."""
+        e, Ct, g = self.e, self.Ct, self.g
+        L.spnet_bn_bwd_from_partials(L.ptr(self.yp), L.ptr(g), self.M, Ct, L.ptr(self.ones), L.ptr(self.beta),
+                                     L.ptr(self.save), self.save[Ct:].data_ptr(), self.rows, L.ptr(self.sum_part), L.ptr(g),
+                                     L.ptr(self.gscr), L.ptr(self.gbeta), L.ptr(e.small[:3 * Ct]), _stream())
+        side = e.wgrad_stream
+        late = [m for m in self.members if not m.deferred_wgrad]      # (shapes that occur once: no batched launch)
+        if late:
+            def wgrads(region):
+                for m in late:
+                    _gemm(self.src.buf, OUT_MAJOR, self.cin, m.g_view, OUT_MAJOR, Ct, m.gw, m.cout, self.cin, m.cout,
+                          self.M, e, region=region)
+            if side is None:
+                wgrads(WS_GEMM)
+            else:
+                side.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(side):
+                    wgrads(WS_GEMM2)
+        src = self.src
+        if src.g is not None and e.ir_acc_epilogue:
+            prof = e.prof
+            t0 = prof.start() if prof is not None else None
+            L.spnet_gemm_f32_accumulate(L.ptr(g), K_MAJOR, Ct, L.ptr(self.Wm), K_MAJOR, Ct, L.ptr(src.g), self.cin, self.M,
+                                        self.cin, Ct, _tile_for(K_MAJOR, K_MAJOR, 0, self.M, self.cin, Ct, 0), _stream())
+            if prof is not None:
+                prof.stop("gemm", t0, 2.0 * self.M * self.cin * Ct, ("aA+=", self.M, self.cin, Ct))
+        else:
+            _gemm(g, K_MAJOR, Ct, self.Wm, K_MAJOR, Ct, self.dx, self.cin, self.M, self.cin, Ct, e)
+            _ir_acc(src, self.dx, e)
+
+
 class _IRConv:
     def __init__(self, eng, net, src, cname, bname, cin, cout, kk, stride, same, relu, bias):
         self.e, self.src, self.cin, self.cout = eng, src, cin, cout
         self.kh, self.kw, self.stride, self.same, self.relu, self.bias = kk[0], kk[1], stride, int(same), relu, bias
+        self.cname, self.bname = cname, bname
+        self.group, self.c0, self.g_view = None, 0, None      # set by _IRGroup: member of a sibling group
         B, H, W, _ = src.buf.shape
         self.H, self.W = H, W
         if same:
@@ -1776,7 +1972,7 @@ class _IRConv:
                          os.environ.get("SPNET_IR_IMPLICIT_FWD", "0") == "1")
         self.w = eng.P(cname + "/kernel")
         # (an inference plan whose convolution runs as an implicit GEMM never needs the patch matrix)
-        no_col = self.direct or self.small or (self.implicit and not eng.train_capable)
+        no_col = self.direct or self.small or (self.implicit and not eng.train_capable and src.buf.is_contiguous())
         self.col = None if no_col else eng.new(self.M, self.K)
         self.col_floats = 0 if (self.direct or self.small) else self.M * self.K
         self.out = _T(eng.new(B, OH, OW, cout))
@@ -1803,20 +1999,40 @@ class _IRConv:
     def srcs(self):
         return [self.src]
 
+    def has_sums(self):
+        """My BatchNorm-backward sums (and the ReLU mask on my gradient) are produced by my one consumer."""
+        return bool(self.sum_rows) or (self.group is not None and self.e.train_capable)
+
+    def sum_views(self):
+        """Where my consumer finds my pre-normalisation tensor / saved statistics and leaves the masked gradient and the
+        partial sums: (yp, ldyp, mean, invstd, partial, ldp, rows, gradient destination or None, its row stride)."""
+        G = self.group
+        if G is None:
+            C = self.cout
+            return (L.ptr(self.yp), C, L.ptr(self.save), self.save[C:].data_ptr(), L.ptr(self.sum_part), C, self.sum_rows,
+                    None, C)
+        c4 = 4 * self.c0
+        return (G.yp.data_ptr() + c4, G.Ct, G.save.data_ptr() + c4, G.save.data_ptr() + 4 * G.Ct + c4,
+                G.sum_part.data_ptr() + c4, G.Ct, G.rows, G.g.data_ptr() + c4, G.Ct)
+
     def gather_patches(self):
         """The patch matrix of my input, for the weight-gradient GEMM (implicit-forward convolutions skipped it in forward)."""
-        if self.implicit:
-            L.spnet_patches(L.ptr(self.src.buf), L.ptr(self.col), self.e.B, self.H, self.W, self.cin, self.kh, self.kw,
-                            self.stride, self.same, 0, _stream())
+        if self.implicit and self.src.buf.is_contiguous():
+            L.spnet_patches_ld(L.ptr(self.src.buf), self.src.buf.stride(2), L.ptr(self.col), self.e.B, self.H, self.W,
+                               self.cin, self.kh, self.kw, self.stride, self.same, _stream())
 
     def fwd(self, training):
+        if self.group is not None:             # one GEMM + one BatchNormalization for the whole sibling group
+            if self.group.members[0] is self:
+                self.group.fwd(training)
+            return
         e, C = self.e, self.cout
         y = self.out.buf
         dst = y if self.bias else self.yp
         if self.small:
             L.spnet_conv3x3_small(0, 3, C, self.stride, 0, L.ptr(self.src.buf), L.ptr(self.w), L.ptr(dst), e.B, self.H,
                                   self.W, e.ws_ptr(WS_MISC), WS_MISC[1], _stream())
-        elif self.implicit:
+        elif self.implicit and self.src.buf.is_contiguous():
             stats = training and not self.bias and e.bn_fold
             prof = e.prof
             t0 = prof.start() if prof is not None else None
@@ -1833,9 +2049,9 @@ class _IRConv:
                                              None, L.ptr(y), self.ldy, BN_EPS, BN_MOMENTUM, _stream())
                 return
         else:
-            if not self.direct:
-                L.spnet_patches(L.ptr(self.src.buf), L.ptr(self.col), e.B, self.H, self.W, self.cin, self.kh, self.kw,
-                                self.stride, self.same, 0, _stream())
+            if not self.direct:       # (the input may be one member's column block of a sibling group's output)
+                L.spnet_patches_ld(L.ptr(self.src.buf), self.src.buf.stride(2), L.ptr(self.col), e.B, self.H, self.W,
+                                   self.cin, self.kh, self.kw, self.stride, self.same, _stream())
             if training and not self.bias and e.bn_fold:
                 # BatchNorm statistics out of the GEMM accumulators, finalize + normalise + ReLU in one more launch
                 # (two when the GEMM leaves more than 128 partial rows): no reduction pass over yp
@@ -1859,6 +2075,10 @@ class _IRConv:
                                     L.ptr(self.mv), L.ptr(self.ss), act, None, 0, L.ptr(y), self.ldy, BN_EPS, _stream())
 
     def bwd(self, net):
+        if self.group is not None:
+            if self.group.members[0] is self:
+                self.group.bwd(net)
+            return
         e, C, g = self.e, self.cout, self.out.g
         if self.bias:
             L.spnet_reduce_rows_ws(L.ptr(g), self.M, C, L.ptr(self.gb), e.ws_ptr(WS_MISC), WS_MISC[1], _stream())
@@ -1905,10 +2125,13 @@ class _IRConv:
         else:
             _gemm(g, K_MAJOR, C, self.w, K_MAJOR, C, net.dcol, self.K, self.M, self.K, C, e)
             p = self.src.owner
-            if p is not None and getattr(p, "sum_rows", 0):      # + ReLU mask and BatchNorm sums of the producing layer
-                L.spnet_patches_bwd_bnsums(L.ptr(net.dcol), L.ptr(self.dx), e.B, self.H, self.W, self.cin, self.kh, self.kw,
-                                           self.stride, self.same, L.ptr(self.src.buf), L.ptr(p.yp), L.ptr(p.save),
-                                           p.save[p.cout:].data_ptr(), int(p.relu), L.ptr(p.sum_part), p.sum_rows, _stream())
+            if isinstance(p, _IRConv) and p.has_sums():          # + ReLU mask and BatchNorm sums of the producing layer
+                yp, ldyp, mean, invstd, part, ldp, rows, gdst, ldg = p.sum_views()
+                L.spnet_patches_bwd_bnsums_ld(L.ptr(net.dcol), gdst if gdst else L.ptr(self.dx), ldg, e.B, self.H, self.W,
+                                              self.cin, self.kh, self.kw, self.stride, self.same, L.ptr(self.src.buf), p.ldy,
+                                              yp, ldyp, mean, invstd, int(p.relu), part, ldp, rows, _stream())
+                if gdst:
+                    return                       # written into the sibling group's gradient block: nothing to accumulate
             else:
                 L.spnet_patches(L.ptr(net.dcol), L.ptr(self.dx), e.B, self.H, self.W, self.cin, self.kh, self.kw,
                                 self.stride, self.same, 1, _stream())
@@ -1964,18 +2187,23 @@ class _IRConcat:
     def fwd(self, training):
         ct, off = sum(self.cs), 0
         for t, c, direct in zip(self.srcs_, self.cs, self.direct):
-            if not direct:
-                L.spnet_copy_cols(L.ptr(t.buf), c, self.out.buf.data_ptr() + 4 * off, ct, self.rows, c, 0, _stream())
+            if not direct:            # (t may be a column block itself: a member of a sibling group)
+                L.spnet_copy_cols(L.ptr(t.buf), t.buf.stride(2), self.out.buf.data_ptr() + 4 * off, ct, self.rows, c, 0,
+                                  _stream())
             off += c
 
     def bwd(self, net):
         ct, off, g = sum(self.cs), 0, self.out.g
         for t, c, d in zip(self.srcs_, self.cs, self.dparts):
             p = t.owner
-            if p is not None and getattr(p, "sum_rows", 0):      # + ReLU mask and BatchNorm sums of the branch's last layer
-                L.spnet_copy_cols_bnsums(g.data_ptr() + 4 * off, ct, L.ptr(d), self.rows, c, L.ptr(t.buf), p.ldy,
-                                         L.ptr(p.yp), L.ptr(p.save), p.save[c:].data_ptr(), int(p.relu), L.ptr(p.sum_part),
-                                         p.sum_rows, _stream())
+            if isinstance(p, _IRConv) and p.has_sums():          # + ReLU mask and BatchNorm sums of the branch's last layer
+                yp, ldyp, mean, invstd, part, ldp, rows, gdst, ldg = p.sum_views()
+                L.spnet_copy_cols_bnsums_ld(g.data_ptr() + 4 * off, ct, gdst if gdst else L.ptr(d), ldg, self.rows, c,
+                                            L.ptr(t.buf), p.ldy, yp, ldyp, mean, invstd, int(p.relu), part, ldp, rows,
+                                            _stream())
+                if gdst:                         # written into the sibling group's gradient block
+                    off += c
+                    continue
             else:
                 L.spnet_copy_cols(g.data_ptr() + 4 * off, ct, L.ptr(d), c, self.rows, c, 0, _stream())
             _ir_acc(t, d, self.e)

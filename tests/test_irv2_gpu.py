@@ -130,6 +130,35 @@ def test_general_convolution_through_patches_and_gemm(B, H, W, C, kh, kw, stride
     np.testing.assert_allclose(sums[1], (g64 * xh).sum(0).numpy(), rtol=1e-4, atol=3e-4 * np.sqrt(B * H * W) * 4)
 
 
+def test_strided_patch_gather_and_batched_column_copies():
+    """spnet_patches_ld on a column block of a wider tensor == spnet_patches on the dense copy; spnet_copy_cols_batched ==
+    the copies one by one (the per-step gather of sibling kernels into their concatenated GEMM operand)."""
+    _need_gpu()
+    from spnet_amd import _lib as L
+    st = torch.cuda.current_stream().cuda_stream
+    rs = np.random.RandomState(4)
+    B, H, W, C, Ct = 2, 9, 7, 32, 96
+    wide = torch.tensor(rs.randn(B, H, W, Ct), dtype=torch.float32).cuda()
+    dense = wide[..., 32:64].contiguous()
+    for kh, kw, stride, same in ((3, 3, 1, 1), (1, 7, 1, 1), (3, 3, 2, 0)):
+        OH = (H + stride - 1) // stride if same else (H - kh) // stride + 1
+        OW = (W + stride - 1) // stride if same else (W - kw) // stride + 1
+        a = torch.full((B * OH * OW, kh * kw * C), float("nan"), device="cuda")
+        b = torch.full_like(a, float("nan"))
+        L.spnet_patches(dense.data_ptr(), a.data_ptr(), B, H, W, C, kh, kw, stride, same, 0, st)
+        L.spnet_patches_ld(wide.data_ptr() + 4 * 32, Ct, b.data_ptr(), B, H, W, C, kh, kw, stride, same, st)
+        assert torch.equal(a, b)
+    srcs = [torch.tensor(rs.randn(320, c), dtype=torch.float32).cuda() for c in (32, 48, 64)]
+    dst = torch.full((320, 144), float("nan"), device="cuda")
+    jobs, off = [], 0
+    for t in srcs:
+        jobs += [t.data_ptr(), dst.data_ptr() + 4 * off, 320, t.shape[1], t.shape[1], 144]
+        off += t.shape[1]
+    table = torch.tensor(jobs, dtype=torch.int64, device="cuda")
+    L.spnet_copy_cols_batched(table.data_ptr(), 3, 320 * 64, st)
+    assert torch.equal(dst, torch.cat(srcs, 1))
+
+
 def test_irv2_pools_and_block_glue():
     _need_gpu()
     from spnet_amd import _lib as L
