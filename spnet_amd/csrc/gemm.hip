@@ -536,8 +536,9 @@ static int launch_tile(const float* A, int amaj, int lda, const float* B, int bm
   return 0;
 }
 
-// Tile ids: 0 = auto, 1 = 128x128, 2 = 128x64, 3 = 64x64, 4 = 32x128, 5 = 96x96, 6 = 96x64, 7 = 64x128, 8 = 128x96
-#define SP_NTILES 8
+// Tile ids: 0 = auto, 1 = 128x128, 2 = 128x64, 3 = 64x64, 4 = 32x128, 5 = 96x96, 6 = 96x64, 7 = 64x128, 8 = 128x96,
+// 9 = 32x64 (few-row problems: M = 384 ... 4,096 rows of Inception-ResNet-v2 at batch 16, where 64-row tiles leave CUs empty)
+#define SP_NTILES 9
 static void tile_dims(int tile, int* bm, int* bn) {
   switch (tile) {
     case 1: *bm = 128; *bn = 128; break;
@@ -547,6 +548,7 @@ static void tile_dims(int tile, int* bm, int* bn) {
     case 6: *bm = 96; *bn = 64; break;
     case 7: *bm = 64; *bn = 128; break;
     case 8: *bm = 128; *bn = 96; break;
+    case 9: *bm = 32; *bn = 64; break;
     default: *bm = 32; *bn = 128; break;
   }
 }
@@ -583,6 +585,7 @@ static int pick_tile(int form, int M, int N, int K, int split_k, bool have_ws, l
                                    {0.80, 0.85, 0.95, 1.00, 0.90, 0.85, 0.80}};
   int best = 1;
   double best_cost = 1e300;
+  // (tile 9, 32x64, is never chosen here: it is selected per shape from measurements -- spnet_amd/gemm_tiles.json)
   for (int c = 0; c < 7; ++c) {
     int bm, bn;
     tile_dims(cand[c], &bm, &bn);
@@ -685,6 +688,7 @@ static int gemm_impl(const float* A, int a_major, int lda, const float* B, int b
     case 6: rc = launch_tile<96, 64, 2, 2>(A, a_major, lda, B, b_major, ldb, out, out_ld, M, N, K, nsplit, k_chunk, slab, kbias, colstats, batch, st, xf, X2, coef, cld, dy_out, kslices, accumulate); break;
     case 7: rc = launch_tile<64, 128, 2, 2>(A, a_major, lda, B, b_major, ldb, out, out_ld, M, N, K, nsplit, k_chunk, slab, kbias, colstats, batch, st, xf, X2, coef, cld, dy_out, kslices, accumulate); break;
     case 8: rc = launch_tile<128, 96, 2, 2>(A, a_major, lda, B, b_major, ldb, out, out_ld, M, N, K, nsplit, k_chunk, slab, kbias, colstats, batch, st, xf, X2, coef, cld, dy_out, kslices, accumulate); break;
+    case 9: rc = launch_tile<32, 64, 2, 2>(A, a_major, lda, B, b_major, ldb, out, out_ld, M, N, K, nsplit, k_chunk, slab, kbias, colstats, batch, st, xf, X2, coef, cld, dy_out, kslices, accumulate); break;
     default: rc = launch_tile<32, 128, 1, 4>(A, a_major, lda, B, b_major, ldb, out, out_ld, M, N, K, nsplit, k_chunk, slab, kbias, colstats, batch, st, xf, X2, coef, cld, dy_out, kslices, accumulate); break;
   }
   if (rc) return rc;

@@ -83,7 +83,7 @@ def test_gemm_dgrad_form(L, M, N, K, tile):
 
 
 @pytest.mark.parametrize("M,N,K", [(728, 728, 6144), (64, 128, 23250), (4096, 576, 32), (288, 64, 5000)])
-@pytest.mark.parametrize("tile", [0, 1, 2, 3, 5, 6, 7, 8])
+@pytest.mark.parametrize("tile", [0, 1, 2, 3, 5, 6, 7, 8, 9])
 def test_gemm_wgrad_form(L, M, N, K, tile):
     # dW[M=cin,N=cout] = X[K,M]^T @ dY[K,N]; K (pixels) need not be a multiple of 4
     rs = np.random.RandomState(2)
@@ -510,7 +510,7 @@ def test_dwconv_tiled_forward_with_the_producer_batchnorm_finalize_folded_in(L, 
 
 
 @pytest.mark.parametrize("M,N,K", [(6144, 728, 728), (372, 128, 64), (1536, 2048, 1536), (100, 64, 288), (33, 72, 40)])
-@pytest.mark.parametrize("tile", [0, 1, 2, 3, 5, 6, 7, 8])
+@pytest.mark.parametrize("tile", [0, 1, 2, 3, 5, 6, 7, 8, 9])
 def test_gemm_colstats_and_bn_finalize(L, M, N, K, tile):
     import ctypes
     rs = np.random.RandomState(M + N)

@@ -4,7 +4,7 @@ For every distinct plain GEMM launch (operand form, BatchNorm statistics or not,
 (engine.TILE_PROBE) for a few whole train steps and that shape's launches are timed with HIP events; a tile is recorded
 only where it beats the library's own choice by more than 3 % in BOTH of two alternating passes.
 MERGES into spnet_amd/gemm_tiles.json (keys carry the shape, so geometries do not collide).
-usage: autotune_gemm.py [steps per probe] [out.json] [H W B] [train|predict]
+usage: autotune_gemm.py [steps per probe] [out.json] [H W B] [train|predict] [backbone]
        (default 384 512 32 train = the benchmark step; 331 331 16 train = the reference's own layout;
         384 512 128 predict = BASELINE configs[4])"""
 import json, os, sys
@@ -17,7 +17,8 @@ from spnet_amd import engine as E
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 4
 H, W, B = (int(v) for v in sys.argv[3:6]) if len(sys.argv) > 5 else (384, 512, 32)
 MODE = sys.argv[6] if len(sys.argv) > 6 else "train"
-eng = E.Engine(H, W, B, device="cuda:0", seed=0, train=(MODE == "train"))
+BACKBONE = sys.argv[7] if len(sys.argv) > 7 else "Xception"
+eng = E.Engine(H, W, B, device="cuda:0", seed=0, train=(MODE == "train"), backbone=BACKBONE)
 X = torch.rand(B, H, W, 1, device="cuda") * 2 - 1
 Y = torch.rand(B, 576, device="cuda")
 
@@ -57,7 +58,7 @@ for key in keys:
     base = min(base1[key], base2[key])
     best = (base, 0)
     res = []
-    for tile in (1, 2, 3, 5, 6, 7, 8):
+    for tile in (1, 2, 3, 5, 6, 7, 8) + ((9,) if M <= 4096 and form != 2 else ()):
         if M <= 32:
             continue
         E.TILE_PROBE.clear()
@@ -91,4 +92,4 @@ with open(out, "w") as f:
     json.dump({"note": "tools/autotune_gemm.py on MI355X: tile ids measured inside the step of each geometry (384x512 batch 32 "
                        "train, 331x331 batch 16 train, 384x512 batch 128 predict); key = a_major,b_major,stats,M,N,K",
                "tiles": tiles}, f, indent=1, sort_keys=True)
-print("wrote %s: %d new shapes for %dx%d batch %d %s, %d in all" % (out, len(chosen), H, W, B, MODE, len(tiles)))
+print("wrote %s: %d new shapes for %s %dx%d batch %d %s, %d in all" % (out, len(chosen), BACKBONE, H, W, B, MODE, len(tiles)))
