@@ -319,3 +319,26 @@ def test_cpu_share_for_the_baseline():
     assert 1 <= n <= share["affinity_cpus"] and n <= 32
     if share["cgroup_quota_cpus"]:
         assert n <= int(share["cgroup_quota_cpus"] + 0.5)
+
+
+def test_irv2_sibling_groups_and_parameter_packs():
+    """The 1x1 convolutions that read one tensor (first layer of every branch of an inception block) form 42 groups --
+    10 x block35 (32+32+32), 20 x block17 (192+128), 10 x block8 (192+192), mixed_5b (96+48+64), mixed_7a (3 x 256) -- and
+    their beta / moving statistics are the names the parameter layout packs back to back (engine.param_packs)."""
+    from collections import Counter
+    from spnet_amd import engine as E
+    groups = E.irv2_sibling_groups()
+    assert len(groups) == 42
+    assert Counter(tuple(c for _, _, c in g) for g in groups) == {(32, 32, 32): 10, (192, 128): 20, (192, 192): 10,
+                                                                 (96, 48, 64): 1, (256, 256, 256): 1}
+    names = {s[0]: s for s in E.param_specs(384, 512, backbone="InceptionResNetV2")}
+    packs = E.param_packs("InceptionResNetV2")
+    assert len(packs) == 3 * 42 and E.param_packs("Xception") == []
+    seen = set()
+    for p in packs:
+        assert len(p) >= 2
+        for n in p:
+            assert n in names and n not in seen and int(np.prod(names[n][1])) % 4 == 0
+            seen.add(n)
+        kinds = {n.split("/")[1] for n in p}
+        assert len(kinds) == 1 and kinds <= {"beta", "moving_mean", "moving_variance"}
