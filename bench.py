@@ -26,6 +26,7 @@ if ROOT not in sys.path:
 
 H, W, BATCH = 384, 512, 32
 FP32_MFMA_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+BF16_MFMA_PEAK_TFLOPS = 2500.0     # MI355X_MICROARCH.md: dense bf16 MFMA (the figure without 2:1 sparsity)
 HBM_PEAK_GBS = 8000.0              # MI355X_MICROARCH.md: HBM3E spec
 DW_TRAIN_BYTES_PER_IMAGE = 157.6e6  # depthwise stack, fwd + bwd, 384x512
 DW_FWD_BYTES_PER_IMAGE = 63.1e6
@@ -363,6 +364,57 @@ def layout_331_measure(dev, steps=20, warmup=3):
     return out
 
 
+def bf16x3_alt_measure(dev, iters=200):
+    """`roofline_alt` (optional part): the bf16x3 operand-split probe (csrc/gemm_bf16x3.hip: six bf16
+    MFMAs with fp32 accumulation per product block) beside the exact fp32 MFMA kernel on the network's dominant forward
+    shape, the Xception middle-flow pointwise GEMM at batch 32 (6144 x 728 x 728).  Never part of `value`: the product
+    path stays the k-ordered fp32 chain.  Error of both kernels against float64 (torch.float64 on the device), relative
+    to |a_row| * |w_col|."""
+    from spnet_amd import _lib as L
+    M, N, K = 6144, 728, 728
+    g = torch.Generator(device=dev)
+    g.manual_seed(3)
+    a = torch.randn(M, K, device=dev, generator=g)
+    w = torch.randn(K, N, device=dev, generator=g) * 0.05
+    Kp = int(L.spnet_bf16x3_kp(K))
+    planes = torch.zeros(3 * N * Kp, dtype=torch.int16, device=dev)
+    c3, c1 = torch.empty(M, N, device=dev), torch.empty(M, N, device=dev)
+    st = torch.cuda.current_stream().cuda_stream
+    split = lambda: L.spnet_split_bf16x3(w.data_ptr(), planes.data_ptr(), K, N, st)
+    f3 = lambda: L.spnet_gemm_bf16x3_fwd(a.data_ptr(), K, planes.data_ptr(), c3.data_ptr(), N, M, N, K, st)
+    f1 = lambda: L.spnet_gemm_f32(a.data_ptr(), 0, K, w.data_ptr(), 1, N, c1.data_ptr(), N, M, N, K, 1, None, 0, None, 0, st)
+
+    def t(fn):
+        for _ in range(10):
+            fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(iters):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) * 1e3 / iters
+
+    split()
+    t3, t1, ts = t(f3), t(f1), t(split)
+    ref = a.double() @ w.double()
+    scale = a.double().norm(dim=1)[:, None] * w.double().norm(dim=0)[None, :]
+    e3, e1 = (c3.double() - ref).abs() / scale, (c1.double() - ref).abs() / scale
+    fl = 2.0 * M * N * K
+    peak = BF16_MFMA_PEAK_TFLOPS / 6.0
+    return {"kernel": "gemm_bf16x3_fwd_kernel (probe, not on the product path): fp32 operands as 3 bf16 pieces, 6 bf16 MFMAs "
+                      "per product block, fp32 accumulate", "shape": {"M": M, "N": N, "K": K}, "bound": "mfma",
+            "achieved": round(fl / t3 / 1e6, 1), "peak": round(peak, 1), "unit": "TFLOP/s (fp32-equivalent)",
+            "frac": round(fl / t3 / 1e6 / peak, 4),
+            "peak_note": "dense bf16 MFMA peak %.0f TFLOP/s / 6 MFMAs per product block" % BF16_MFMA_PEAK_TFLOPS,
+            "avg_launch_us": round(t3, 1), "exact_fp32_kernel_us": round(t1, 1), "speedup_vs_exact": round(t1 / t3, 3),
+            "weight_split_us": round(ts, 1),
+            "max_rel_err_vs_f64": float("%.3g" % e3.max().item()), "rms_rel_err_vs_f64": float("%.3g" % e3.pow(2).mean().sqrt().item()),
+            "exact_max_rel_err_vs_f64": float("%.3g" % e1.max().item()),
+            "exact_rms_rel_err_vs_f64": float("%.3g" % e1.pow(2).mean().sqrt().item()),
+            "iters": iters}
+
+
 def rccl_version():
     try:
         import torch
@@ -687,6 +739,7 @@ def main():
             torch.cuda.empty_cache()
             result["predict"] = predict_measure(X_pool[:min(args.pool, 2048) // 128 * 128], dev, 10, 2)
             result["layout_331"] = layout_331_measure(dev)
+            result["roofline_alt"] = bf16x3_alt_measure(dev)
             eng = aug = None
         if world == 1 and not args.no_cpu_baseline:
             del eng, aug, X_pool

@@ -37,6 +37,16 @@ int spnet_gemm_f32(const float* A, int a_major, int lda, const float* B, int b_m
  * has already left in C (the branch convolutions of an inception block; call site spnet/models.py:357-359). */
 int spnet_gemm_f32_accumulate(const float* A, int a_major, int lda, const float* B, int b_major, int ldb, float* C,
                               int ldc, int M, int N, int K, int tile, void* stream);
+
+/* ---- probe, not on the product path: fp32 GEMM on the bf16 matrix cores by operand splitting ------------------------- */
+/* x = h + m + l (three bf16, exact), a*b ~ six piece products (error ~ one fp32 rounding per product), six
+ * v_mfma_f32_16x16x32_bf16 in place of eight fp32 MFMAs per 16x16x32 block.  Forward operand form only: A [M][K] fp32
+ * (split while staged), W as the three K-major bf16 planes spnet_split_bf16x3 makes of a Keras pointwise kernel
+ * [K][N] (3 * N * spnet_bf16x3_kp(K) bf16), C [M][N] fp32.  NOT the k-ordered fmaf chain of spnet_gemm_f32: bench.py
+ * reports it as `roofline_alt` only (pointwise convolutions of the Xception middle flow; call site spnet/models.py:357-359). */
+long spnet_bf16x3_kp(int K);
+int spnet_split_bf16x3(const float* W, void* planes, int K, int N, void* stream);
+int spnet_gemm_bf16x3_fwd(const float* A, int lda, const void* planes, float* C, int ldc, int M, int N, int K, void* stream);
 /* Same contraction (no split-K, no bias) that also emits BatchNorm column statistics of C from the
  * accumulators: colstats[rows][2][N] per row-tile (sum, sum of squares), *stat_rows (HOST int) = rows.
  * colstats must hold ceil(M/32)*2*N floats. */

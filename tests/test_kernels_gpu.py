@@ -146,6 +146,34 @@ def test_gemm_accumulate_into_c(L, M, N, K, form, tile):
     assert torch.equal(C, want)
 
 
+@pytest.mark.parametrize("M,N,K", [(6144, 728, 728), (200, 96, 32), (97, 100, 260), (1536, 1024, 1536)])
+def test_gemm_bf16x3_probe_accuracy(L, M, N, K):
+    """The bf16x3 probe (fp32 operands as three bf16 pieces, six bf16 MFMAs, fp32 accumulation; NOT on the product path):
+    its error against float64 is of the size of the exact fp32 kernel's own -- within 3x of it, and below 2e-6 of the
+    row / column norms product -- on random operands with a wide dynamic range; the weight planes reproduce W exactly."""
+    rs = np.random.RandomState(M + N)
+    A = (rs.randn(M, K) * np.exp(rs.randn(M, K))).astype(np.float32)
+    W = (rs.randn(K, N) * 0.1 * np.exp(rs.randn(K, N))).astype(np.float32)
+    a, w = dev(A), dev(W)
+    Kp = int(L.spnet_bf16x3_kp(K))
+    planes = torch.zeros(3 * N * Kp, dtype=torch.int16, device="cuda")
+    L.spnet_split_bf16x3(w.data_ptr(), planes.data_ptr(), K, N, st())
+    pl = planes.view(torch.bfloat16).reshape(3, N, Kp).float().cpu().double()
+    assert torch.equal((pl[0] + pl[1] + pl[2])[:, :K].T.contiguous(), torch.from_numpy(W).double())     # h + m + l == w exactly
+    assert float(pl[:, :, K:].abs().max()) == 0.0 if Kp > K else True
+    c3 = torch.full((M, N), float("nan"), device="cuda")
+    L.spnet_gemm_bf16x3_fwd(a.data_ptr(), K, planes.data_ptr(), c3.data_ptr(), N, M, N, K, st())
+    c1 = torch.empty(M, N, device="cuda")
+    L.spnet_gemm_f32(a.data_ptr(), 0, K, w.data_ptr(), 1, N, c1.data_ptr(), N, M, N, K, 1, None, 0, None, 0, st())
+    ref = A.astype(np.float64) @ W.astype(np.float64)
+    scale = np.sqrt((A.astype(np.float64) ** 2).sum(1))[:, None] * np.sqrt((W.astype(np.float64) ** 2).sum(0))[None, :]
+    e3 = np.abs(c3.cpu().double().numpy() - ref) / scale
+    e1 = np.abs(c1.cpu().double().numpy() - ref) / scale
+    assert np.isfinite(e3).all()
+    assert e3.max() < 2e-6 and e3.max() < 3.0 * max(e1.max(), 1e-8), (e3.max(), e1.max())
+    assert np.sqrt((e3 ** 2).mean()) < 3.0 * max(np.sqrt((e1 ** 2).mean()), 1e-9)
+
+
 @pytest.mark.parametrize("tile", [0, 3, 5, 6])
 def test_gemm_batched_wgrad_form(L, tile):
     """Several weight-gradient problems of one shape in one launch == the same problems one by one."""
