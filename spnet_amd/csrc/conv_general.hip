@@ -72,8 +72,12 @@ __global__ __launch_bounds__(256) void col2im_kernel(const float* __restrict__ d
 // activation left to handle.  blockDim = (8 channel quads, 32 rows); one partial row [2][C] per grid row, fixed order.
 //   MODE 0: g = col2im(dcol)      MODE 1: g = src[r * lds + c] (strided column block)
 // ------------------------------------------------------------------------------------------------
+// KHT x KWT > 0 (MODE 0, stride 1 only): the taps unrolled and branch-free -- an out-of-range tap loads a clamped address
+// and contributes +0 -- so that a thread's KHT*KWT loads are all in flight together; with run-time loops and `continue`
+// every tap waits for the one before it, and these launches (a few waves per CU) are pure load latency: 9,744 pixels x
+// 32 channels x 9 taps took 33 us.  The sum keeps the tap order (a skipped tap and an added zero are the same value).
 #define GS_CL 8
-template <int MODE>
+template <int MODE, int KHT = 0, int KWT = 0>
 __global__ __launch_bounds__(256) void grad_bnsums_kernel(const float* __restrict__ src, int lds, float* __restrict__ dx,
                                                           long lddx, int Bn, int H, int W, int C, int KH, int KW, int s,
                                                           int pt, int pl, int OH, int OW, const float* __restrict__ y,
@@ -95,6 +99,33 @@ __global__ __launch_bounds__(256) void grad_bnsums_kernel(const float* __restric
       float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
       if (MODE == 1) {
         g = *reinterpret_cast<const float4*>(src + r * lds + c4 * 4);
+      } else if constexpr (KHT > 0) {
+        const int w = (int)(r % W);
+        const int t = (int)(r / W);
+        const int h = t % H, b = t / H;
+        float4 v[KHT * KWT > 0 ? KHT * KWT : 1];
+#pragma unroll
+        for (int kh = 0; kh < KHT; ++kh) {
+          const int oh = h + pt - kh;
+          const int ohc = min(max(oh, 0), OH - 1);
+#pragma unroll
+          for (int kw = 0; kw < KWT; ++kw) {
+            const int ow = w + pl - kw;
+            const int owc = min(max(ow, 0), OW - 1);
+            v[kh * KWT + kw] = *reinterpret_cast<const float4*>(src + (((long)b * OH + ohc) * OW + owc) * K +
+                                                                (kh * KWT + kw) * C + c4 * 4);
+          }
+        }
+#pragma unroll
+        for (int kh = 0; kh < KHT; ++kh) {
+          const bool vh = (unsigned)(h + pt - kh) < (unsigned)OH;
+#pragma unroll
+          for (int kw = 0; kw < KWT; ++kw) {
+            const bool ok = vh && (unsigned)(w + pl - kw) < (unsigned)OW;
+            const float4 u = v[kh * KWT + kw];
+            g.x += ok ? u.x : 0.f; g.y += ok ? u.y : 0.f; g.z += ok ? u.z : 0.f; g.w += ok ? u.w : 0.f;
+          }
+        }
       } else {
         const int w = (int)(r % W);
         long t = r / W;
@@ -201,8 +232,16 @@ extern "C" int spnet_patches_bwd_bnsums_ld(const float* dcol, float* dx, long ld
   conv_geom(W, KW, stride, same, &OW, &pl);
   if (OH < 1 || OW < 1 || rows < 1 || rows > spnet_grad_bnsums_rows((long)B * H * W, rows)) return (int)hipErrorInvalidValue;
   dim3 grid((C / 4 + GS_CL - 1) / GS_CL, (unsigned)rows), block(GS_CL, 32);
-  hipLaunchKernelGGL(grad_bnsums_kernel<0>, grid, block, 0, (hipStream_t)stream, dcol, 0, dx, lddx, B, H, W, C, KH, KW,
-                     stride, pt, pl, OH, OW, y, ldy, yp, ldyp, mean, invstd, relu ? 1 : 0, partial, ldp);
+#define GS_ARGS dcol, 0, dx, lddx, B, H, W, C, KH, KW, stride, pt, pl, OH, OW, y, ldy, yp, ldyp, mean, invstd, relu ? 1 : 0, partial, ldp
+#define GS_CASE(KH_, KW_)                                                                                          \
+  if (stride == 1 && KH == KH_ && KW == KW_) {                                                                     \
+    hipLaunchKernelGGL((grad_bnsums_kernel<0, KH_, KW_>), grid, block, 0, (hipStream_t)stream, GS_ARGS);           \
+    SPNET_RETURN_LAUNCH_STATUS();                                                                                  \
+  }
+  GS_CASE(3, 3) GS_CASE(1, 7) GS_CASE(7, 1) GS_CASE(1, 3) GS_CASE(3, 1) GS_CASE(5, 5)
+  hipLaunchKernelGGL((grad_bnsums_kernel<0>), grid, block, 0, (hipStream_t)stream, GS_ARGS);
+#undef GS_CASE
+#undef GS_ARGS
   SPNET_RETURN_LAUNCH_STATUS();
 }
 extern "C" int spnet_patches_bwd_bnsums(const float* dcol, float* dx, int B, int H, int W, int C, int KH, int KW, int stride,
@@ -221,7 +260,7 @@ extern "C" int spnet_copy_cols_bnsums_ld(const float* src, int lds, float* dst, 
   if (ldd < C || ldy < C || ldyp < C || ldp < C || ((ldd | ldy | ldyp | ldp) & 3)) return (int)hipErrorInvalidValue;
   if (rows < 1 || rows > spnet_grad_bnsums_rows(M, rows)) return (int)hipErrorInvalidValue;
   dim3 grid((C / 4 + GS_CL - 1) / GS_CL, (unsigned)rows), block(GS_CL, 32);
-  hipLaunchKernelGGL(grad_bnsums_kernel<1>, grid, block, 0, (hipStream_t)stream, src, lds, dst, ldd, 1, 1, (int)M, C, 1, 1, 1,
+  hipLaunchKernelGGL((grad_bnsums_kernel<1>), grid, block, 0, (hipStream_t)stream, src, lds, dst, ldd, 1, 1, (int)M, C, 1, 1, 1,
                      0, 0, 1, (int)M, y, ldy, yp, ldyp, mean, invstd, relu ? 1 : 0, partial, ldp);
   SPNET_RETURN_LAUNCH_STATUS();
 }
