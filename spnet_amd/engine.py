@@ -2080,8 +2080,13 @@ class _IRConv:
                 self.group.bwd(net)
             return
         e, C, g = self.e, self.cout, self.out.g
-        if self.bias:
-            L.spnet_reduce_rows_ws(L.ptr(g), self.M, C, L.ptr(self.gb), e.ws_ptr(WS_MISC), WS_MISC[1], _stream())
+        if self.bias:       # a weight gradient like the kernel's: off the data-gradient chain (two launches per block)
+            if e.wgrad_stream is None:
+                L.spnet_reduce_rows_ws(L.ptr(g), self.M, C, L.ptr(self.gb), e.ws_ptr(WS_MISC), WS_MISC[1], _stream())
+            else:
+                e.wgrad_stream.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(e.wgrad_stream):
+                    L.spnet_reduce_rows_ws(L.ptr(g), self.M, C, L.ptr(self.gb), e.ws_ptr(WS_GEMM2), WS_GEMM2[1], _stream())
         elif self.sum_rows:     # my one consumer left the masked gradient in g and the two sums in sum_part
             L.spnet_bn_bwd_from_partials(L.ptr(self.yp), L.ptr(g), self.M, C, L.ptr(self.ones), L.ptr(self.beta),
                                          L.ptr(self.save), self.save[C:].data_ptr(), self.sum_rows, L.ptr(self.sum_part),
