@@ -1743,7 +1743,7 @@ class IRv2Backbone(Node):
         # (spnet_gemm_f32_batched_splitk) instead of a small split-K GEMM + slab reduce per layer: their operands --
         # the patch matrix / block input and the BatchNorm-backward output left in the gradient accumulator -- stay
         # untouched until the next step.  SPNET_IR_BATCH_WGRAD=0: per-layer launches.
-        self.wg_groups, self.wg_ws = [], None
+        self.wg_groups, self.wg_ws, self._wg_trigger = [], None, None
         if eng.train_capable and os.environ.get("SPNET_IR_BATCH_WGRAD", "1") != "0":
             by_shape = {}
             for o in self.ops:
@@ -1798,20 +1798,33 @@ class IRv2Backbone(Node):
             o.out.g = getattr(o, "g_view", None)      # members of a sibling group: their block of the group's gradient
         self.t_in.g = None
         self.t_out.g = g
-        for o in reversed(self.ops):
-            o.bwd(self)
-        self.flush_wgrads()
+        if self._wg_trigger is None:
+            # a shape's batched weight gradient is launched as soon as its LAST member (the earliest layer; for a member
+            # of a sibling group, the group's leader, whose bwd differentiates the whole group) has been back-propagated:
+            # all of them at the end of backward left the weight-gradient stream a 1.9 ms tail with nothing beside it
+            pos = {id(o): i for i, o in enumerate(self.ops)}
+            lead = lambda m: m if m.group is None else m.group.members[0]
+            self._wg_trigger = {}
+            eager = os.environ.get("SPNET_IR_EAGER_WGRAD", "1") != "0"
+            for g in self.wg_groups:
+                i = min(pos[id(lead(m))] for m in g["members"]) if eager else 0
+                self._wg_trigger.setdefault(i, []).append(g)
+        for i in range(len(self.ops) - 1, -1, -1):
+            self.ops[i].bwd(self)
+            if i in self._wg_trigger:
+                self.flush_wgrads(self._wg_trigger[i])
         return self.t_in.g
 
-    def flush_wgrads(self):
-        """The deferred weight gradients, one batched launch (+ one slab reduce) per shape, on the weight-gradient
-        stream.  The operand offset tables live in device memory and are rebuilt only if a buffer address changed."""
-        if not self.wg_groups:
+    def flush_wgrads(self, groups=None):
+        """Deferred weight gradients, one batched launch (+ one slab reduce) per shape, on the weight-gradient stream.
+        The operand offset tables live in device memory and are rebuilt only if a buffer address changed."""
+        groups = self.wg_groups if groups is None else groups
+        if not groups:
             return
         e = self.e
 
         def run():
-            for g in self.wg_groups:
+            for g in groups:
                 ms = g["members"]
                 for o in ms:
                     o.gather_patches()
