@@ -105,3 +105,29 @@ def test_bench_self_launched_two_ranks_on_one_gpu():
     assert out["config"]["collective_backend"] == "gloo" and out["scaling"] == "weak"
     assert out["value"] > 0 and np.isfinite(out["config"]["final_loss"])
     assert "cpu_baseline" not in out and "predict" not in out          # N = 1 only
+
+
+def test_bench_default_line_carries_every_block():
+    """The driver's N = 1 command with short step counts: one JSON line with the roofline of the dominant family, the
+    secondary family by sub-family, the predict / 331 x 331 legs, the bf16x3 probe as `roofline_alt` and the CPU baseline
+    (one short oracle step here) -- every leg of the default run executes, none is skipped by a flag."""
+    import json
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(PYTHONPATH=ROOT)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--pool", "256",
+                        "--sustained-seconds", "0", "--cpu-baseline-steps", "1", "--cpu-baseline-batch", "2"],
+                       env=env, capture_output=True, text=True, timeout=1200)
+    assert r.returncode == 0, r.stdout[-2000:] + "\n" + r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    for key in ("roofline", "roofline_secondary", "roofline_alt", "cpu_baseline", "predict", "layout_331", "kernel_families"):
+        assert key in out, key
+    assert out["n_gpus"] == 1 and out["dtype"] == "f32" and out["value"] > 0
+    assert set(out["roofline_secondary"].get("sub_families", out["roofline"].get("sub_families", {}))) >= {"entry", "middle", "exit"}
+    alt = out["roofline_alt"]
+    assert alt["max_rel_err_vs_f64"] < 5e-7 and alt["avg_launch_us"] > 0 and 0 < alt["frac"] < 1
+    assert out["cpu_baseline"]["kind"] in ("port", "reference") and out["cpu_baseline"]["value"] > 0
