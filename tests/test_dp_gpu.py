@@ -95,7 +95,7 @@ def test_bench_self_launched_two_ranks_on_one_gpu():
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
     env.update(PYTHONPATH=ROOT, SPNET_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
-                        "--pool", "128", "--sustained-seconds", "0", "--no-kernel-timers"],
+                        "--pool", "128", "--sustained-seconds", "0"],
                        env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + "\n" + r.stderr[-3000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
@@ -105,6 +105,7 @@ def test_bench_self_launched_two_ranks_on_one_gpu():
     assert out["config"]["collective_backend"] == "gloo" and out["scaling"] == "weak"
     assert out["value"] > 0 and np.isfinite(out["config"]["final_loss"])
     assert "cpu_baseline" not in out and "predict" not in out          # N = 1 only
+    assert 0 < out["roofline"]["frac"] < 1 and out["kernel_families"]["gemm"]["launches_per_step"] == 97
 
 
 def test_bench_default_line_carries_every_block():
