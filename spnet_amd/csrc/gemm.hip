@@ -537,8 +537,10 @@ static int launch_tile(const float* A, int amaj, int lda, const float* B, int bm
 }
 
 // Tile ids: 0 = auto, 1 = 128x128, 2 = 128x64, 3 = 64x64, 4 = 32x128, 5 = 96x96, 6 = 96x64, 7 = 64x128, 8 = 128x96,
-// 9 = 32x64 (few-row problems: M = 384 ... 4,096 rows of Inception-ResNet-v2 at batch 16, where 64-row tiles leave CUs empty)
-#define SP_NTILES 9
+// 9 = 32x64 (few-row problems: M = 384 ... 4,096 rows of Inception-ResNet-v2 at batch 16, where 64-row tiles leave CUs empty),
+// 10 = 32x32 (the same problems with few columns as well: twice the workgroups, half the MFMA chain per K tile).
+// 9 and 10 are never chosen by the cost model: spnet_amd/gemm_tiles.json names the shapes where they win in the step.
+#define SP_NTILES 10
 static void tile_dims(int tile, int* bm, int* bn) {
   switch (tile) {
     case 1: *bm = 128; *bn = 128; break;
@@ -549,6 +551,7 @@ static void tile_dims(int tile, int* bm, int* bn) {
     case 7: *bm = 64; *bn = 128; break;
     case 8: *bm = 128; *bn = 96; break;
     case 9: *bm = 32; *bn = 64; break;
+    case 10: *bm = 32; *bn = 32; break;
     default: *bm = 32; *bn = 128; break;
   }
 }
@@ -689,6 +692,7 @@ static int gemm_impl(const float* A, int a_major, int lda, const float* B, int b
     case 7: rc = launch_tile<64, 128, 2, 2>(A, a_major, lda, B, b_major, ldb, out, out_ld, M, N, K, nsplit, k_chunk, slab, kbias, colstats, batch, st, xf, X2, coef, cld, dy_out, kslices, accumulate); break;
     case 8: rc = launch_tile<128, 96, 2, 2>(A, a_major, lda, B, b_major, ldb, out, out_ld, M, N, K, nsplit, k_chunk, slab, kbias, colstats, batch, st, xf, X2, coef, cld, dy_out, kslices, accumulate); break;
     case 9: rc = launch_tile<32, 64, 2, 2>(A, a_major, lda, B, b_major, ldb, out, out_ld, M, N, K, nsplit, k_chunk, slab, kbias, colstats, batch, st, xf, X2, coef, cld, dy_out, kslices, accumulate); break;
+    case 10: rc = launch_tile<32, 32, 2, 2>(A, a_major, lda, B, b_major, ldb, out, out_ld, M, N, K, nsplit, k_chunk, slab, kbias, colstats, batch, st, xf, X2, coef, cld, dy_out, kslices, accumulate); break;
     default: rc = launch_tile<32, 128, 1, 4>(A, a_major, lda, B, b_major, ldb, out, out_ld, M, N, K, nsplit, k_chunk, slab, kbias, colstats, batch, st, xf, X2, coef, cld, dy_out, kslices, accumulate); break;
   }
   if (rc) return rc;

@@ -258,7 +258,7 @@ def test_gemm_tile_table_precedence_and_format():
     for k, t in tiles.items():
         parts = [int(v) for v in k.split(",")]
         assert len(parts) == 6 and parts[0] in (0, 1) and parts[1] in (0, 1) and parts[2] in (0, 1)
-        assert 1 <= int(t) <= 9          # 9 = 32x64 (few-row problems)
+        assert 1 <= int(t) <= 10         # 9 = 32x64, 10 = 32x32 (few-row problems)
         assert E.TILE_TABLE[tuple(parts)] == int(t)
     key = next(iter(E.TILE_TABLE)) if E.TILE_TABLE else (0, 1, 0, 7, 7, 7)
     assert E._tile_for(*key, 5) == 5                                    # explicit

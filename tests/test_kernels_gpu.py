@@ -36,7 +36,7 @@ WS = 8 * 1024 * 1024
 
 @pytest.mark.parametrize("M,N,K", [(128, 128, 64), (6144, 728, 728), (100, 728, 256), (37, 64, 288), (32, 576, 4096),
                                    (1000, 128, 64), (4, 12, 8)])
-@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4, 5, 6, 7, 8])
+@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10])
 def test_gemm_forward_form(L, M, N, K, tile):
     rs = np.random.RandomState(M + N + K)
     A, B = rs.randn(M, K).astype(np.float32), rs.randn(K, N).astype(np.float32)
@@ -69,7 +69,7 @@ def test_gemm_split_k_is_deterministic_and_correct(L, split):
 
 
 @pytest.mark.parametrize("M,N,K", [(6144, 728, 728), (200, 64, 128), (32, 4096, 576)])
-@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4, 5, 6, 7, 8])
+@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10])
 def test_gemm_dgrad_form(L, M, N, K, tile):
     # dX[M,N=cin] = dY[M,K=cout] @ W[N,K]^T, W read in place (K-major B)
     rs = np.random.RandomState(1)
@@ -83,7 +83,7 @@ def test_gemm_dgrad_form(L, M, N, K, tile):
 
 
 @pytest.mark.parametrize("M,N,K", [(728, 728, 6144), (64, 128, 23250), (4096, 576, 32), (288, 64, 5000)])
-@pytest.mark.parametrize("tile", [0, 1, 2, 3, 5, 6, 7, 8, 9])
+@pytest.mark.parametrize("tile", [0, 1, 2, 3, 5, 6, 7, 8, 9, 10])
 def test_gemm_wgrad_form(L, M, N, K, tile):
     # dW[M=cin,N=cout] = X[K,M]^T @ dY[K,N]; K (pixels) need not be a multiple of 4
     rs = np.random.RandomState(2)
@@ -538,7 +538,7 @@ def test_dwconv_tiled_forward_with_the_producer_batchnorm_finalize_folded_in(L, 
 
 
 @pytest.mark.parametrize("M,N,K", [(6144, 728, 728), (372, 128, 64), (1536, 2048, 1536), (100, 64, 288), (33, 72, 40)])
-@pytest.mark.parametrize("tile", [0, 1, 2, 3, 5, 6, 7, 8, 9])
+@pytest.mark.parametrize("tile", [0, 1, 2, 3, 5, 6, 7, 8, 9, 10])
 def test_gemm_colstats_and_bn_finalize(L, M, N, K, tile):
     import ctypes
     rs = np.random.RandomState(M + N)
@@ -889,7 +889,7 @@ def test_transpose_batched(L):
 
 
 @pytest.mark.parametrize("M,N,K", [(6144, 728, 728), (1000, 136, 200), (96, 64, 32), (37, 64, 288), (23250, 128, 128)])
-@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4, 5, 6, 7, 8])
+@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10])
 def test_gemm_with_batchnorm_backward_blended_into_the_a_operand(L, M, N, K, tile):
     """dX = BN'(g, yp) @ W^T without a BatchNorm-backward pass: spnet_bn_bwd_coeffs* + spnet_gemm_f32_bnblend against
     autograd through BatchNorm (fp64) followed by the product; dy_out must hold exactly the blended operand."""

@@ -58,7 +58,7 @@ for key in keys:
     base = min(base1[key], base2[key])
     best = (base, 0)
     res = []
-    for tile in (1, 2, 3, 5, 6, 7, 8) + ((9,) if M <= 16384 and form != 2 else ()):
+    for tile in (1, 2, 3, 5, 6, 7, 8) + ((9, 10) if M <= 16384 and form != 2 else ()):
         if M <= 32:
             continue
         E.TILE_PROBE.clear()
