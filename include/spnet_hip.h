@@ -29,7 +29,9 @@ extern "C" {
  *                    1 = output index contiguous    (A[k*lda+m], B[k*ldb+n]).
  * Supported pairs: (0,1) forward, (0,0) dgrad, (1,1) wgrad.
  * split_k: 0 = choose automatically, >1 = that many K slices summed deterministically through
- * `workspace` (>= split_k*M*N floats).  tile: 0 auto, 1 128x128, 2 128x64, 3 64x64, 4 32x128, 5 96x96. */
+ * `workspace` (>= split_k*M*N floats).  tile (BM x BN): 0 auto (cost model over ids 1-8), 1 128x128, 2 128x64, 3 64x64,
+ * 4 32x128, 5 96x96, 6 96x64, 7 64x128, 8 128x96, 9 32x64, 10 32x32 (9 and 10: few-row problems, chosen only through
+ * spnet_amd/gemm_tiles.json, where tools/autotune_gemm.py measured them faster inside the step). */
 int spnet_gemm_f32(const float* A, int a_major, int lda, const float* B, int b_major, int ldb, float* C,
                    int ldc, int M, int N, int K, int split_k, float* workspace, long ws_floats,
                    const float* bias, int tile, void* stream);
