@@ -239,6 +239,16 @@ int spnet_patches_ld(const float* in, long ldx, float* out, int B, int H, int W,
 int spnet_conv_fwd_implicit(const float* x, const float* w, float* y, int B, int H, int W, int cin, int cout, int KH,
                             int KW, int stride, int same, const float* bias, float* colstats, int* stat_rows,
                             void* stream);
+/* The same on the tuned GEMM kernel itself (gemm.hip, AG = 1): the A tile of K step (tap, 32 channels) is the plain
+ * K-major fetch from a shifted base with the out-of-image rows zeroed, in the pipeline slots of the matrix form -- no
+ * patch matrix, no gather launch, the tile ids / autotuned table of spnet_gemm_f32.  x pixels ldx floats apart (ldx >= C:
+ * a column block of a wider tensor), Wk = the HWIO kernel as [KH*KW*C][Cout], y [B*OH*OW][ldy]; C % 32 == 0, stride
+ * 1 | 2, TF SAME (same != 0) or VALID; bias / colstats + stat_rows optional (as spnet_gemm_f32_colstats).  Bit-identical
+ * to spnet_patches(_ld) + spnet_gemm_f32(_colstats) on the same tile (keras Conv2D k_h x k_w of Inception-ResNet-v2,
+ * spnet/models.py:357-359). */
+int spnet_conv_gemm_f32(const float* x, long ldx, const float* Wk, float* y, int ldy, int B, int H, int W, int C, int Cout,
+                        int KH, int KW, int stride, int same, const float* bias, int tile, float* colstats,
+                        int* stat_rows, void* stream);
 /* Gradient producers that also leave the BatchNorm-backward sums (sum g, sum g*xhat) of the conv2d_bn layer whose output
  * y = relu(BN(yp)) they differentiate, g masked with y > 0 when relu != 0: partial[rows][2][C], rows <=
  * spnet_grad_bnsums_rows(pixels, max_rows).  spnet_patches_bwd_bnsums = spnet_patches(backward = 1) + mask + sums (the

@@ -78,6 +78,7 @@ _SIGS = {
     "spnet_avgpool3x3s1_same": (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, P]),
     "spnet_patches": (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P]),
     "spnet_patches_ld": (c_int, [P, c_long, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P]),
+    "spnet_conv_gemm_f32": (c_int, [P, c_long, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, c_int, P, P, P]),
     "spnet_conv_fwd_implicit": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P, P, P]),
     "spnet_grad_bnsums_rows": (c_long, [c_long, c_int]),
     "spnet_patches_bwd_bnsums": (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P, P, P, c_int, P,

@@ -109,10 +109,21 @@ __device__ __forceinline__ void sp_interleave() {
   }
 }
 
+// AG = 1: the A operand is not a matrix in memory but the patch matrix of a convolution, gathered from the NHWC tensor
+// while the tile is staged (implicit GEMM): A[m][k] = X[b][oh*s + kh - pt][ow*s + kw - pl][c] with m = (b, oh, ow) and
+// k = (kh*KW + kw)*C + c, zero outside the image.  C is a multiple of the K tile (32), so a K tile lies inside ONE tap: the
+// tile's fetch is the plain K-major fetch from a shifted base pointer (the row offsets are those of the tap-(0,0) pixels,
+// computed once) with the rows whose tap falls outside the image zeroed -- TileStage::load_gather, the same loads in the
+// same pipeline slots as the matrix form, no patch matrix, no gather launch.  k runs in the order of the patch matrix,
+// so the result has the bits of spnet_patches + spnet_gemm_f32 on the same tile.
+struct ConvGeom {
+  int H, W, C, KW, stride, pt, pl, OH, OW;      // C == 0: not a convolution
+};
+
 // PIPE = 1: the explicitly software-pipelined main loop (below) instead of the compiler-scheduled one.  It needs four
 // K tiles of lead-in and pays from about 32 K tiles per workgroup (the weight gradients, the exit flow): measured per
 // shape with tools/gemm_table.py, +3..8 % there, -10..20 % on the 2-8-tile GEMMs of the entry flow, equal at 23 tiles.
-template <int BM, int BN, int BK, int WM, int WN, int AMAJ, int BMAJ, int AX = 0, int PIPE = 0>
+template <int BM, int BN, int BK, int WM, int WN, int AMAJ, int BMAJ, int AX = 0, int PIPE = 0, int AG = 0>
 __global__ __launch_bounds__(256, (AX && BM * BN <= 96 * 64) ? 3 : 2) void gemm_f32_kernel(const float* __restrict__ A_, int lda,
                                                        const float* __restrict__ B_, int ldb,
                                                        float* __restrict__ C_, int ldc, int M, int N,
@@ -123,8 +134,10 @@ __global__ __launch_bounds__(256, (AX && BM * BN <= 96 * 64) ? 3 : 2) void gemm_
                                                        const long long* __restrict__ batch,
                                                        const float* __restrict__ X2,
                                                        const float* __restrict__ coef, int cld,
-                                                       float* __restrict__ dy_out, int kslices, int accumulate) {
+                                                       float* __restrict__ dy_out, int kslices, int accumulate,
+                                                       const ConvGeom cg) {
   static_assert(WM * WN == 4, "4 waves per workgroup");
+  static_assert(!AG || (!AX && AMAJ == SP_K_MAJOR), "gathered A operands are plain and K-major");
   static_assert(!AX || AMAJ == SP_K_MAJOR, "blended A operands are K-major");
   constexpr int TM = BM / WM / 16, TN = BN / WN / 16;
   static_assert(TM >= 1 && TN >= 1 && (BM % (WM * 16)) == 0 && (BN % (WN * 16)) == 0, "wave tile");
@@ -195,6 +208,47 @@ __global__ __launch_bounds__(256, (AX && BM * BN <= 96 * 64) ? 3 : 2) void gemm_
   for (int i = 0; i < SA::NV; ++i) sa[1].off[i] = sa[0].off[i];
 #pragma unroll
   for (int i = 0; i < SB::NV; ++i) sb[1].off[i] = sb[0].off[i];
+  // Gathered A: per slot, the element offset of the slot's output pixel at tap (0,0) without padding (lda = the pixel
+  // stride of X) and that pixel's input row / column, from which a tap's validity follows.
+  int goff[AG ? SA::NV : 1], gh[AG ? SA::NV : 1], gw[AG ? SA::NV : 1];
+  if constexpr (AG) {
+    static_assert(SA::TOTAL % 256 == 0, "whole float4 slots per thread");
+#pragma unroll
+    for (int i = 0; i < SA::NV; ++i) {
+      const int f = tid + i * 256;
+      const int r = min(m0 + f / (BK / 4), M - 1);
+      const int ow = r % cg.OW, t2 = r / cg.OW;
+      const int oh = t2 % cg.OH, b = t2 / cg.OH;
+      gh[i] = oh * cg.stride;
+      gw[i] = ow * cg.stride;
+      goff[i] = ((b * cg.H + gh[i]) * cg.W + gw[i]) * lda + (f % (BK / 4)) * 4;
+    }
+  }
+  // The K tiles of a problem are fetched in order (prologue: tiles 0, 1 (, 2, 3); step t: tile t+2 or t+4), so the tap
+  // of the next tile is running state -- a few scalar adds per tile; dividing k0 by C and KW on every fetch costs as
+  // much as the gather launch it replaces.
+  int g_c0 = 0, g_kw = 0, g_dh = -cg.pt, g_dw = -cg.pl;
+  auto gather_a = [&](auto& stA, int k0) {          // the next K tile of the patch matrix (inside one tap)
+    if constexpr (AG) {
+      const int shift = (g_dh * cg.W + g_dw) * lda + g_c0;
+      unsigned ok = 0;
+#pragma unroll
+      for (int i = 0; i < SA::NV; ++i)
+        ok |= (unsigned)((unsigned)(gh[i] + g_dh) < (unsigned)cg.H && (unsigned)(gw[i] + g_dw) < (unsigned)cg.W) << i;
+      stA.load_gather(A, goff, shift, k0 < kend ? ok : 0u);
+      g_c0 += BK;
+      if (g_c0 == cg.C) {
+        g_c0 = 0;
+        ++g_kw;
+        ++g_dw;
+        if (g_kw == cg.KW) {
+          g_kw = 0;
+          g_dw = -cg.pl;
+          ++g_dh;
+        }
+      }
+    }
+  };
 
   // Blended A operand: tile t+1 waits in its register stage as TWO raw tensors (v = g, w = yp); it is blended -- and,
   // by the column tile whose turn it is, written out as dy -- at the START of step t, before tile t+2's fetch
@@ -216,6 +270,7 @@ __global__ __launch_bounds__(256, (AX && BM * BN <= 96 * 64) ? 3 : 2) void gemm_
   };
   auto fetch = [&](auto& stA, auto& stB, int k0, auto& wreg) {      // any tile: predicated
     if constexpr (AX) stA.load2(A, X2, lda, m0, M, k0, kend, tid, wreg);
+    else if constexpr (AG) gather_a(stA, k0);
     else stA.load(A, lda, m0, M, k0, kend, tid);
     stB.load(B, ldb, n0, N, k0, kend, tid);
   };
@@ -330,7 +385,8 @@ __global__ __launch_bounds__(256, (AX && BM * BN <= 96 * 64) ? 3 : 2) void gemm_
       sb[PAR].store(cur + SA::SIZE, tid);
     }
     if (FULL) {
-      sa[PAR].load_full(Ak);
+      if constexpr (AG) gather_a(sa[PAR], kbeg + (t + 4) * BK);
+      else sa[PAR].load_full(Ak);
       sb[PAR].load_full(Bk);
       Ak += SA::kstep(lda);
       Bk += SB::kstep(ldb);
@@ -361,6 +417,7 @@ __global__ __launch_bounds__(256, (AX && BM * BN <= 96 * 64) ? 3 : 2) void gemm_
     }
     if (FULL) {
       if constexpr (AX) sa[PAR].load_full2(Ak, Xk, wsh);
+      else if constexpr (AG) gather_a(sa[PAR], kbeg + (t + 2) * BK);
       else sa[PAR].load_full(Ak);
       sb[PAR].load_full(Bk);
 #ifdef SP_DWMOCK
@@ -502,7 +559,8 @@ static int launch_tile(const float* A, int amaj, int lda, const float* B, int bm
                        int ldc, int M, int N, int K, int nsplit, int k_chunk, long slab_stride,
                        const float* bias, float* colstats, const long long* batch, hipStream_t st,
                        int xf = 0, const float* X2 = nullptr, const float* coef = nullptr, int cld = 0,
-                       float* dy_out = nullptr, int kslices = 1, int accumulate = 0) {
+                       float* dy_out = nullptr, int kslices = 1, int accumulate = 0, const ConvGeom* cgp = nullptr) {
+  const ConvGeom cg = cgp ? *cgp : ConvGeom{0, 0, 0, 0, 0, 0, 0, 0, 0};
   const int tm = spnet_cdiv(M, BM), tn = spnet_cdiv(N, BN);
   dim3 grid(tm * tn * nsplit), block(256);
 #ifdef SP_DWMOCK
@@ -511,7 +569,7 @@ static int launch_tile(const float* A, int amaj, int lda, const float* B, int bm
   // the pipelined main loop from 32 K tiles per workgroup (see the kernel's header comment)
   constexpr bool CAN_PIPE = SP_PIPE && (BM / WM / 16) * (BN / WN / 16) < 16;
   const bool pipe = CAN_PIPE && !xf && spnet_cdiv(K < k_chunk ? K : k_chunk, SP_BK) >= SP_PIPE_MIN_TILES;
-#define SP_ARGS A, lda, B, ldb, C, ldc, M, N, K, k_chunk, slab_stride, tm, tn, nsplit, bias, colstats, batch, X2, coef, cld, dy_out, kslices, accumulate
+#define SP_ARGS A, lda, B, ldb, C, ldc, M, N, K, k_chunk, slab_stride, tm, tn, nsplit, bias, colstats, batch, X2, coef, cld, dy_out, kslices, accumulate, cg
 #define SP_LAUNCH(BKV, AM, BMJ, AXV, PV) \
   hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, BKV, WM, WN, AM, BMJ, AXV, PV>), grid, block, 0, st, SP_ARGS)
 #define SP_LAUNCH_P(AM, BMJ)                                          \
@@ -523,7 +581,15 @@ static int launch_tile(const float* A, int amaj, int lda, const float* B, int bm
       SP_LAUNCH(SP_BK, AM, BMJ, 0, 0);                                \
     }                                                                 \
   } while (0)
-  if (xf == 1) {
+  if (cg.C) {          // gathered A (implicit-GEMM convolution): forward operand form only
+    if (xf || amaj != SP_K_MAJOR || bmaj != SP_OUT_MAJOR) return (int)hipErrorInvalidValue;
+    if constexpr (CAN_PIPE) {
+      if (pipe) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, SP_BK, WM, WN, SP_K_MAJOR, SP_OUT_MAJOR, 0, 1, 1>), grid, block, 0, st, SP_ARGS);
+      else hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, SP_BK, WM, WN, SP_K_MAJOR, SP_OUT_MAJOR, 0, 0, 1>), grid, block, 0, st, SP_ARGS);
+    } else {
+      hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, SP_BK, WM, WN, SP_K_MAJOR, SP_OUT_MAJOR, 0, 0, 1>), grid, block, 0, st, SP_ARGS);
+    }
+  } else if (xf == 1) {
     if (amaj == SP_K_MAJOR && bmaj == SP_OUT_MAJOR) SP_LAUNCH(SP_BK, SP_K_MAJOR, SP_OUT_MAJOR, 1, 0);
     else return (int)hipErrorInvalidValue;
   } else if (amaj == SP_K_MAJOR && bmaj == SP_OUT_MAJOR) SP_LAUNCH_P(SP_K_MAJOR, SP_OUT_MAJOR);
@@ -624,8 +690,11 @@ static int gemm_impl(const float* A, int a_major, int lda, const float* B, int b
                      int ldc, int M, int N, int K, int split_k, float* workspace, long ws_floats,
                      const float* bias, int tile, float* colstats, int* stat_rows, void* stream,
                      const long long* batch = nullptr, int nbatch = 0, int xf = 0, const float* X2 = nullptr,
-                     const float* coef = nullptr, int cld = 0, float* dy_out = nullptr, int accumulate = 0) {
+                     const float* coef = nullptr, int cld = 0, float* dy_out = nullptr, int accumulate = 0,
+                     const ConvGeom* cg = nullptr) {
   hipStream_t st = (hipStream_t)stream;
+  if (cg && (batch || xf || accumulate || a_major != SP_K_MAJOR || b_major != SP_OUT_MAJOR || split_k != 1))
+    return (int)hipErrorInvalidValue;     // gathered A: one whole forward-form problem
   if (accumulate) {                  // C += A B in the epilogue: whole dot products only (no slabs), one problem
     if (batch || colstats || xf) return (int)hipErrorInvalidValue;
     split_k = 1;
@@ -684,16 +753,16 @@ static int gemm_impl(const float* A, int a_major, int lda, const float* B, int b
   if (batch) nsplit = nbatch * kslices;      // the kernel's slice index selects (problem, K slice)
   int rc;
   switch (tile) {
-    case 1: rc = launch_tile<128, 128, 2, 2>(A, a_major, lda, B, b_major, ldb, out, out_ld, M, N, K, nsplit, k_chunk, slab, kbias, colstats, batch, st, xf, X2, coef, cld, dy_out, kslices, accumulate); break;
-    case 2: rc = launch_tile<128, 64, 2, 2>(A, a_major, lda, B, b_major, ldb, out, out_ld, M, N, K, nsplit, k_chunk, slab, kbias, colstats, batch, st, xf, X2, coef, cld, dy_out, kslices, accumulate); break;
-    case 3: rc = launch_tile<64, 64, 2, 2>(A, a_major, lda, B, b_major, ldb, out, out_ld, M, N, K, nsplit, k_chunk, slab, kbias, colstats, batch, st, xf, X2, coef, cld, dy_out, kslices, accumulate); break;
-    case 5: rc = launch_tile<96, 96, 2, 2>(A, a_major, lda, B, b_major, ldb, out, out_ld, M, N, K, nsplit, k_chunk, slab, kbias, colstats, batch, st, xf, X2, coef, cld, dy_out, kslices, accumulate); break;
-    case 6: rc = launch_tile<96, 64, 2, 2>(A, a_major, lda, B, b_major, ldb, out, out_ld, M, N, K, nsplit, k_chunk, slab, kbias, colstats, batch, st, xf, X2, coef, cld, dy_out, kslices, accumulate); break;
-    case 7: rc = launch_tile<64, 128, 2, 2>(A, a_major, lda, B, b_major, ldb, out, out_ld, M, N, K, nsplit, k_chunk, slab, kbias, colstats, batch, st, xf, X2, coef, cld, dy_out, kslices, accumulate); break;
-    case 8: rc = launch_tile<128, 96, 2, 2>(A, a_major, lda, B, b_major, ldb, out, out_ld, M, N, K, nsplit, k_chunk, slab, kbias, colstats, batch, st, xf, X2, coef, cld, dy_out, kslices, accumulate); break;
-    case 9: rc = launch_tile<32, 64, 2, 2>(A, a_major, lda, B, b_major, ldb, out, out_ld, M, N, K, nsplit, k_chunk, slab, kbias, colstats, batch, st, xf, X2, coef, cld, dy_out, kslices, accumulate); break;
-    case 10: rc = launch_tile<32, 32, 2, 2>(A, a_major, lda, B, b_major, ldb, out, out_ld, M, N, K, nsplit, k_chunk, slab, kbias, colstats, batch, st, xf, X2, coef, cld, dy_out, kslices, accumulate); break;
-    default: rc = launch_tile<32, 128, 1, 4>(A, a_major, lda, B, b_major, ldb, out, out_ld, M, N, K, nsplit, k_chunk, slab, kbias, colstats, batch, st, xf, X2, coef, cld, dy_out, kslices, accumulate); break;
+    case 1: rc = launch_tile<128, 128, 2, 2>(A, a_major, lda, B, b_major, ldb, out, out_ld, M, N, K, nsplit, k_chunk, slab, kbias, colstats, batch, st, xf, X2, coef, cld, dy_out, kslices, accumulate, cg); break;
+    case 2: rc = launch_tile<128, 64, 2, 2>(A, a_major, lda, B, b_major, ldb, out, out_ld, M, N, K, nsplit, k_chunk, slab, kbias, colstats, batch, st, xf, X2, coef, cld, dy_out, kslices, accumulate, cg); break;
+    case 3: rc = launch_tile<64, 64, 2, 2>(A, a_major, lda, B, b_major, ldb, out, out_ld, M, N, K, nsplit, k_chunk, slab, kbias, colstats, batch, st, xf, X2, coef, cld, dy_out, kslices, accumulate, cg); break;
+    case 5: rc = launch_tile<96, 96, 2, 2>(A, a_major, lda, B, b_major, ldb, out, out_ld, M, N, K, nsplit, k_chunk, slab, kbias, colstats, batch, st, xf, X2, coef, cld, dy_out, kslices, accumulate, cg); break;
+    case 6: rc = launch_tile<96, 64, 2, 2>(A, a_major, lda, B, b_major, ldb, out, out_ld, M, N, K, nsplit, k_chunk, slab, kbias, colstats, batch, st, xf, X2, coef, cld, dy_out, kslices, accumulate, cg); break;
+    case 7: rc = launch_tile<64, 128, 2, 2>(A, a_major, lda, B, b_major, ldb, out, out_ld, M, N, K, nsplit, k_chunk, slab, kbias, colstats, batch, st, xf, X2, coef, cld, dy_out, kslices, accumulate, cg); break;
+    case 8: rc = launch_tile<128, 96, 2, 2>(A, a_major, lda, B, b_major, ldb, out, out_ld, M, N, K, nsplit, k_chunk, slab, kbias, colstats, batch, st, xf, X2, coef, cld, dy_out, kslices, accumulate, cg); break;
+    case 9: rc = launch_tile<32, 64, 2, 2>(A, a_major, lda, B, b_major, ldb, out, out_ld, M, N, K, nsplit, k_chunk, slab, kbias, colstats, batch, st, xf, X2, coef, cld, dy_out, kslices, accumulate, cg); break;
+    case 10: rc = launch_tile<32, 32, 2, 2>(A, a_major, lda, B, b_major, ldb, out, out_ld, M, N, K, nsplit, k_chunk, slab, kbias, colstats, batch, st, xf, X2, coef, cld, dy_out, kslices, accumulate, cg); break;
+    default: rc = launch_tile<32, 128, 1, 4>(A, a_major, lda, B, b_major, ldb, out, out_ld, M, N, K, nsplit, k_chunk, slab, kbias, colstats, batch, st, xf, X2, coef, cld, dy_out, kslices, accumulate, cg); break;
   }
   if (rc) return rc;
   if (nsplit > 1 && !batch) {
@@ -787,6 +856,32 @@ extern "C" int spnet_gemm_f32_colstats(const float* A, int a_major, int lda, con
   if (!colstats || !stat_rows) return (int)hipErrorInvalidValue;
   return gemm_impl(A, a_major, lda, B, b_major, ldb, C, ldc, M, N, K, 1, nullptr, 0, nullptr, tile, colstats,
                    stat_rows, stream);
+}
+
+// The forward convolution of an NHWC tensor as an implicit GEMM on the same kernel: y[B*OH*OW][Cout] = patches(x) * Wk,
+// Wk = the HWIO kernel read as [KH*KW*C][Cout], the patch matrix never written (AG = 1 above).  x pixels are ldx floats
+// apart (ldx >= C: x may be a column block of a wider tensor); C % 32 == 0; stride 1 or 2; `same` = TF SAME padding, else
+// VALID.  bias (or NULL) is added in the epilogue; colstats / stat_rows (or NULL / NULL) as spnet_gemm_f32_colstats.
+// Bit-identical to spnet_patches + spnet_gemm_f32(_colstats) with the same tile.
+extern "C" int spnet_conv_gemm_f32(const float* x, long ldx, const float* Wk, float* y, int ldy, int B, int H, int W,
+                                   int C, int Cout, int KH, int KW, int stride, int same, const float* bias, int tile,
+                                   float* colstats, int* stat_rows, void* stream) {
+  if (!x || !Wk || !y || B < 1 || H < 1 || W < 1 || KH < 1 || KW < 1 || (stride != 1 && stride != 2)) return (int)hipErrorInvalidValue;
+  if (C < SP_BK || (C % SP_BK) || (ldx & 3) || ldx < C || (!colstats) != (!stat_rows)) return (int)hipErrorInvalidValue;
+  if ((long)B * H * W * ldx >= (1L << 31)) return (int)hipErrorInvalidValue;       // 32-bit element offsets in the gather
+  ConvGeom cg;
+  cg.H = H; cg.W = W; cg.C = C; cg.KW = KW; cg.stride = stride;
+  if (same) {
+    cg.OH = (H + stride - 1) / stride; cg.OW = (W + stride - 1) / stride;
+    int th = (cg.OH - 1) * stride + KH - H, tw = (cg.OW - 1) * stride + KW - W;
+    cg.pt = (th < 0 ? 0 : th) / 2; cg.pl = (tw < 0 ? 0 : tw) / 2;
+  } else {
+    cg.OH = (H - KH) / stride + 1; cg.OW = (W - KW) / stride + 1;
+    cg.pt = cg.pl = 0;
+  }
+  if (cg.OH < 1 || cg.OW < 1) return (int)hipErrorInvalidValue;
+  return gemm_impl(x, SP_K_MAJOR, (int)ldx, Wk, SP_OUT_MAJOR, Cout, y, ldy, B * cg.OH * cg.OW, Cout, KH * KW * C, 1, nullptr, 0,
+                   bias, tile, colstats, stat_rows, stream, nullptr, 0, 0, nullptr, nullptr, 0, nullptr, 0, &cg);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -1983,9 +1983,16 @@ class _IRConv:
         # the tuned GEMM behind it beats the gathered 64x64-tile kernel by more than that.
         self.implicit = (not self.direct and not self.small and cin % 16 == 0 and self.kh * self.kw <= 32 and
                          os.environ.get("SPNET_IR_IMPLICIT_FWD", "0") == "1")
+        # Round 3, second attempt, ON by default (SPNET_IR_GATHER_FWD=0: patch gather + GEMM): the same convolution on the
+        # TUNED GEMM kernel with its A tiles gathered while they are staged (spnet_conv_gemm_f32: same tiles, same
+        # pipeline, same bits; cin a multiple of the 32-deep K tile) -- the forward patch gather launch disappears from
+        # the main stream's chain; the weight gradient gathers its patch matrix itself, on its own stream.
+        self.gathered = (not self.direct and not self.small and not self.implicit and cin % 32 == 0 and
+                         os.environ.get("SPNET_IR_GATHER_FWD", "1") != "0")
         self.w = eng.P(cname + "/kernel")
         # (an inference plan whose convolution runs as an implicit GEMM never needs the patch matrix)
-        no_col = self.direct or self.small or (self.implicit and not eng.train_capable and src.buf.is_contiguous())
+        no_col = self.direct or self.small or (not eng.train_capable and
+                                               (self.gathered or (self.implicit and src.buf.is_contiguous())))
         self.col = None if no_col else eng.new(self.M, self.K)
         self.col_floats = 0 if (self.direct or self.small) else self.M * self.K
         self.out = _T(eng.new(B, OH, OW, cout))
@@ -2030,7 +2037,7 @@ class _IRConv:
 
     def gather_patches(self):
         """The patch matrix of my input, for the weight-gradient GEMM (implicit-forward convolutions skipped it in forward)."""
-        if self.implicit and self.src.buf.is_contiguous():
+        if self.gathered or (self.implicit and self.src.buf.is_contiguous()):
             L.spnet_patches_ld(L.ptr(self.src.buf), self.src.buf.stride(2), L.ptr(self.col), self.e.B, self.H, self.W,
                                self.cin, self.kh, self.kw, self.stride, self.same, _stream())
 
@@ -2045,6 +2052,25 @@ class _IRConv:
         if self.small:
             L.spnet_conv3x3_small(0, 3, C, self.stride, 0, L.ptr(self.src.buf), L.ptr(self.w), L.ptr(dst), e.B, self.H,
                                   self.W, e.ws_ptr(WS_MISC), WS_MISC[1], _stream())
+        elif self.gathered:
+            stats = training and not self.bias and e.bn_fold
+            prof = e.prof
+            t0 = prof.start() if prof is not None else None
+            L.spnet_conv_gemm_f32(L.ptr(self.src.buf), self.src.buf.stride(2), L.ptr(self.w), L.ptr(dst), C, e.B, self.H,
+                                  self.W, self.cin, C, self.kh, self.kw, self.stride, self.same,
+                                  L.ptr(self.b) if self.bias else None,
+                                  _tile_for(K_MAJOR, OUT_MAJOR, 1 if stats else 0, self.M, C, self.K, 0),
+                                  e.ws_ptr(WS_BNP) if stats else None,
+                                  __import__("ctypes").addressof(_stat_rows) if stats else None, _stream())
+            if prof is not None:
+                prof.stop("gemm", t0, 2.0 * self.M * C * self.K, ("conv gathered", self.M, C, self.K))
+                prof.keys[len(prof.records) - 1] = (K_MAJOR, OUT_MAJOR, 1 if stats else 0, self.M, C, self.K)
+            if stats:
+                L.spnet_bn_finalize_apply_ld(e.ws_ptr(WS_BNP), _stat_rows.value, L.ptr(self.yp), self.M, C, L.ptr(self.ones),
+                                             L.ptr(self.beta), L.ptr(self.mm), L.ptr(self.mv), L.ptr(self.save),
+                                             self.save[C:].data_ptr(), L.ptr(self.ss), ACT_RELU if self.relu else ACT_NONE,
+                                             None, L.ptr(y), self.ldy, BN_EPS, BN_MOMENTUM, _stream())
+                return
         elif self.implicit and self.src.buf.is_contiguous():
             stats = training and not self.bias and e.bn_fold
             prof = e.prof

@@ -89,6 +89,39 @@ def test_general_convolution_through_patches_and_gemm(B, H, W, C, kh, kw, stride
         L.spnet_conv_fwd_implicit(xd.data_ptr(), wd.data_ptr(), yb.data_ptr(), B, H, W, C, cout, kh, kw, stride, same,
                                   bias.data_ptr(), None, None, st)
         assert torch.equal(yb, yi + bias)
+    # ... and on the tuned GEMM kernel itself (gathered A tiles, spnet_conv_gemm_f32): every tile id, bit-identical to
+    # patches + GEMM on that tile, statistics rows as the GEMM leaves them, bias, and an input that is a column block
+    if C % 32 == 0:
+        import ctypes
+        wide = torch.tensor(rs.randn(B, H, W, C + 24), dtype=torch.float32).cuda()
+        wide[..., 8:8 + C] = xd
+        for tile in (0, 1, 2, 3, 5, 6, 7, 8, 9, 10):
+            yt = torch.empty(M, cout, device="cuda")
+            cst = torch.full(((M + 31) // 32 * 2 * cout,), float("nan"), device="cuda")
+            nr = ctypes.c_int(0)
+            L.spnet_gemm_f32_colstats(col.data_ptr(), 0, K, wd.data_ptr(), 1, cout, yt.data_ptr(), cout, M, cout, K, tile,
+                                      cst.data_ptr(), ctypes.addressof(nr), st)
+            yg = torch.full((M, cout), float("nan"), device="cuda")
+            csg = torch.full_like(cst, float("nan"))
+            ng = ctypes.c_int(0)
+            L.spnet_conv_gemm_f32(xd.data_ptr(), C, wd.data_ptr(), yg.data_ptr(), cout, B, H, W, C, cout, kh, kw, stride, same,
+                                  None, tile, csg.data_ptr(), ctypes.addressof(ng), st)
+            assert torch.equal(yg, yt), tile
+            assert ng.value == nr.value and torch.equal(csg[:ng.value * 2 * cout], cst[:nr.value * 2 * cout]), tile
+            yw = torch.full((M, cout), float("nan"), device="cuda")
+            L.spnet_conv_gemm_f32(wide.data_ptr() + 32, C + 24, wd.data_ptr(), yw.data_ptr(), cout, B, H, W, C, cout, kh, kw,
+                                  stride, same, None, tile, None, None, st)
+            assert torch.equal(yw, yt), tile
+        bias2 = torch.tensor(rs.randn(cout), dtype=torch.float32).cuda()
+        yb2 = torch.empty(M, cout, device="cuda")
+        L.spnet_gemm_f32(col.data_ptr(), 0, K, wd.data_ptr(), 1, cout, yt.data_ptr(), cout, M, cout, K, 1, None, 0,
+                         bias2.data_ptr(), 9, st)
+        L.spnet_conv_gemm_f32(xd.data_ptr(), C, wd.data_ptr(), yb2.data_ptr(), cout, B, H, W, C, cout, kh, kw, stride, same,
+                              bias2.data_ptr(), 9, None, None, st)
+        assert torch.equal(yb2, yt)
+        with pytest.raises(L.HipError):                                                      # C % 32 != 0 is refused
+            L.spnet_conv_gemm_f32(xd.data_ptr(), C, wd.data_ptr(), yb2.data_ptr(), cout, B, H, W, C - 16, cout, kh, kw,
+                                  stride, same, None, 0, None, None, st)
     # the adjoint gather that also masks with the producer's ReLU and leaves its BatchNorm-backward sums
     rows = int(L.spnet_grad_bnsums_rows(B * H * W, 512))
     assert 1 <= rows <= 512
