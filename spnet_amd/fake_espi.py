@@ -36,12 +36,14 @@ def _overlaps(a, b):
     return not (a[2] < b[0] or a[0] > b[2] or a[3] < b[1] or a[1] > b[3])
 
 
-def draw_params(seed):
+def draw_params(seed, count_range=(1, 7)):
     """All random PARAMETERS of one frame, drawn in the generator's order from RandomState(seed):
     waves = (amp, wavelength, thickness, slope, spacing) (draw_waves, gen_fake_espi.py:60-80) and
     nodes = [(cx, cy, a, b, angle, rings, ring_start)] (draw_antinodes :145-206 incl. the non-overlap rejection
     loop, draw_rings' rand_start :107).  Returns (waves, nodes, rs) -- rs continues with the noise / dropout draws
-    of the host rasteriser."""
+    of the host rasteriser.  count_range = (lo, hi) inclusive: the number of antinodes drawn per frame -- (1, 7) is the
+    reference's current generator (gen_fake_espi.py:250-251); its comments there date that to 'Nov 11 2020 increasing
+    from 6 to 7 ... elminating 0', i.e. the published Dataset-A run was generated with (0, 6): 3.0 objects per frame."""
     rs = np.random.RandomState(seed)
     amp = rs.randint(10, 201)
     wavelength = rs.randint(100, IM_W // 2 + 1)
@@ -51,7 +53,7 @@ def draw_params(seed):
     spacing = rs.randint(lo, max(lo, IM_H // 3) + 1)
     waves = (amp, wavelength, thick, slope, spacing)
     boxes, nodes = [], []
-    for _ in range(rs.randint(1, 8)):
+    for _ in range(rs.randint(count_range[0], count_range[1] + 1)):
         axes = sorted((rs.randint(15, int(IM_W / 3.5) + 1), rs.randint(15, int(IM_H / 3.5) + 1)), reverse=True)
         rings = rs.randint(1, min(axes[1] // 8, 11) + 1)
         if axes[1] / rings < MIN_LINE_WIDTH:
@@ -121,7 +123,7 @@ def frame_seeds(n, seed):
     return [seed * 1000003 + i for i in range(n)]
 
 
-def generate_device(n, seed=0, device="cuda:0", noise=True, want_u8=False, chunk=1024):
+def generate_device(n, seed=0, device="cuda:0", noise=True, want_u8=False, chunk=1024, count_range=(1, 7)):
     """n frames rasterised directly in HBM (csrc/espi.hip): the SAME per-frame parameters as generate(n, seed)
     (so the labels are identical), pixels from the analytic device rasteriser, sensor noise / dropout from a
     counter-based RNG.  Returns (float32 device tensor [n,384,512,1] in [-1,1], label rows[, uint8 device tensor])."""
@@ -138,7 +140,7 @@ def generate_device(n, seed=0, device="cuda:0", noise=True, want_u8=False, chunk
         nodes = np.zeros((hi - lo, 7, 8), np.float32)
         nn = np.zeros(hi - lo, np.int32)
         for k, s in enumerate(frame_seeds(n, seed)[lo:hi]):
-            w, nd, _ = draw_params(s)
+            w, nd, _ = draw_params(s, count_range)
             waves[k] = w
             nn[k] = len(nd)
             for j, node in enumerate(nd):

@@ -127,6 +127,12 @@ class InterleaveColumns:
 
 
 # ----------------------------------------------------------------------------- model object
+# epsilon of keras.optimizers.Adam as the reference constructs it (Adam(lr=0.00001), spnet/models.py:494): Keras 2.1.3's
+# default is epsilon=None -> K.epsilon() = 1e-7 (earlier releases: 1e-8).  Unpinned by any Keras run here; DESIGN.md
+# section 1b records which value the early training dynamics of the reference's published run select.
+ADAM_EPS = 1e-7
+
+
 class _Optimizer:
     def __init__(self, lr=1e-5):
         self.lr = lr
@@ -243,7 +249,7 @@ class Model:
                 for a in ("grad", "m", "v"):       # optimizer state lives beside the weights it updates
                     setattr(root, a, torch.zeros(root.n_theta, device=root.dev, dtype=torch.float32))
             eng = self._Engine(self.H, self.W, batch, n_out=self.Y0size, device=self.device, loss_type=cf.loss_type,
-                               seed=self.seed, train=train, share_from=root, rank=self.rank,
+                               seed=self.seed, train=train, adam_eps=ADAM_EPS, share_from=root, rank=self.rank,
                                sigmoid_cols=(cf.ind_noobj, cf.vars_per_pred) if self.compound else None,
                                backbone=self.basemodel)
             if root is None:
@@ -343,10 +349,12 @@ class Model:
 
     def _device_frames(self, X):
         torch = _torch()
-        if isinstance(X, torch.Tensor):
-            return X if X.is_cuda else X.to(self.device)
+        # (the registered training array first: AugmentOnTheFly given a device tensor keeps it pristine and augments a
+        # second tensor, which is the one fit() must read -- the reference's in-place aliasing, callbacks.py:289,336)
         if self._train_frames is not None and self._train_frames[0] == id(X):
             return self._train_frames[1]
+        if isinstance(X, torch.Tensor):
+            return X if X.is_cuda else X.to(self.device)
         # One-entry upload cache so that fit() does not re-send an unchanged training array every epoch.  The
         # entry keeps a reference to the host array: id() of a dead temporary (X[:n]) can be handed to the next
         # one, and would otherwise return the wrong frames.

@@ -1,8 +1,46 @@
 """Shared helpers of the engine-vs-oracle parity tests (test infrastructure)."""
+import json
+import os
+
 import numpy as np
 import torch
 
 from oracle import torch_ref as T
+
+# Tolerances of the end-to-end parity tests, set from what is OBSERVED (round 4): every case logs its worst figure
+# through observe() (SPNET_PARITY_LOG=<file>: one JSON line per figure; profiles/r04_parity_observed.txt is the GPU
+# suite's log), and each bound below is about 10x the worst value any case of the suite produced.
+GRAD_TOL = 5e-3          # max|dgrad - ref| / max|ref| per parameter tensor (fp64 oracle on the device's decisions)
+OUT_REL_TOL = 5e-4       # the same measure on the network output of a training forward
+FWD_MSE_FACTOR = 1e-8    # inference forward: MSE <= factor * max(mean(ref^2), 1)   (north-star tolerance: 1e-4)
+
+
+def observe(kind, value, detail=""):
+    """Append one observed parity figure to $SPNET_PARITY_LOG (no-op when unset)."""
+    path = os.environ.get("SPNET_PARITY_LOG")
+    if path:
+        with open(path, "a") as f:
+            f.write(json.dumps({"kind": kind, "value": float(value), "detail": detail,
+                                "test": os.environ.get("PYTEST_CURRENT_TEST", "").split(" ")[0]}) + "\n")
+
+
+def assert_forward_mse(got, want, factor=None):
+    """Inference forward against the oracle: MSE <= factor * max(mean(want^2), 1)."""
+    got, want = np.asarray(got, np.float64), np.asarray(want, np.float64)
+    mse = float(((got - want) ** 2).mean())
+    scale = max(float((want ** 2).mean()), 1.0)
+    observe("fwd_mse_over_scale", mse / scale)
+    f = FWD_MSE_FACTOR if factor is None else factor
+    assert mse <= f * scale, (mse, scale)
+    return mse
+
+
+def assert_output_close(got, ref64, tol=None):
+    """Network output of a training forward against the fp64 oracle's (rel_err measure)."""
+    e = rel_err(got, ref64)
+    observe("train_out_rel_err", e)
+    assert e <= (OUT_REL_TOL if tol is None else tol), e
+    return e
 
 
 def dropout_mask(n, seed, rate=0.1):
@@ -112,12 +150,14 @@ def device_decisions(eng):
     return T.Decisions(relu, pool)
 
 
-def assert_gradients_match(eng, P, X, Y, mask, tol=5e-3, tie=1e-5, loss_type="same", sigmoid_cols=None,
+def assert_gradients_match(eng, P, X, Y, mask, tol=None, tie=1e-5, loss_type="same", sigmoid_cols=None,
                            max_override_rate=1e-5):
     """Every parameter gradient of the engine's last forward/backward against the fp64 oracle evaluated on the
     device's own discrete decisions: max|diff| <= tol * max|ref| on EVERY tensor, and every decision in which the
     device departs from the oracle's own must have been a tie (|pre-activation| or window gap <= tie x the largest
-    value of that tensor), and at most max_override_rate of all decisions may be overridden at all.  Returns (data_loss64, y_pred64, params64, decisions)."""
+    value of that tensor), and at most max_override_rate of all decisions may be overridden at all.  tol=None: GRAD_TOL.
+    Returns (data_loss64, y_pred64, params64, decisions); the worst per-tensor error is logged through observe()."""
+    tol = GRAD_TOL if tol is None else tol
     dec = device_decisions(eng)
     data64, g64, yp64, P64 = oracle_grads(P, X, Y, mask, double=True, decisions=dec, loss_type=loss_type,
                                           sigmoid_cols=sigmoid_cols)
@@ -132,11 +172,14 @@ def assert_gradients_match(eng, P, X, Y, mask, tol=5e-3, tie=1e-5, loss_type="sa
     # a tensor whose true gradient vanishes identically (a bias in front of a training-mode BatchNorm: Inception-
     # ResNet's block8_10_conv/bias, 1e-17 in fp64) is measured against 1e-6 of the model's largest gradient entry
     floor = 1e-6 * max(float(np.abs(v.numpy()).max()) for v in g64.values())
-    bad = {}
+    bad, worst = {}, (0.0, "")
     for k in g64:
         ref = g64[k].numpy()
         e = float(np.abs(gd[k].numpy().astype(np.float64) - ref).max()) / max(float(np.abs(ref).max()), floor)
+        worst = max(worst, (e, k))
         if e > tol:
             bad[k] = e
+    observe("grad_rel_err_worst_tensor", worst[0], worst[1])
+    observe("decisions_overridden", n_over, "of %d; largest gap %.3g" % (dec.n_decisions, max([f[2] for f in dec.flips] or [0.0])))
     assert not bad, sorted(bad.items(), key=lambda kv: -kv[1])[:8]
     return data64, yp64, P64, dec

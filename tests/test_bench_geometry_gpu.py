@@ -11,7 +11,7 @@ import torch
 pytestmark = pytest.mark.gpu
 
 from oracle import torch_ref as T
-from tests.parity_util import assert_gradients_match, make_case, rel_err
+from tests.parity_util import assert_forward_mse, assert_gradients_match, assert_output_close, make_case, rel_err
 
 H, W = 384, 512
 
@@ -38,8 +38,7 @@ def test_inference_forward_at_benchmark_geometry(case):
     np.testing.assert_allclose(eng.stem_out.cpu().numpy(), taps["stem"].numpy(), rtol=1e-4, atol=1e-5)
     scale = float(taps["backbone"].abs().max())
     np.testing.assert_allclose(eng.backbone_out.cpu().numpy(), taps["backbone"].numpy(), rtol=1e-3, atol=1e-4 * scale)
-    mse = float(((got - want) ** 2).mean())
-    assert mse <= 1e-8 * max(float((want ** 2).mean()), 1.0), mse      # north-star tolerance: 1e-4
+    assert_forward_mse(got, want)      # north-star tolerance: 1e-4; fp32 against fp32 is far tighter
 
 
 def test_training_forward_and_every_gradient_at_benchmark_geometry(case):
@@ -55,9 +54,9 @@ def test_training_forward_and_every_gradient_at_benchmark_geometry(case):
     loss = eng.loss(Y.cuda())
     eng.backward()
     torch.cuda.synchronize()
-    data64, yp64, P64, dec = assert_gradients_match(eng, P, X, Y, mask, tol=5e-3)
+    data64, yp64, P64, dec = assert_gradients_match(eng, P, X, Y, mask)
     print("decisions overridden (site, count, distance from the tie):", dec.flips)
-    assert rel_err(out.cpu().numpy(), yp64.numpy()) <= 5e-4
+    assert_output_close(out.cpu().numpy(), yp64.numpy())
     np.testing.assert_allclose(float(loss[5]), data64, rtol=1e-4)
     sd = eng.state_dict()
     for k in P:                          # BatchNorm moving statistics after one training forward
@@ -79,7 +78,7 @@ def test_predict_config4_batch128(case):
     y128 = m.predict(X, batch_size=128)
     assert y128.shape == (128, 576) and np.isfinite(y128).all()
     want = T.forward(P, X2, training=False).numpy()
-    assert float(((y128[:2] - want) ** 2).mean()) <= 1e-8 * max(float((want ** 2).mean()), 1.0)
+    assert_forward_mse(y128[:2], want)
     y2 = m.predict(X, batch_size=2)
     scale = float(np.abs(y2).max())
     np.testing.assert_allclose(y128, y2, rtol=1e-4, atol=1e-5 * scale)

@@ -197,7 +197,7 @@ def test_compound_head_model(tmp_path):
     from oracle import torch_ref as T
     from spnet_amd import config as cf
     from spnet_amd import models as M
-    from tests.parity_util import assert_gradients_match, make_case, rel_err
+    from tests.parity_util import assert_forward_mse, assert_gradients_match, assert_output_close, make_case, rel_err
     H, W, B = 96, 128, 2
     P, X, Y, mask, dseed = make_case(H, W, B, 1)
     old = cf.model_type
@@ -213,7 +213,7 @@ def test_compound_head_model(tmp_path):
     sc = (cf.ind_noobj, cf.vars_per_pred)
     want = T.forward(P, X, training=False, sigmoid_cols=sc).numpy()
     got = model.predict(X.numpy(), batch_size=B)
-    assert float(((got - want) ** 2).mean()) <= 1e-8 * max(float((want ** 2).mean()), 1.0)
+    assert_forward_mse(got, want)
     assert got[:, 6::8].min() > 0 and got[:, 6::8].max() < 1      # sigmoid columns where InterleaveColumns puts them
     # the interleaving itself: SigmoidOutput column p is output column 6 + 8p
     np.testing.assert_array_equal(model.state_dict()["SigmoidOutput/kernel"].numpy(), P["FinalOutput/kernel"].numpy()[:, 6::8])
@@ -223,8 +223,8 @@ def test_compound_head_model(tmp_path):
     eng.loss(Y.cuda())
     eng.backward()
     torch.cuda.synchronize()
-    _, yp64, _, _ = assert_gradients_match(eng, P, X, Y, mask, tol=5e-3, sigmoid_cols=sc)
-    assert rel_err(out.cpu().numpy(), yp64.numpy()) <= 5e-4
+    _, yp64, _, _ = assert_gradients_match(eng, P, X, Y, mask, sigmoid_cols=sc)
+    assert_output_close(out.cpu().numpy(), yp64.numpy())
     # checkpoint round trips keep the head variant
     path = str(tmp_path / "full_model.h5")
     model.save(path)
