@@ -399,24 +399,26 @@ def layout_331_measure(dev, steps=20, warmup=3):
 
 
 def bf16x3_alt_measure(dev, iters=200):
-    """`roofline_alt` (optional part): the bf16x3 operand-split probe (csrc/gemm_bf16x3.hip: six bf16
+    """`roofline_alt` (optional part): the bf16x3 operand-split probe (tools/probes/gemm_bf16x3.hip, a library of its own: six bf16
     MFMAs with fp32 accumulation per product block) beside the exact fp32 MFMA kernel on the network's dominant forward
     shape, the Xception middle-flow pointwise GEMM at batch 32 (6144 x 728 x 728).  Never part of `value`: the product
     path stays the k-ordered fp32 chain.  Error of both kernels against float64 (torch.float64 on the device), relative
     to |a_row| * |w_col|."""
     import torch
     from spnet_amd import _lib as L
+    from tools.probes import probe_lib
+    PL = probe_lib.load()
     M, N, K = 6144, 728, 728
     g = torch.Generator(device=dev)
     g.manual_seed(3)
     a = torch.randn(M, K, device=dev, generator=g)
     w = torch.randn(K, N, device=dev, generator=g) * 0.05
-    Kp = int(L.spnet_bf16x3_kp(K))
+    Kp = int(PL.spnet_bf16x3_kp(K))
     planes = torch.zeros(3 * N * Kp, dtype=torch.int16, device=dev)
     c3, c1 = torch.empty(M, N, device=dev), torch.empty(M, N, device=dev)
     st = torch.cuda.current_stream().cuda_stream
-    split = lambda: L.spnet_split_bf16x3(w.data_ptr(), planes.data_ptr(), K, N, st)
-    f3 = lambda: L.spnet_gemm_bf16x3_fwd(a.data_ptr(), K, planes.data_ptr(), c3.data_ptr(), N, M, N, K, st)
+    split = lambda: PL.spnet_split_bf16x3(w.data_ptr(), planes.data_ptr(), K, N, st)
+    f3 = lambda: PL.spnet_gemm_bf16x3_fwd(a.data_ptr(), K, planes.data_ptr(), c3.data_ptr(), N, M, N, K, st)
     f1 = lambda: L.spnet_gemm_f32(a.data_ptr(), 0, K, w.data_ptr(), 1, N, c1.data_ptr(), N, M, N, K, 1, None, 0, None, 0, st)
 
     def t(fn):
@@ -463,20 +465,36 @@ def self_launch(n):
     (`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ...`), as a CHILD process
     -- this parent has not imported torch.cuda or touched the GPU, and never exec()s -- relay its output (rank 0
     prints the one JSON line) and exit with its return code (reference capability: spnet/multi_gpu.py:35-88,
-    train_spnet.py:55)."""
+    train_spnet.py:55).  Every rank's stderr is also kept in a log directory (`--tee 2`); when the job fails, the last 40
+    stderr lines of every rank that wrote any are repeated at the end, rank by rank, so that the tail of the driver's log
+    shows WHY (an RCCL / HIP message of one rank) and not only torchrun's summary of who died."""
+    import glob
     import socket
     import subprocess
+    import tempfile
     with socket.socket() as so:
         so.bind(("127.0.0.1", 0))
         port = so.getsockname()[1]
+    logdir = tempfile.mkdtemp(prefix="spnet_bench_ranks_")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
-           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+           "--master-addr", "127.0.0.1", "--master-port", str(port), "--log-dir", logdir, "--tee", "2",
+           os.path.abspath(__file__)] + sys.argv[1:]
     env = dict(os.environ)
+    # the pool's host driver supports dmabuf IPC only: without this RCCL's peer-to-peer setup fails with
+    # `hipIpcGetMemHandle: invalid argument` (it is exported on the GPU boxes already; kept for any other caller)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("NCCL_DEBUG", "WARN")         # a failed RCCL init / collective says why
     env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // n)))
     rc = subprocess.run(cmd, env=env).returncode
     if rc != 0:
         sys.stderr.write("bench.py: the %d-rank child job failed with exit code %d\n" % (n, rc))
+        for f in sorted(glob.glob(os.path.join(logdir, "**", "stderr.log"), recursive=True)):
+            try:
+                tail = open(f, errors="replace").read().splitlines()[-40:]
+            except OSError:
+                continue
+            if tail:
+                sys.stderr.write("---- last %d stderr lines of %s\n%s\n" % (len(tail), os.path.relpath(f, logdir), "\n".join(tail)))
     raise SystemExit(rc)
 
 
@@ -515,7 +533,23 @@ def main():
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         return self_launch(args.gpus)
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1:
+        os.environ.setdefault("NCCL_DEBUG", "WARN")      # (also under the driver's own launcher)
+        try:
+            return run(args)
+        except BaseException as e:      # noqa: BLE001  (re-raised: the launcher must see the failure)
+            if not isinstance(e, SystemExit) or e.code not in (0, None):
+                import traceback
+                sys.stderr.write("bench.py: rank %s of %s failed: %s: %s\n%s\n" % (
+                    os.environ.get("RANK", "?"), os.environ.get("WORLD_SIZE", "?"), type(e).__name__, e,
+                    "".join(traceback.format_exc().splitlines(True)[-12:])))
+                sys.stderr.flush()
+            raise
+    return run(args)
 
+
+def run(args):
+    """One rank of the benchmark (the only rank at N = 1)."""
     import torch
     import torch.distributed as dist
     from spnet_amd import fake_espi as F
@@ -534,11 +568,15 @@ def main():
             ones = torch.ones(1, device=parallel.local_device() if dist.get_backend() == "nccl" else "cpu")
             dist.all_reduce(ones)
             seen = int(round(float(ones.item())))
+        if os.environ.get("SPNET_BENCH_FAIL_RANK") == str(rank):      # test hook (tests/test_host_cpu.py)
+            raise RuntimeError("SPNET_BENCH_FAIL_RANK=%d: this rank fails on purpose" % rank)
+        backend = dist.get_backend() if world > 1 else None
+        if world > 1:
+            dist.barrier()          # (a rank that failed above never arrives: no result line from a failed job)
         if rank == 0:
             print(json.dumps({"launch_check": True, "n_gpus": world, "n_ranks_seen": seen,
-                              "collective_backend": dist.get_backend() if world > 1 else None}), flush=True)
+                              "collective_backend": backend}), flush=True)
         if world > 1:
-            dist.barrier()
             dist.destroy_process_group()
         return
     if args.mode == "predict" and (args.height, args.width) == (H, W) and args.batch in (BATCH, 128) \
@@ -770,7 +808,9 @@ def main():
             torch.cuda.empty_cache()
             result["predict"] = predict_measure(X_pool[:min(args.pool, 2048) // 128 * 128], dev, 10, 2)
             result["layout_331"] = layout_331_measure(dev)
-            result["roofline_alt"] = bf16x3_alt_measure(dev)
+            from tools.probes import probe_lib
+            if probe_lib.available():      # (the probe library is not part of the product: tools/probes/Makefile)
+                result["roofline_alt"] = bf16x3_alt_measure(dev)
             eng = aug = None
         if world == 1 and not args.no_cpu_baseline:
             del eng, aug, X_pool

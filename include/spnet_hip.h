@@ -41,14 +41,6 @@ int spnet_gemm_f32_accumulate(const float* A, int a_major, int lda, const float*
                               int ldc, int M, int N, int K, int tile, void* stream);
 
 /* ---- probe, not on the product path: fp32 GEMM on the bf16 matrix cores by operand splitting ------------------------- */
-/* x = h + m + l (three bf16, exact), a*b ~ six piece products (error ~ one fp32 rounding per product), six
- * v_mfma_f32_16x16x32_bf16 in place of eight fp32 MFMAs per 16x16x32 block.  Forward operand form only: A [M][K] fp32
- * (split while staged), W as the three K-major bf16 planes spnet_split_bf16x3 makes of a Keras pointwise kernel
- * [K][N] (3 * N * spnet_bf16x3_kp(K) bf16), C [M][N] fp32.  NOT the k-ordered fmaf chain of spnet_gemm_f32: bench.py
- * reports it as `roofline_alt` only (pointwise convolutions of the Xception middle flow; call site spnet/models.py:357-359). */
-long spnet_bf16x3_kp(int K);
-int spnet_split_bf16x3(const float* W, void* planes, int K, int N, void* stream);
-int spnet_gemm_bf16x3_fwd(const float* A, int lda, const void* planes, float* C, int ldc, int M, int N, int K, void* stream);
 /* Same contraction (no split-K, no bias) that also emits BatchNorm column statistics of C from the
  * accumulators: colstats[rows][2][N] per row-tile (sum, sum of squares), *stat_rows (HOST int) = rows.
  * colstats must hold ceil(M/32)*2*N floats. */
@@ -140,6 +132,19 @@ int spnet_dwconv3x3_tiled_bwd(const float* dy, const float* x_fwd, const float* 
                               int B, int H, int W, int C, int relu_in, const float* add, float* workspace,
                               const float* in_scale, const float* in_shift, const float* bn_mean,
                               const float* bn_invstd, float* bn_partial, const float* bn_x, void* stream);
+/* The same two operations as STREAMING kernels for planes large enough to be pure bandwidth (entry flow at batch 32,
+ * every plane of the batch-128 inference plan; call site spnet/models.py:357-359): a wave owns 8 columns x 32 channels
+ * and marches down its rows with its loads 3-4 rows ahead in registers; no LDS tile, no barrier, no row halo.
+ * rows_per_seg: rows per wave (<= 0: the library's choice); the backward's partial buffers have
+ * spnet_dwconv3x3_stream_rows() rows.  y and dx are bit-identical to the tiled kernels' (same fmaf order). */
+long spnet_dwconv3x3_stream_rows(int B, int H, int W, int C, int rows_per_seg);
+long spnet_dwconv3x3_stream_bwd_ws(int B, int H, int W, int C, int rows_per_seg);
+int spnet_dwconv3x3_stream_fwd(const float* x, const float* w, float* y, int B, int H, int W, int C, int relu_in,
+                               const float* in_scale, const float* in_shift, int rows_per_seg, void* stream);
+int spnet_dwconv3x3_stream_bwd(const float* dy, const float* x_fwd, const float* w, float* dx, float* dw, int B, int H,
+                               int W, int C, int relu_in, const float* add, float* workspace, const float* in_scale,
+                               const float* in_shift, const float* bn_mean, const float* bn_invstd, float* bn_partial,
+                               const float* bn_x, int rows_per_seg, void* stream);
 
 /* ---- BatchNormalization(axis=-1, momentum .99, eps 1e-3) (spnet/models.py:326-336 + 40 in Xception) --- */
 /* act: 0 none, 1 ReLU, 2 LeakyReLU(0.1), 3 ReLU6 (MobileNet) fused behind the affine; residual (or NULL) added last;
@@ -157,8 +162,10 @@ int spnet_bn_bwd(const float* x, const float* dy, long M, int C, const float* ga
                  const float* save_mean, const float* save_invstd, int act, float* dx, float* dgamma,
                  float* dbeta, float* coeffs, float* workspace, void* stream);
 /* Split forms for fused pipelines: statistics arrive as partial[P][2][C] from a GEMM epilogue
- * (spnet_gemm_f32_colstats) or from the fused depthwise backward. */
-int spnet_bn_finalize_fwd(const float* partial, int P, long M, int C, const float* gamma, const float* beta,
+ * (spnet_gemm_f32_colstats) or from the fused depthwise backward.  The three finalize entries CONSUME `partial` when
+ * P >= 1024: a first stage leaves 64 slice sums (hi, lo float pairs) in the buffer's own first rows, so the partial rows
+ * cannot be read again afterwards (a second consumer must take its copy first). */
+int spnet_bn_finalize_fwd(float* partial, int P, long M, int C, const float* gamma, const float* beta,
                           float* moving_mean, float* moving_var, float* save_mean, float* save_invstd,
                           float* scale_shift, float eps, float momentum, void* stream);
 int spnet_bn_infer_coeffs(int C, const float* gamma, const float* beta, const float* moving_mean,
@@ -167,14 +174,14 @@ int spnet_bn_apply(const float* x, long M, int C, const float* scale_shift, int 
                    int res_bcast, float* y, void* stream);
 /* spnet_bn_finalize_fwd + spnet_bn_apply (no broadcast residual) as ONE launch while P <= 128 partial rows -- the closing
  * BatchNormalization + Add of a keras Xception middle block in training (spnet/models.py:357-359); results identical. */
-int spnet_bn_finalize_apply(const float* partial, int P, const float* x, long M, int C, const float* gamma,
+int spnet_bn_finalize_apply(float* partial, int P, const float* x, long M, int C, const float* gamma,
                             const float* beta, float* moving_mean, float* moving_var, float* save_mean,
                             float* save_invstd, float* scale_shift, int act, const float* residual, float* y, float eps,
                             float momentum, void* stream);
 /* The `_ld` forms of the three forward entries write y with a row stride of ldy floats (>= C, multiples of 4): the output
  * is a column block of a wider tensor -- a conv2d_bn branch of keras InceptionResNetV2 written straight into the buffer
  * of its Concatenate (call site spnet/models.py:357-359), so that no copy pass follows. */
-int spnet_bn_finalize_apply_ld(const float* partial, int P, const float* x, long M, int C, const float* gamma,
+int spnet_bn_finalize_apply_ld(float* partial, int P, const float* x, long M, int C, const float* gamma,
                                const float* beta, float* moving_mean, float* moving_var, float* save_mean,
                                float* save_invstd, float* scale_shift, int act, const float* residual, float* y, long ldy,
                                float eps, float momentum, void* stream);
@@ -232,14 +239,7 @@ int spnet_patches(const float* in, float* out, int B, int H, int W, int C, int K
 /* The forward gather of an input whose pixels are ldx floats apart (a column block of a wider tensor). */
 int spnet_patches_ld(const float* in, long ldx, float* out, int B, int H, int W, int C, int KH, int KW, int stride, int same,
                      void* stream);
-/* The forward convolution itself as an implicit GEMM: A tiles gathered from x tap by tap (no patch matrix written or
- * read), same k order as spnet_patches + spnet_gemm_f32.  x [B][H][W][cin], w HWIO [KH][KW][cin][cout] -> y
- * [B][OH][OW][cout] (+ bias); cin % 16 == 0, cout % 4 == 0, KH*KW <= 32, stride 1 | 2.  colstats (or NULL): BatchNorm
- * column sums of y as [*stat_rows][2][cout] partial rows (64-row tiles), as spnet_gemm_f32_colstats leaves them. */
-int spnet_conv_fwd_implicit(const float* x, const float* w, float* y, int B, int H, int W, int cin, int cout, int KH,
-                            int KW, int stride, int same, const float* bias, float* colstats, int* stat_rows,
-                            void* stream);
-/* The same on the tuned GEMM kernel itself (gemm.hip, AG = 1): the A tile of K step (tap, 32 channels) is the plain
+/* The forward convolution itself on the tuned GEMM kernel (gemm.hip, AG = 1; no patch matrix written or read): the A tile of K step (tap, 32 channels) is the plain
  * K-major fetch from a shifted base with the out-of-image rows zeroed, in the pipeline slots of the matrix form -- no
  * patch matrix, no gather launch, the tile ids / autotuned table of spnet_gemm_f32.  x pixels ldx floats apart (ldx >= C:
  * a column block of a wider tensor), Wk = the HWIO kernel as [KH*KW*C][Cout], y [B*OH*OW][ldy]; C % 32 == 0, stride

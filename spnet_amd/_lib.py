@@ -27,9 +27,6 @@ P = c_void_p  # device pointers travel as integers
 _SIGS = {
     "spnet_gemm_f32": (c_int, [P, c_int, c_int, P, c_int, c_int, P, c_int, c_int, c_int, c_int, c_int, P, c_long, P, c_int, P]),
     "spnet_gemm_f32_accumulate": (c_int, [P, c_int, c_int, P, c_int, c_int, P, c_int, c_int, c_int, c_int, c_int, P]),
-    "spnet_bf16x3_kp": (c_long, [c_int]),
-    "spnet_split_bf16x3": (c_int, [P, P, c_int, c_int, P]),
-    "spnet_gemm_bf16x3_fwd": (c_int, [P, c_int, P, P, c_int, c_int, c_int, c_int, P]),
     "spnet_conv3x3_fwd": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, P]),
     "spnet_conv3x3_dgrad": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, P]),
     "spnet_conv3x3_wgrad_ws": (c_long, [c_int, c_int, c_int, c_int, c_int]),
@@ -49,6 +46,10 @@ _SIGS = {
     "spnet_dwconv3x3_tiled_bwd_ws": (c_long, [c_int, c_int, c_int, c_int]),
     "spnet_dwconv3x3_tiled_rows": (c_long, [c_int, c_int, c_int, c_int]),
     "spnet_dwconv3x3_tiled_bwd": (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, P, P, P, P, P, P, P, P, P]),
+    "spnet_dwconv3x3_stream_rows": (c_long, [c_int, c_int, c_int, c_int, c_int]),
+    "spnet_dwconv3x3_stream_bwd_ws": (c_long, [c_int, c_int, c_int, c_int, c_int]),
+    "spnet_dwconv3x3_stream_fwd": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, P, P, c_int, P]),
+    "spnet_dwconv3x3_stream_bwd": (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, P, P, P, P, P, P, P, P, c_int, P]),
     "spnet_bn_finalize_fwd": (c_int, [P, c_int, c_long, c_int, P, P, P, P, P, P, P, c_float, c_float, P]),
     "spnet_bn_infer_coeffs": (c_int, [c_int, P, P, P, P, P, c_float, P]),
     "spnet_bn_apply": (c_int, [P, c_long, c_int, P, c_int, P, c_int, P, P]),
@@ -79,7 +80,6 @@ _SIGS = {
     "spnet_patches": (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P]),
     "spnet_patches_ld": (c_int, [P, c_long, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P]),
     "spnet_conv_gemm_f32": (c_int, [P, c_long, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, c_int, P, P, P]),
-    "spnet_conv_fwd_implicit": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P, P, P]),
     "spnet_grad_bnsums_rows": (c_long, [c_long, c_int]),
     "spnet_patches_bwd_bnsums": (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P, P, P, c_int, P,
                                          c_int, P]),
@@ -137,6 +137,26 @@ def _bind(name, restype, argtypes):
 
 for _n, (_r, _a) in _SIGS.items():
     globals()[_n] = _bind(_n, _r, _a)
+
+
+def _public_stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _resolve_current_stream():
+    """Raw handle of the current HIP stream of the current device, for the `stream` argument of every entry point.
+    torch.cuda.current_stream().cuda_stream builds a Stream object per call (~2 us; a step is 330 ... 1,300 launches);
+    torch's private accessors return the same handle without it.  They are not public API and have moved between torch
+    releases, so they are resolved ONCE here and anything missing falls back to the public call
+    (tests/test_host_cpu.py checks the resolution; tests/test_engine_gpu.py that both return the same handle)."""
+    raw = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+    dev = getattr(torch._C, "_cuda_getDevice", None)
+    if raw is None or dev is None:
+        return _public_stream, "public"
+    return (lambda: raw(dev())), "raw"
+
+
+current_stream, STREAM_ACCESSOR = _resolve_current_stream()
 
 
 def ptr(t):

@@ -18,8 +18,7 @@ from . import _lib as L
 MAX_RECTS = 6
 
 
-def _stream():
-    return torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice())
+_stream = L.current_stream
 
 
 def cleanup_angle(angle):

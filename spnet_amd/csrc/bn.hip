@@ -794,7 +794,7 @@ extern "C" int spnet_bn_bwd(const float* x, const float* dy, long M, int C, cons
 // spnet_dwconv3x3_tiled_bwd backward) as partial[P][2][C]; these entries do only the remaining steps.
 
 // partial -> batch mean/invstd, scale_shift[2C], moving-stat update.  No pass over the activations.
-extern "C" int spnet_bn_finalize_fwd(const float* partial, int P, long M, int C, const float* gamma,
+extern "C" int spnet_bn_finalize_fwd(float* partial, int P, long M, int C, const float* gamma,
                                      const float* beta, float* moving_mean, float* moving_var,
                                      float* save_mean, float* save_invstd, float* scale_shift, float eps,
                                      float momentum, void* stream) {
@@ -802,7 +802,7 @@ extern "C" int spnet_bn_finalize_fwd(const float* partial, int P, long M, int C,
   if (P >= BN_SLICE_MIN_P) {     // `partial` is scratch of the caller: the slice sums are left in its own rows
     const int L = P / BN_SLICES, S = BN_SLICES;
     hipLaunchKernelGGL(bn_slice_partials_kernel, dim3(gx, S), dim3(256), 0, (hipStream_t)stream,
-                       const_cast<float*>(partial), P, C, L, S);
+                       partial, P, C, L, S);
     hipLaunchKernelGGL(bn_fwd_finalize_kernel, dim3(gx), dim3(256), 0, (hipStream_t)stream, partial, S, C, M, gamma,
                        beta, moving_mean, moving_var, save_mean, save_invstd, scale_shift, scale_shift + C, eps,
                        momentum, L);
@@ -833,7 +833,7 @@ extern "C" int spnet_bn_apply(const float* x, long M, int C, const float* scale_
 
 // spnet_bn_finalize_fwd + spnet_bn_apply in ONE launch where the statistics arrive as at most 128 partial rows (the
 // closing BatchNorm of an Xception middle block, whose output x + BN(.) is materialised); otherwise the two launches.
-extern "C" int spnet_bn_finalize_apply_ld(const float* partial, int P, const float* x, long M, int C, const float* gamma,
+extern "C" int spnet_bn_finalize_apply_ld(float* partial, int P, const float* x, long M, int C, const float* gamma,
                                           const float* beta, float* moving_mean, float* moving_var, float* save_mean,
                                           float* save_invstd, float* scale_shift, int act, const float* residual, float* y,
                                           long ldy, float eps, float momentum, void* stream) {
@@ -856,7 +856,7 @@ extern "C" int spnet_bn_finalize_apply_ld(const float* partial, int P, const flo
   launch_apply(x, M, C, scale_shift, scale_shift + C, act, residual, 0, y, st, ldy);
   SPNET_RETURN_LAUNCH_STATUS();
 }
-extern "C" int spnet_bn_finalize_apply(const float* partial, int P, const float* x, long M, int C, const float* gamma,
+extern "C" int spnet_bn_finalize_apply(float* partial, int P, const float* x, long M, int C, const float* gamma,
                                        const float* beta, float* moving_mean, float* moving_var, float* save_mean,
                                        float* save_invstd, float* scale_shift, int act, const float* residual, float* y,
                                        float eps, float momentum, void* stream) {

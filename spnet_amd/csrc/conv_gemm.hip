@@ -402,160 +402,3 @@ extern "C" int spnet_conv3x3_wgrad(const float* x, const float* dy, float* dw, i
                      workspace, B, H, W, H - 2, W - 2, p_chunk);
   return spnet_reduce_slabs(workspace, ns, 9 * cin, cout, dw, cout, stream);
 }
-
-// ================================================================================================
-// General k_h x k_w forward convolution as an implicit GEMM (keras InceptionResNetV2's 3x3, 5x5, 1x7, 7x1, 1x3, 3x1
-// convolutions, strides 1 | 2, 'same' | 'valid'; call site spnet/models.py:357-359): y[m, co] = sum_{tap, ci}
-// x[in(m) + tap, ci] * w[tap, ci, co] with M = B*OH*OW output pixels, N = COUT, K = KH*KW*CIN taken tap by tap in
-// K tiles of BK input channels (CIN % BK == 0; BK = 32, or 16 for the 48-, 80-, 160-, 224-, 288-channel layers).  The
-// A tile of K tile t is the input tensor shifted by that tile's tap -- one loop-invariant offset per staged row plus a
-// wave-uniform shift, with a validity bit per (row, tap) for the zero padding -- so no patch matrix is written or
-// read on the forward path.  Same tile machinery, same k order (tap-major, then channel) as the patch matrix GEMM:
-// the result is bit-identical to spnet_patches + spnet_gemm_f32 on the same tile shape.  Optional BatchNorm column
-// sums from the accumulators (training).
-// ================================================================================================
-template <int BM, int BN, int BK>
-__global__ __launch_bounds__(256, 2) void convkxk_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
-                                                             float* __restrict__ y, int Bn, int H, int W, int CIN, int COUT,
-                                                             int KH, int KW, int s, int pt, int pl, int OH, int OW,
-                                                             int tiles_m, int tiles_n, const float* __restrict__ bias,
-                                                             float* __restrict__ colstats) {
-  constexpr int WM = 2, WN = 2;
-  constexpr int TM = BM / WM / 16, TN = BN / WN / 16;
-  typedef TileStage<BM, BK, SP_K_MAJOR, TM> SA;
-  typedef TileStage<BN, BK, SP_OUT_MAJOR, TN> SB;
-  static_assert(SA::TOTAL % 256 == 0 || SA::TOTAL < 256, "A slots");
-  constexpr int STAGE = SA::SIZE + SB::SIZE;
-  constexpr int NCH = BK / 16;
-  __shared__ __attribute__((aligned(16))) float smem[2 * STAGE];
-
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave / WN, wn = wave % WN;
-  const long M = (long)Bn * OH * OW;
-  const int lid = xcd_remap(blockIdx.x, tiles_m * tiles_n);
-  const int tn = lid % tiles_n, tm = lid / tiles_n;
-  const int m0 = tm * BM, n0 = tn * BN;
-  const int kpt = CIN / BK;                          // K tiles per tap
-  const int ntap = KH * KW;
-  const int KT = ntap * kpt;
-
-  // loop-invariant part of the A gather: this thread's rows (output pixels), their window origin and tap validity
-  int abase[SA::NV];
-  unsigned amask[SA::NV];
-  unsigned aslot = 0;                                // slots that exist (TOTAL < 256: the upper threads idle)
-  const int kq = tid % (BK / 4);
-#pragma unroll
-  for (int i = 0; i < SA::NV; ++i) {
-    const int f = tid + i * 256;
-    const int r = f / (BK / 4);
-    long m = (long)m0 + r;
-    if (m > M - 1) m = M - 1;                        // clamped rows only feed output rows >= M (never stored)
-    const int ow = (int)(m % OW);
-    const long q = m / OW;
-    const int oh = (int)(q % OH);
-    const int b = (int)(q / OH);
-    const int ih0 = oh * s - pt, iw0 = ow * s - pl;
-    abase[i] = (int)((((long)b * H + ih0) * W + iw0) * CIN) + kq * 4;
-    unsigned mk = 0;
-    for (int tap = 0; tap < ntap; ++tap) {
-      const int ih = ih0 + tap / KW, iw = iw0 + tap % KW;
-      if (ih >= 0 && ih < H && iw >= 0 && iw < W) mk |= 1u << tap;
-    }
-    amask[i] = (SA::TOTAL % 256 == 0 || f < SA::TOTAL) ? mk : 0u;
-  }
-  int boff[SB::NV];
-  unsigned bmask = 0;
-#pragma unroll
-  for (int i = 0; i < SB::NV; ++i) {
-    const int f = tid + i * 256;
-    const int k = f / (BN / 4), c = n0 + (f % (BN / 4)) * 4;
-    const bool ok = (SB::TOTAL % 256 == 0 || f < SB::TOTAL) && c < COUT;
-    boff[i] = k * COUT + (ok ? c : 0);
-    bmask |= (ok ? 1u : 0u) << i;
-  }
-
-  SA sa0, sa1;
-  SB sb0, sb1;
-#define KF_FETCH(SA_, SB_, T_)                                                                              \
-  do {                                                                                                      \
-    const int tap_ = (T_) / kpt, part_ = (T_) - tap_ * kpt;     /* wave-uniform */                          \
-    const int shift_ = ((tap_ / KW) * W + tap_ % KW) * CIN + part_ * BK;                                    \
-    SA_.load_gather(x, abase, shift_, tap_ok(amask, tap_));                                                 \
-    SB_.load_gather(w + ((long)tap_ * CIN + part_ * BK) * COUT, boff, 0, bmask);                            \
-  } while (0)
-#define KF_STEP(CUR_, SA_LD, SB_LD, SA_ST, SB_ST, T_)                                                       \
-  do {                                                                                                      \
-    if ((T_) + 2 < KT) KF_FETCH(SA_LD, SB_LD, (T_) + 2);                                                    \
-    if ((T_) + 1 < KT)                                                                                      \
-      mma_tile_store<SA, SB, TM, TN, NCH, true>(smem + (CUR_) * STAGE, wm * (TM * 16), wn * (TN * 16), lane, acc, SA_ST, \
-                                                SB_ST, smem + (1 - (CUR_)) * STAGE, tid);                  \
-    else                                                                                                    \
-      mma_tile_store<SA, SB, TM, TN, NCH, false>(smem + (CUR_) * STAGE, wm * (TM * 16), wn * (TN * 16), lane, acc, SA_ST, \
-                                                 SB_ST, smem + (1 - (CUR_)) * STAGE, tid);                 \
-    __syncthreads();                                                                                        \
-  } while (0)
-
-  f32x4 acc[TM][TN];
-#pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int j = 0; j < TN; ++j)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) acc[i][j][r] = 0.f;
-
-  KF_FETCH(sa0, sb0, 0);
-  if (KT > 1) KF_FETCH(sa1, sb1, 1);
-  sa0.store(smem, tid);
-  sb0.store(smem + SA::SIZE, tid);
-  __syncthreads();
-  for (int t = 0; t < KT; t += 2) {
-    KF_STEP(0, sa0, sb0, sa1, sb1, t);
-    if (t + 1 < KT) KF_STEP(1, sa1, sb1, sa0, sb0, t + 1);
-  }
-#undef KF_STEP
-#undef KF_FETCH
-
-  gemm_epilogue<SA, SB, BM, BN, WM, WN, TM, TN>(acc, smem, y, COUT, (int)M, COUT, m0, n0, tm, 0, 0, bias, colstats, tid,
-                                                lane, wm, wn);
-}
-
-static void convk_geom(int in, int k, int s, int same, int* out, int* before) {
-  if (same) {
-    *out = (in + s - 1) / s;
-    int total = (*out - 1) * s + k - in;
-    if (total < 0) total = 0;
-    *before = total / 2;
-  } else {
-    *out = (in - k) / s + 1;
-    *before = 0;
-  }
-}
-
-// x [B][H][W][cin], w HWIO [KH][KW][cin][cout] -> y [B][OH][OW][cout] (+ bias).  cin % 16 == 0, cout % 4 == 0,
-// KH * KW <= 32.  colstats (or NULL): BatchNorm column sums of y, [*stat_rows][2][cout] (64-row tiles).
-extern "C" int spnet_conv_fwd_implicit(const float* x, const float* w, float* y, int B, int H, int W, int cin, int cout,
-                                       int KH, int KW, int stride, int same, const float* bias, float* colstats,
-                                       int* stat_rows, void* stream) {
-  if ((cin & 15) || (cout & 3) || KH < 1 || KW < 1 || KH * KW > 32 || (stride != 1 && stride != 2) || B < 1)
-    return (int)hipErrorInvalidValue;
-  if (((uintptr_t)x | (uintptr_t)w | (uintptr_t)y) & 15) return (int)hipErrorInvalidValue;
-  if (colstats && !stat_rows) return (int)hipErrorInvalidValue;
-  int OH, OW, pt, pl;
-  convk_geom(H, KH, stride, same, &OH, &pt);
-  convk_geom(W, KW, stride, same, &OW, &pl);
-  if (OH < 1 || OW < 1) return (int)hipErrorInvalidValue;
-  if ((long)B * (H + KH) * (W + KW) * cin >= (1L << 31)) return (int)hipErrorInvalidValue;      // 32-bit element offsets
-  const long M = (long)B * OH * OW;
-  const int tm = (int)((M + 63) / 64), tn = (cout + 63) / 64;
-  if (stat_rows) *stat_rows = tm;
-  dim3 grid((unsigned)(tm * tn)), block(256);
-  if (cin % 32 == 0)
-    hipLaunchKernelGGL((convkxk_fwd_kernel<64, 64, 32>), grid, block, 0, (hipStream_t)stream, x, w, y, B, H, W, cin, cout, KH,
-                       KW, stride, pt, pl, OH, OW, tm, tn, bias, colstats);
-  else
-    hipLaunchKernelGGL((convkxk_fwd_kernel<64, 64, 16>), grid, block, 0, (hipStream_t)stream, x, w, y, B, H, W, cin, cout, KH,
-                       KW, stride, pt, pl, OH, OW, tm, tn, bias, colstats);
-  SPNET_RETURN_LAUNCH_STATUS();
-}

@@ -362,6 +362,274 @@ __global__ __launch_bounds__(256) void dw3x3_tile_bwd_kernel(
 }
 
 // ================================================================================================
+// Streaming depthwise kernels (round 4): for planes that are large enough to be pure bandwidth (the entry flow at batch
+// 32, every plane of the batch-128 inference plan) the tile kernels above leave one load -> barrier -> compute -> store
+// chain per workgroup with nothing in flight behind it and re-read a 2-row halo per 12-row tile.  Here a WAVE is the
+// unit and nothing is shared: it owns SW = 64/CL columns x CL channel quads (CL x 16 contiguous bytes per pixel) and
+// MARCHES DOWN its rows.  Each lane fetches only its own column -- PD rows ahead, in a register ring, so PD (+PD edge)
+// loads are in flight per lane at any time -- the left / right neighbours come from the adjacent lanes (ds_bpermute: no
+// LDS memory, no barrier), and the two columns just outside the wave's strip from one extra, 2 x CL-lane load per row.
+// Three running rows of partial sums turn every input row into one output row: no tile, no H halo (except at the row
+// segments the host cuts long planes into to fill the chip), the same fmaf order as the tile kernels (bit-identical).
+// ================================================================================================
+__device__ __forceinline__ float4 f4_shfl_up(const float4 v, int d) {
+  return make_float4(__shfl_up(v.x, d, 64), __shfl_up(v.y, d, 64), __shfl_up(v.z, d, 64), __shfl_up(v.w, d, 64));
+}
+__device__ __forceinline__ float4 f4_shfl_down(const float4 v, int d) {
+  return make_float4(__shfl_down(v.x, d, 64), __shfl_down(v.y, d, 64), __shfl_down(v.z, d, 64), __shfl_down(v.w, d, 64));
+}
+__device__ __forceinline__ float4 f4_affine(const float4 v, const float4 sc, const float4 sh) {
+  return make_float4(fmaf(v.x, sc.x, sh.x), fmaf(v.y, sc.y, sh.y), fmaf(v.z, sc.z, sh.z), fmaf(v.w, sc.w, sh.w));
+}
+__device__ __forceinline__ float4 f4_mul(const float4 x, const float4 w) {
+  return make_float4(x.x * w.x, x.y * w.y, x.z * w.z, x.w * w.w);
+}
+
+// wave id -> (batch, row segment, column strip, channel chunk), channel chunk fastest: the four waves of a workgroup
+// read 4 x CL x 16 contiguous bytes per pixel where the plane has that many channels
+struct DwStreamGeom { int strips, cchunks, segs, rows_per_seg; long waves; };
+
+template <int CL, int PD>
+__global__ __launch_bounds__(256) void dw3x3_stream_fwd_kernel(const float* __restrict__ in, const float* __restrict__ wt,
+                                                               float* __restrict__ out, int H, int W, int C, int relu_in,
+                                                               const float* __restrict__ in_scale,
+                                                               const float* __restrict__ in_shift, DwStreamGeom g) {
+  constexpr int SW = 64 / CL;
+  const int lane = threadIdx.x & 63;
+  long gw = (long)xcd_remap(blockIdx.x, gridDim.x) * 4 + (threadIdx.x >> 6);
+  if (gw >= g.waves) return;                          // whole wave
+  const int cc = (int)(gw % g.cchunks); gw /= g.cchunks;
+  const int strip = (int)(gw % g.strips); gw /= g.strips;
+  const int seg = (int)(gw % g.segs);
+  const int b = (int)(gw / g.segs);
+  const int l = lane % CL, col = lane / CL;
+  const int c4 = cc * CL + l, w = strip * SW + col;
+  const bool chan_ok = c4 * 4 < C;
+  const bool own_ok = chan_ok && w < W;
+  // the one column outside the strip this lane fetches: the left one (lanes of column 0), the right one (column SW-1)
+  const int we = col == 0 ? w - 1 : w + 1;
+  const bool edge_lane = col == 0 || col == SW - 1;
+  const bool edge_ok = chan_ok && edge_lane && we >= 0 && we < W;
+  const int h_lo = seg * g.rows_per_seg;
+  const int h_hi = min(H, h_lo + g.rows_per_seg);     // output rows [h_lo, h_hi)
+  const long rstride = (long)W * C;
+  const float* po = in + (long)b * H * rstride + (long)w * C + c4 * 4;      // + row * rstride
+  const float* pe = in + (long)b * H * rstride + (long)we * C + c4 * 4;
+  float* pout = out + (long)b * H * rstride + (long)w * C + c4 * 4;
+  const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  float4 k[9];
+#pragma unroll
+  for (int tp = 0; tp < 9; ++tp) k[tp] = chan_ok ? *reinterpret_cast<const float4*>(wt + (long)tp * C + c4 * 4) : zero4;
+  const bool affine = in_scale != nullptr;
+  float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = zero4;
+  if (affine && chan_ok) {
+    sc = *reinterpret_cast<const float4*>(in_scale + c4 * 4);
+    sh = *reinterpret_cast<const float4*>(in_shift + c4 * 4);
+  }
+  // input rows r_first .. r_last (clipped to the image: rows outside contribute zeros = SAME padding)
+  const int r_first = h_lo - 1, r_last = h_hi;        // inclusive; r_last may be H (outside)
+  float4 ring[PD], ering[PD];
+#pragma unroll
+  for (int d = 0; d < PD; ++d) {
+    const int r = r_first + d;
+    const bool rv = r >= 0 && r < H && r <= r_last;
+    ring[d] = (rv && own_ok) ? *reinterpret_cast<const float4*>(po + (long)r * rstride) : zero4;
+    ering[d] = (rv && edge_ok) ? *reinterpret_cast<const float4*>(pe + (long)r * rstride) : zero4;
+  }
+  float4 a_prev = zero4, a_cur = zero4;
+  for (int r0 = r_first; r0 <= r_last; r0 += PD) {
+#pragma unroll
+    for (int d = 0; d < PD; ++d) {
+      const int r = r0 + d;
+      if (r > r_last) break;                          // wave-uniform
+      float4 v1 = ring[d], e = ering[d];
+      {                                               // refill the slot with the row PD ahead
+        const int rn = r + PD;
+        const bool rv = rn < H && rn <= r_last;       // (rn >= 0 always: r >= -1, PD >= 1)
+        ring[d] = (rv && own_ok) ? *reinterpret_cast<const float4*>(po + (long)rn * rstride) : zero4;
+        ering[d] = (rv && edge_ok) ? *reinterpret_cast<const float4*>(pe + (long)rn * rstride) : zero4;
+      }
+      const bool rin = r >= 0 && r < H;
+      // zero padding must stay zero: the affine / relu only apply to pixels inside the image
+      if (affine) {
+        v1 = (rin && own_ok) ? f4_affine(v1, sc, sh) : zero4;
+        e = (rin && edge_ok) ? f4_affine(e, sc, sh) : zero4;
+      }
+      if (relu_in) { v1 = f4_relu(v1); e = f4_relu(e); }
+      float4 v0 = f4_shfl_up(v1, CL), v2 = f4_shfl_down(v1, CL);
+      if (col == 0) v0 = e;
+      if (col == SW - 1) v2 = e;
+      // output row t = sum_kh in[t+kh-1] . k[kh]; input row r feeds t = r+1 (kh 0), r (kh 1), r-1 (kh 2)
+      f4_fma(a_prev, v0, k[6]); f4_fma(a_prev, v1, k[7]); f4_fma(a_prev, v2, k[8]);
+      f4_fma(a_cur, v0, k[3]); f4_fma(a_cur, v1, k[4]); f4_fma(a_cur, v2, k[5]);
+      float4 a_next = f4_mul(v0, k[0]);
+      f4_fma(a_next, v1, k[1]); f4_fma(a_next, v2, k[2]);
+      const int t = r - 1;                            // completed output row
+      if (t >= h_lo && t < h_hi && own_ok) *reinterpret_cast<float4*>(pout + (long)t * rstride) = a_prev;
+      a_prev = a_cur;
+      a_cur = a_next;
+    }
+  }
+}
+
+// Streaming fused backward (same outputs as dw3x3_tile_bwd_kernel: dx, per-"row" weight-gradient partial sums, the
+// producer BatchNorm's two backward sums).  The wave marches down its strip with a 3-row window of dz (own column from
+// the register ring, neighbours from the adjacent lanes, the two outside columns from the edge load); x, the
+// residual-branch gradient `add` and bn_x are only needed at the centre pixel: own-column rings, PD rows ahead.  The 9 tap
+// sums and the 2 BatchNorm sums stay in registers for the whole march and are folded over the wave's SW columns by a
+// butterfly at the end (fixed order): ONE partial row per (batch, row segment, column strip), written by the waves of
+// its channel chunks.  dx has the tile kernel's fmaf order (bit-identical); the partial sums group differently.
+template <int CL, int PD, bool ADD, bool BNX>
+__global__ __launch_bounds__(256) void dw3x3_stream_bwd_kernel(
+    const float* __restrict__ dz, const float* __restrict__ x, const float* __restrict__ wt, float* __restrict__ dx,
+    float* __restrict__ partial, const float* __restrict__ add, int H, int W, int C, int relu_in,
+    const float* __restrict__ in_scale, const float* __restrict__ in_shift, const float* __restrict__ bn_mean,
+    const float* __restrict__ bn_invstd, float* __restrict__ bn_partial, const float* __restrict__ bn_x, DwStreamGeom g) {
+  constexpr int SW = 64 / CL;
+  const int lane = threadIdx.x & 63;
+  long gw = (long)xcd_remap(blockIdx.x, gridDim.x) * 4 + (threadIdx.x >> 6);
+  if (gw >= g.waves) return;                          // whole wave
+  const int cc = (int)(gw % g.cchunks); gw /= g.cchunks;
+  const long sp = gw;                                 // partial row: (batch, segment, strip)
+  const int strip = (int)(gw % g.strips); gw /= g.strips;
+  const int seg = (int)(gw % g.segs);
+  const int b = (int)(gw / g.segs);
+  const int l = lane % CL, col = lane / CL;
+  const int c4 = cc * CL + l, w = strip * SW + col;
+  const bool chan_ok = c4 * 4 < C;
+  const bool own_ok = chan_ok && w < W;
+  const int we = col == 0 ? w - 1 : w + 1;
+  const bool edge_lane = col == 0 || col == SW - 1;
+  const bool edge_ok = chan_ok && edge_lane && we >= 0 && we < W;
+  const int h_lo = seg * g.rows_per_seg;
+  const int h_hi = min(H, h_lo + g.rows_per_seg);     // output rows [h_lo, h_hi)
+  const long rstride = (long)W * C;
+  const long obase = (long)b * H * rstride + (long)w * C + c4 * 4;          // own column, + row * rstride
+  const float* pz = dz + obase;
+  const float* pze = dz + (long)b * H * rstride + (long)we * C + c4 * 4;
+  const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  float4 k[9], accw[9];
+#pragma unroll
+  for (int tp = 0; tp < 9; ++tp) {
+    k[tp] = chan_ok ? *reinterpret_cast<const float4*>(wt + (long)tp * C + c4 * 4) : zero4;
+    accw[tp] = zero4;
+  }
+  float4 bsg = zero4, bsgx = zero4;
+  const bool affine = in_scale != nullptr;
+  float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = zero4, mu = zero4, is = zero4;
+  if (affine && chan_ok) {
+    sc = *reinterpret_cast<const float4*>(in_scale + c4 * 4);
+    sh = *reinterpret_cast<const float4*>(in_shift + c4 * 4);
+  }
+  if (bn_partial && chan_ok) {
+    mu = *reinterpret_cast<const float4*>(bn_mean + c4 * 4);
+    is = *reinterpret_cast<const float4*>(bn_invstd + c4 * 4);
+  }
+  // dz rows r_first .. r_last feed output rows h_lo .. h_hi-1 (row r completes output row r-1); the centre tensors of
+  // output row t travel in slot (t - h_lo) % PD, fetched when dz row t+1-PD ... i.e. PD output rows ahead
+  const int r_first = h_lo - 1, r_last = h_hi;
+  float4 zr[PD], ze[PD], xr[PD], ar[PD], br[PD];
+#pragma unroll
+  for (int d = 0; d < PD; ++d) {
+    const int r = r_first + d;
+    const bool rv = r >= 0 && r < H && r <= r_last;
+    zr[d] = (rv && own_ok) ? *reinterpret_cast<const float4*>(pz + (long)r * rstride) : zero4;
+    ze[d] = (rv && edge_ok) ? *reinterpret_cast<const float4*>(pze + (long)r * rstride) : zero4;
+    const int t = h_lo + d;                           // centre tensors: output rows h_lo .. h_lo+PD-1
+    const bool tv = t < h_hi && own_ok;
+    xr[d] = tv ? *reinterpret_cast<const float4*>(x + obase + (long)t * rstride) : zero4;
+    if (ADD) ar[d] = tv ? *reinterpret_cast<const float4*>(add + obase + (long)t * rstride) : zero4;
+    if (BNX) br[d] = tv ? *reinterpret_cast<const float4*>(bn_x + obase + (long)t * rstride) : zero4;
+  }
+  float4 m0 = zero4, m1 = zero4, m2 = zero4, c0 = zero4, c1 = zero4, c2 = zero4;
+  // slot bookkeeping: dz row r sits in slot (r - r_first) % PD, output row t in slot (t - h_lo) % PD; row r completes
+  // t = r - 1 = h_lo + (r - r_first) - 2, i.e. centre slot (d + PD - 2 % PD) % PD when r is in dz slot d: static per d
+  for (int r0 = r_first; r0 <= r_last; r0 += PD) {
+#pragma unroll
+    for (int d = 0; d < PD; ++d) {
+      const int r = r0 + d;
+      if (r > r_last) break;                          // wave-uniform
+      const float4 n1 = zr[d];
+      const float4 e = ze[d];
+      {
+        const int rn = r + PD;
+        const bool rv = rn < H && rn <= r_last;
+        zr[d] = (rv && own_ok) ? *reinterpret_cast<const float4*>(pz + (long)rn * rstride) : zero4;
+        ze[d] = (rv && edge_ok) ? *reinterpret_cast<const float4*>(pze + (long)rn * rstride) : zero4;
+      }
+      float4 n0 = f4_shfl_up(n1, CL), n2 = f4_shfl_down(n1, CL);
+      if (col == 0) n0 = e;
+      if (col == SW - 1) n2 = e;
+      const int t = r - 1;
+      if (t >= h_lo) {                                // wave-uniform; t < h_hi holds since r <= r_last = h_hi
+        constexpr int PDm = PD;
+        const int cs = (d + 2 * PDm - 2) % PDm;       // centre slot of output row t (see above)
+        const float4 raw = xr[cs];
+        float4 ad = zero4, pre = raw;
+        if (ADD) ad = ar[cs];
+        if (BNX) pre = br[cs];
+        {
+          const int tn = t + PD;
+          const bool tv = tn < h_hi && own_ok;
+          xr[cs] = tv ? *reinterpret_cast<const float4*>(x + obase + (long)tn * rstride) : zero4;
+          if (ADD) ar[cs] = tv ? *reinterpret_cast<const float4*>(add + obase + (long)tn * rstride) : zero4;
+          if (BNX) br[cs] = tv ? *reinterpret_cast<const float4*>(bn_x + obase + (long)tn * rstride) : zero4;
+        }
+        float4 a = raw;
+        if (affine) a = f4_affine(raw, sc, sh);
+        const float4 xin = relu_in ? f4_relu(a) : a;
+        // dz[q-d]: kh = 0 -> next row (n*), 1 -> centre (c*), 2 -> previous (m*); kw = 0 -> right (index 2), 2 -> left (0)
+        float4 res = f4_mul(n2, k[0]);
+        f4_fma(res, n1, k[1]); f4_fma(res, n0, k[2]);
+        f4_fma(res, c2, k[3]); f4_fma(res, c1, k[4]); f4_fma(res, c0, k[5]);
+        f4_fma(res, m2, k[6]); f4_fma(res, m1, k[7]); f4_fma(res, m0, k[8]);
+        if (own_ok) {                                 // (lanes outside the image / the channel range hold zeros: skip)
+          f4_fma(accw[0], xin, n2); f4_fma(accw[1], xin, n1); f4_fma(accw[2], xin, n0);
+          f4_fma(accw[3], xin, c2); f4_fma(accw[4], xin, c1); f4_fma(accw[5], xin, c0);
+          f4_fma(accw[6], xin, m2); f4_fma(accw[7], xin, m1); f4_fma(accw[8], xin, m0);
+          if (relu_in) {
+            res.x = a.x > 0.f ? res.x : 0.f; res.y = a.y > 0.f ? res.y : 0.f;
+            res.z = a.z > 0.f ? res.z : 0.f; res.w = a.w > 0.f ? res.w : 0.f;
+          }
+          if (ADD) { res.x += ad.x; res.y += ad.y; res.z += ad.z; res.w += ad.w; }
+          *reinterpret_cast<float4*>(dx + obase + (long)t * rstride) = res;
+          if (bn_partial) {   // res = dL/d(BN output of the producer); xhat from the pre-BN value
+            bsg.x += res.x; bsg.y += res.y; bsg.z += res.z; bsg.w += res.w;
+            bsgx.x = fmaf(res.x, (pre.x - mu.x) * is.x, bsgx.x);
+            bsgx.y = fmaf(res.y, (pre.y - mu.y) * is.y, bsgx.y);
+            bsgx.z = fmaf(res.z, (pre.z - mu.z) * is.z, bsgx.z);
+            bsgx.w = fmaf(res.w, (pre.w - mu.w) * is.w, bsgx.w);
+          }
+        }
+      }
+      m0 = c0; m1 = c1; m2 = c2;
+      c0 = n0; c1 = n1; c2 = n2;
+    }
+  }
+  // fold the 9 + 2 sums over the SW columns of the wave (butterfly over the column bits of the lane id: fixed order)
+#pragma unroll
+  for (int off = CL; off < 64; off <<= 1) {
+#pragma unroll
+    for (int tp = 0; tp < 9; ++tp) {
+      accw[tp].x += __shfl_xor(accw[tp].x, off, 64); accw[tp].y += __shfl_xor(accw[tp].y, off, 64);
+      accw[tp].z += __shfl_xor(accw[tp].z, off, 64); accw[tp].w += __shfl_xor(accw[tp].w, off, 64);
+    }
+    bsg.x += __shfl_xor(bsg.x, off, 64); bsg.y += __shfl_xor(bsg.y, off, 64);
+    bsg.z += __shfl_xor(bsg.z, off, 64); bsg.w += __shfl_xor(bsg.w, off, 64);
+    bsgx.x += __shfl_xor(bsgx.x, off, 64); bsgx.y += __shfl_xor(bsgx.y, off, 64);
+    bsgx.z += __shfl_xor(bsgx.z, off, 64); bsgx.w += __shfl_xor(bsgx.w, off, 64);
+  }
+  if (col == 0 && chan_ok) {
+#pragma unroll
+    for (int tp = 0; tp < 9; ++tp) *reinterpret_cast<float4*>(partial + (sp * 9 + tp) * C + c4 * 4) = accw[tp];
+    if (bn_partial) {
+      *reinterpret_cast<float4*>(bn_partial + (sp * 2 + 0) * C + c4 * 4) = bsg;
+      *reinterpret_cast<float4*>(bn_partial + (sp * 2 + 1) * C + c4 * 4) = bsgx;
+    }
+  }
+}
+
+// ================================================================================================
 // Strided depthwise 3x3 / SAME (keras.applications.mobilenet: DepthwiseConv2D((3,3), padding='same', strides=(2,2)),
 // call site spnet/models.py:346-355).  TF SAME: out = ceil(in/s), pad_total = max((out-1)*s + 3 - in, 0), floor(half)
 // before.  One thread per (pixel, channel quad); these layers are a small share of a MobileNet step, so the plain
@@ -688,6 +956,77 @@ extern "C" int spnet_dwconv3x3_tiled_fwd_bnfin(const float* x, const float* w, f
   fin.rows = rows; fin.M = M;
   fin.eps = eps; fin.momentum = momentum;
   return dw_tiled_fwd(x, w, y, B, H, W, C, relu_in, nullptr, nullptr, fin, stream);
+}
+
+// ---------------------------------------------------------------- streaming entry points
+constexpr int DWS_CL = 8, DWS_SW = 64 / DWS_CL, DWS_PD_FWD = 4, DWS_PD_BWD = 3;
+
+// rows_per_seg <= 0: the library's choice -- whole columns unless the plane then gives fewer than ~16 waves per CU, in
+// which case the rows are cut into segments (2 halo rows re-read per segment) of at least 8 rows
+static DwStreamGeom dw_stream_geom(int B, int H, int W, int C, int rows_per_seg) {
+  DwStreamGeom g;
+  g.strips = (W + DWS_SW - 1) / DWS_SW;
+  g.cchunks = (C / 4 + DWS_CL - 1) / DWS_CL;
+  const long base = (long)B * g.strips * g.cchunks;
+  if (rows_per_seg <= 0) {
+    long segs = (4096 + base - 1) / base;
+    if (segs < 1) segs = 1;
+    rows_per_seg = (int)((H + segs - 1) / segs);
+    if (rows_per_seg < 8) rows_per_seg = 8;
+  }
+  if (rows_per_seg > H) rows_per_seg = H;
+  g.rows_per_seg = rows_per_seg;
+  g.segs = (H + rows_per_seg - 1) / rows_per_seg;
+  g.waves = base * g.segs;
+  return g;
+}
+
+// rows of the [rows][9][C] weight-gradient / [rows][2][C] BatchNorm partial buffers the streaming backward leaves
+extern "C" long spnet_dwconv3x3_stream_rows(int B, int H, int W, int C, int rows_per_seg) {
+  const DwStreamGeom g = dw_stream_geom(B, H, W, C, rows_per_seg);
+  return (long)B * g.segs * g.strips;
+}
+
+extern "C" long spnet_dwconv3x3_stream_bwd_ws(int B, int H, int W, int C, int rows_per_seg) {
+  return (spnet_dwconv3x3_stream_rows(B, H, W, C, rows_per_seg) + 32) * 9 * C;      // partial rows + 32 second-level slices
+}
+
+// y = dw3x3(relu?(x * in_scale + in_shift)), the arithmetic (and bits) of spnet_dwconv3x3_tiled_fwd
+extern "C" int spnet_dwconv3x3_stream_fwd(const float* x, const float* w, float* y, int B, int H, int W, int C,
+                                          int relu_in, const float* in_scale, const float* in_shift, int rows_per_seg,
+                                          void* stream) {
+  if ((C & 3) || B < 1 || H < 1 || W < 1) return (int)hipErrorInvalidValue;
+  const DwStreamGeom g = dw_stream_geom(B, H, W, C, rows_per_seg);
+  if ((g.waves + 3) / 4 > 0x7fffffffL) return (int)hipErrorInvalidValue;
+  hipLaunchKernelGGL((dw3x3_stream_fwd_kernel<DWS_CL, DWS_PD_FWD>), dim3((unsigned)((g.waves + 3) / 4)), dim3(256), 0,
+                     (hipStream_t)stream, x, w, y, H, W, C, relu_in, in_scale, in_shift, g);
+  SPNET_RETURN_LAUNCH_STATUS();
+}
+
+// The fused backward of spnet_dwconv3x3_tiled_bwd in streaming form: same arguments and outputs; the partial buffers
+// have spnet_dwconv3x3_stream_rows(B,H,W,C,rows_per_seg) rows, workspace spnet_dwconv3x3_stream_bwd_ws floats.
+extern "C" int spnet_dwconv3x3_stream_bwd(const float* dy, const float* x_fwd, const float* w, float* dx, float* dw, int B,
+                                          int H, int W, int C, int relu_in, const float* add, float* workspace,
+                                          const float* in_scale, const float* in_shift, const float* bn_mean,
+                                          const float* bn_invstd, float* bn_partial, const float* bn_x, int rows_per_seg,
+                                          void* stream) {
+  if (bn_partial && (!bn_mean || !bn_invstd)) return (int)hipErrorInvalidValue;
+  if (bn_x && !bn_partial) return (int)hipErrorInvalidValue;
+  if ((C & 3) || B < 1 || H < 1 || W < 1 || !workspace) return (int)hipErrorInvalidValue;
+  const DwStreamGeom g = dw_stream_geom(B, H, W, C, rows_per_seg);
+  if ((g.waves + 3) / 4 > 0x7fffffffL) return (int)hipErrorInvalidValue;
+#define DWS_BWD(ADD, BNX)                                                                                              \
+  hipLaunchKernelGGL((dw3x3_stream_bwd_kernel<DWS_CL, DWS_PD_BWD, ADD, BNX>), dim3((unsigned)((g.waves + 3) / 4)),     \
+                     dim3(256), 0, (hipStream_t)stream, dy, x_fwd, w, dx, workspace, add, H, W, C, relu_in, in_scale,  \
+                     in_shift, bn_mean, bn_invstd, bn_partial, bn_x, g)
+  if (add && bn_x) DWS_BWD(true, true);
+  else if (add) DWS_BWD(true, false);
+  else if (bn_x) DWS_BWD(false, true);
+  else DWS_BWD(false, false);
+#undef DWS_BWD
+  const int P = (int)((long)B * g.segs * g.strips), L = 9 * C;
+  if (dw) launch_reduce_rows(workspace, P, L, dw, workspace + (long)P * L, (hipStream_t)stream);
+  SPNET_RETURN_LAUNCH_STATUS();
 }
 
 extern "C" long spnet_dwconv3x3_tiled_rows(int B, int H, int W, int C) {

@@ -43,61 +43,7 @@
 // tile t % tiles_n, so the extra stores are spread evenly over the workgroups that stage that row tile.
 // (blended kernels of the small tiles are held to 3 workgroups per CU like their plain counterparts: the middle
 // flow's 768-workgroup launches are exactly one resident wave of 3 per CU)
-#ifdef SP_STAMPS
-// Diagnostic build only (tools/gemm_phases.py): per-workgroup 100 MHz real-time stamps of the kernel's phases, written
-// to a buffer nothing else reads.  [workgroup][8]: 0 entry, 1 first tile in LDS, 2 main loop done, 3 epilogue issued, 4 stores
-// drained (real-time ticks); 5, 6 the shader clock counter at stamps 1 and 2; 7 the XCC id the workgroup ran on.
-__device__ unsigned long long sp_stamps[16384 * 8];
-#define SP_STAMP(i) do { if (tid == 0 && gwg < 16384) { sp_stamps[gwg * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); \
-  if ((i) == 1 || (i) == 2) sp_stamps[gwg * 8 + 4 + (i)] = __builtin_amdgcn_s_memtime(); \
-  if ((i) == 0) { unsigned xcc; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc)); sp_stamps[gwg * 8 + 7] = xcc; } } } while (0)
-extern "C" int spnet_debug_read_stamps(unsigned long long* host, int n) {
-  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(sp_stamps), sizeof(unsigned long long) * n, 0, hipMemcpyDeviceToHost);
-}
-#else
-#define SP_STAMP(i)
-#endif
 
-#ifdef SP_DWMOCK
-// Diagnostic build only (tools/dwfuse_mock.py): what would the pointwise GEMM cost if its A operand were the depthwise
-// 3x3 of the layer input, evaluated while the A tile is staged?  TIMING ONLY -- results are wrong, traffic and
-// instruction mix are those of the fused path for a 96-row tile of a 12x16 plane (6 image rows x 16 columns):
-//   + 1.5x the A bytes from global memory (the (6+2) x (16+2) halo of a 6 x 16 tile: two more float4 per thread and
-//     K tile, fetched from a second tensor so that they are distinct lines)
-//   + the halo staged through LDS (18.4 KB, 4.5 float4 stores per thread), one more barrier per K tile
-//   + per A element: BatchNorm affine + ReLU on the 9 taps, 9 LDS reads of 16 bytes, 36 FMAs
-static const float* g_mock_x2 = nullptr;
-extern "C" int spnet_debug_set_dwmock(const float* x2) { g_mock_x2 = x2; return 0; }
-#define SP_MOCK_HALO 1152          // float4: 8 x 18 pixels x 8 channel quads
-template <class SA>
-__device__ __forceinline__ void dw_mock(SA& st, float4* __restrict__ halo, const float4* __restrict__ wts,
-                                        const float4 (&extra)[2], int tid) {
-#pragma unroll
-  for (int i = 0; i < SA::NV; ++i) halo[tid + i * 256] = st.v[i];
-  halo[768 + tid] = extra[0];
-  if (tid < 128) halo[1024 + tid] = extra[1];
-  __syncthreads();
-  const int kq = tid & 7;
-  const float4 sc = wts[72 + kq], sh = wts[80 + kq];
-  const int tapoff[9] = {-19 * 8, -18 * 8, -17 * 8, -8, 0, 8, 17 * 8, 18 * 8, 19 * 8};
-#pragma unroll
-  for (int i = 0; i < SA::NV; ++i) {
-    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-    for (int tap = 0; tap < 9; ++tap) {
-      int idx = tid + i * 256 + tapoff[tap] + 19 * 8;
-      if (idx >= SP_MOCK_HALO) idx -= SP_MOCK_HALO;
-      float4 v = halo[idx];
-      v.x = fmaxf(fmaf(v.x, sc.x, sh.x), 0.f); v.y = fmaxf(fmaf(v.y, sc.y, sh.y), 0.f);
-      v.z = fmaxf(fmaf(v.z, sc.z, sh.z), 0.f); v.w = fmaxf(fmaf(v.w, sc.w, sh.w), 0.f);
-      const float4 w = wts[tap * 8 + kq];
-      acc.x = fmaf(v.x, w.x, acc.x); acc.y = fmaf(v.y, w.y, acc.y);
-      acc.z = fmaf(v.z, w.z, acc.z); acc.w = fmaf(v.w, w.w, acc.w);
-    }
-    st.v[i] = acc;
-  }
-}
-#endif
 
 // N x { one MFMA, PER instructions of class MASK } for the instruction scheduler
 template <int N, int MASK, int PER>
@@ -148,13 +94,6 @@ __global__ __launch_bounds__(256, (AX && BM * BN <= 96 * 64) ? 3 : 2) void gemm_
   // (+ a two-slot ring of blend coefficients: [a | b | c] x BK floats per K tile)
   constexpr int CFS = 3 * BK;
   __shared__ __attribute__((aligned(16))) float smem[2 * STAGE + (AX ? 2 * CFS : 0)];
-#ifdef SP_DWMOCK
-  __shared__ float4 mock_halo[SP_MOCK_HALO];
-  __shared__ float4 mock_w[88];                       // 9 taps x 8 channel quads, scale, shift
-  float4 mock_extra[2][2];
-  if (threadIdx.x < 88) mock_w[threadIdx.x] = make_float4(0.01f, 0.02f, 0.03f, 0.04f);
-  mock_extra[0][0] = mock_extra[0][1] = mock_extra[1][0] = mock_extra[1][1] = make_float4(0.f, 0.f, 0.f, 0.f);
-#endif
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -164,7 +103,6 @@ __global__ __launch_bounds__(256, (AX && BM * BN <= 96 * 64) ? 3 : 2) void gemm_
   const int nblk = tiles_m * tiles_n * nsplit;
   int lid = xcd_remap(blockIdx.x, nblk);
   const int gwg = blockIdx.x;
-  SP_STAMP(0);
   const int tn = lid % tiles_n;
   lid /= tiles_n;
   const int tm = lid % tiles_m;
@@ -309,7 +247,6 @@ __global__ __launch_bounds__(256, (AX && BM * BN <= 96 * 64) ? 3 : 2) void gemm_
     }
   }
   __syncthreads();
-  SP_STAMP(1);
 
   // PAR = t & 1: tile t sits in LDS buffer PAR, tile t+1 in register stage 1-PAR, stage PAR is free.
   // FULL: tile t+2 exists and lies completely below kend -> its fetch is branch-free, the whole step is one
@@ -420,13 +357,6 @@ __global__ __launch_bounds__(256, (AX && BM * BN <= 96 * 64) ? 3 : 2) void gemm_
       else if constexpr (AG) gather_a(sa[PAR], kbeg + (t + 2) * BK);
       else sa[PAR].load_full(Ak);
       sb[PAR].load_full(Bk);
-#ifdef SP_DWMOCK
-      if constexpr (!AX && AMAJ == SP_K_MAJOR)
-        if (X2) {                                      // the halo's extra half: two more float4 of a second tensor
-          mock_extra[PAR][0] = *reinterpret_cast<const float4*>(X2 + (Ak - A) + sa[PAR].off[0]);
-          mock_extra[PAR][1] = *reinterpret_cast<const float4*>(X2 + (Ak - A) + sa[PAR].off[SA::NV - 1]);
-        }
-#endif
       Ak += SA::kstep(lda);
       Bk += SB::kstep(ldb);
       if constexpr (AX) Xk += SA::kstep(lda);
@@ -436,10 +366,6 @@ __global__ __launch_bounds__(256, (AX && BM * BN <= 96 * 64) ? 3 : 2) void gemm_
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
       if (c == NCH / 2 && more) {
-#ifdef SP_DWMOCK
-        if constexpr (!AX && AMAJ == SP_K_MAJOR)
-          if (X2) dw_mock(sa[1 - PAR], mock_halo, mock_w, mock_extra[1 - PAR], tid);
-#endif
         sa[1 - PAR].store(nxt, tid);
         sb[1 - PAR].store(nxt + SA::SIZE, tid);
         if (FULL || t + 2 < nt) cf_park(PAR);          // coefficients of tile t+2 (slot parity of t+2 = PAR)
@@ -483,15 +409,8 @@ __global__ __launch_bounds__(256, (AX && BM * BN <= 96 * 64) ? 3 : 2) void gemm_
     }
   }
 
-  SP_STAMP(2);
   gemm_epilogue<SA, SB, BM, BN, WM, WN, TM, TN>(acc, smem, C, ldc, M, N, m0, n0, tm, zs, slab_stride, bias, colstats,
                                                 tid, lane, wm, wn, accumulate);
-#ifdef SP_STAMPS
-  SP_STAMP(3);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  SP_STAMP(4);
-#endif
 }
 
 // out[row*ldc + col] = sum_z ws[z*M*N + row*N + col] (+ bias[col]); N % 4 == 0, ldc % 4 == 0.
@@ -563,9 +482,6 @@ static int launch_tile(const float* A, int amaj, int lda, const float* B, int bm
   const ConvGeom cg = cgp ? *cgp : ConvGeom{0, 0, 0, 0, 0, 0, 0, 0, 0};
   const int tm = spnet_cdiv(M, BM), tn = spnet_cdiv(N, BN);
   dim3 grid(tm * tn * nsplit), block(256);
-#ifdef SP_DWMOCK
-  if (!xf && !X2) X2 = g_mock_x2;
-#endif
   // the pipelined main loop from 32 K tiles per workgroup (see the kernel's header comment)
   constexpr bool CAN_PIPE = SP_PIPE && (BM / WM / 16) * (BN / WN / 16) < 16;
   const bool pipe = CAN_PIPE && !xf && spnet_cdiv(K < k_chunk ? K : k_chunk, SP_BK) >= SP_PIPE_MIN_TILES;
@@ -869,6 +785,10 @@ extern "C" int spnet_conv_gemm_f32(const float* x, long ldx, const float* Wk, fl
   if (!x || !Wk || !y || B < 1 || H < 1 || W < 1 || KH < 1 || KW < 1 || (stride != 1 && stride != 2)) return (int)hipErrorInvalidValue;
   if (C < SP_BK || (C % SP_BK) || (ldx & 3) || ldx < C || (!colstats) != (!stat_rows)) return (int)hipErrorInvalidValue;
   if ((long)B * H * W * ldx >= (1L << 31)) return (int)hipErrorInvalidValue;       // 32-bit element offsets in the gather
+  // (the gathered fetch carries its tap as running state from k = 0 on: gemm_impl refuses a K split for it; taps beyond a
+  // 16 x 16 window, an output row stride below Cout or a K of 2^31 are not convolutions this entry point serves)
+  if (KH > 16 || KW > 16 || Cout < 4 || (Cout & 3) || ldy < Cout || (ldy & 3) || (long)KH * KW * C >= (1L << 31))
+    return (int)hipErrorInvalidValue;
   ConvGeom cg;
   cg.H = H; cg.W = W; cg.C = C; cg.KW = KW; cg.stride = stride;
   if (same) {

@@ -64,10 +64,7 @@ def _capture(fn):
     return g
 
 
-def _stream():
-    """Raw handle of the current HIP stream of the current device.  (torch.cuda.current_stream().cuda_stream builds a
-    Stream object per call, ~2 us; a step is 330 ... 1,900 launches and this is called for each of them.)"""
-    return torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice())
+_stream = L.current_stream       # raw handle of the current HIP stream (resolved once in _lib, public-API fallback)
 
 
 class KernelTimer:
@@ -388,14 +385,10 @@ class Engine:
         self._dw_reduce_table = None
         self._wgrad_table = None
         self._first_middle = None
-        self.defer_mid_wgrad = os.environ.get("SPNET_DEFER_WGRAD", "1") != "0"
-        # BatchNorm finalize kernels folded into their consumers where the statistics arrive as <= 128 partial rows
-        self.bn_fold = os.environ.get("SPNET_BN_FOLD", "1") != "0"
-        # dev toggle: Inception-ResNet-v2 data gradients of 1x1 convolutions added onto the accumulator in the GEMM epilogue
-        self.ir_acc_epilogue = os.environ.get("SPNET_IR_ACC_EPILOGUE", "1") != "0"
-        # dev toggle: BatchNorm backward sums from the max-pool backward pass (StridedBlock) instead of a reduction pass
-        self.pool_stats = os.environ.get("SPNET_POOL_STATS", "1") != "0"
-        # pointwise weight gradients on a side stream (joined before Adam); SPNET_OVERLAP_WGRAD=0: one stream
+        # The three run-time switches of the engine (DESIGN.md section 2 lists them with the tests that run the non-default
+        # branch): SPNET_OVERLAP_WGRAD=0 -- weight gradients on the main stream instead of a side stream joined before
+        # Adam; SPNET_TRAIN_GRAPH=1 -- the single-GPU train step as a hipGraph; SPNET_GEMM_TILES=0 (_load_tile_table) --
+        # the library's own tile choice instead of the in-step autotuned table.
         self.overlap_wgrad = os.environ.get("SPNET_OVERLAP_WGRAD", "1") != "0"
         # Optional: capture the single-GPU train step as a hipGraph after one eager step.  Off by default:
         # measured on MI355X / ROCm 7.2 the replay of this ~400-node two-stream graph takes 13.8 ms against
@@ -683,10 +676,8 @@ class Engine:
         model.predict loop).  The plan is static, so the ~110 launches of a forward are captured once per plan; the
         BatchNorm inference coefficients are refreshed by an eager forward whenever the weights or moving statistics
         changed since this plan last ran (the graph itself holds no weight-dependent host decisions).
-        SPNET_PREDICT_GRAPH=0 keeps the eager launches."""
-        if use_graph is None:
-            use_graph = os.environ.get("SPNET_PREDICT_GRAPH", "1") != "0"
-        if not use_graph or self.prof is not None:
+        use_graph=False keeps the eager launches."""
+        if use_graph is False or self.prof is not None:
             return self.forward(None, training=False)
         if self._coeff_ver != self._wver[0] or self._igraph is None:
             out = self.forward(None, training=False)          # eager: also recomputes scale|shift of every BatchNorm
@@ -912,7 +903,7 @@ class Engine:
                 first[node] = min(offs)
         cur_hi = self.n_theta
         owners = [n for n in self.nodes if n in first]
-        is_mid = lambda n: isinstance(n, MiddleBlock) and self.defer_mid_wgrad
+        is_mid = lambda n: isinstance(n, MiddleBlock)
         for i in range(len(owners) - 1, -1, -1):
             node = owners[i]
             if first[node] >= cur_hi:
@@ -1168,7 +1159,7 @@ class Pointwise:
         # pass of its own.  The blend reads BOTH g and yp once per COLUMN tile of dX, so it only pays while dX has
         # one or two column tiles; measured on MI355X (tools/gemm_sweep.py blend, us incl. the BN kernels):
         #   cin 128 (M 372,000): 242 -> 202     cin 256 (M 94,752): 163 -> 189     cin 728 (M 6,144): 85 -> 99
-        self.blend = bool(allow_blend and eng.train_capable and cin <= 128 and os.environ.get("SPNET_BN_BLEND", "1") != "0")
+        self.blend = bool(allow_blend and eng.train_capable and cin <= 128)
         self.wT = eng.transposed(wname) if self.blend else None     # [cout][cin]: forward operand form for the blend
         self.defer_wgrad = defer_wgrad      # dW is left to Engine.flush_deferred_wgrads() (one batched launch)
 
@@ -1417,7 +1408,7 @@ class SepConvBN:
             src.owner.consumer_rows = self.rows_src
             # the producer's training-forward BatchNorm finalize runs inside this unit's depthwise prologue
             # (spnet_dwconv3x3_tiled_fwd_bnfin) whenever its GEMM leaves at most 128 partial rows
-            src.owner.fin_by_consumer = eng.train_capable and eng.bn_fold
+            src.owner.fin_by_consumer = eng.train_capable
 
     def ref(self):
         if self.mode == "apply":
@@ -1447,7 +1438,7 @@ class SepConvBN:
             rows = self.pw.fwd_colstats(self.z, self.yp)
             if self.fin_by_consumer and rows <= 128:
                 self.pending_rows = rows            # the consumer's depthwise is the next launch on this stream
-            elif self.mode == "apply" and e.bn_fold:
+            elif self.mode == "apply":
                 bn = self.bn                        # finalize + y = act(BN(yp)) (+ residual) in one launch
                 L.spnet_bn_finalize_apply(e.ws_ptr(WS_BNP), rows, L.ptr(self.yp), self.M, self.cout, L.ptr(bn.gamma),
                                           L.ptr(bn.beta), L.ptr(bn.mm), L.ptr(bn.mv), bn.mean_ptr, bn.invstd_ptr,
@@ -1508,7 +1499,7 @@ class MiddleBlock(Node):
         # The 24 middle-flow weight gradients (728 x 728, K = batch*12*16 pixels) are each too small to fill
         # the chip without a K split; their operands (z, dy) stay intact until the next step, so they are
         # collected here and run as ONE batched GEMM once block 5 has been back-propagated.
-        d = eng.train_capable and eng.defer_mid_wgrad
+        d = eng.train_capable
         self.u1 = SepConvBN(eng, src, C, C, "block%d_sepconv1" % b, True, mode="lazy", defer_wgrad=d)
         if src.stats_bn is not None:
             prev.u3.consumer_rows = self.u1.rows_src
@@ -1561,7 +1552,7 @@ class StridedBlock(Node):
             # (the partial rows are the kernel's workgroup rows: 128 where u2's BatchNorm backward is the one-launch
             # finalize + apply, 1,024 where u2 only derives blend coefficients from the sums)
             rows = L.spnet_maxpool3x3s2_bwd_rows(B, H, W, c2, 1024 if self.u2.blend else 128)
-            self.pool_stats = eng.pool_stats and rows * 2 * c2 <= WS_BNP[1]
+            self.pool_stats = rows * 2 * c2 <= WS_BNP[1]      # (else: stand-alone reduction pass inside u2's backward)
             if self.pool_stats:
                 self.u2.consumer_rows = self.pool_rows = rows
         else:
@@ -1683,50 +1674,42 @@ class IRv2Backbone(Node):
         # Sibling 1x1 convolutions (the first layer of every branch of a block reads the block input) as ONE GEMM + ONE
         # BatchNormalization (_IRGroup).  In training every member needs its one consumer to be a k x k convolution or a
         # Concatenate (they leave the masked gradient and the BatchNorm sums in the group's blocks): true for every
-        # group of the network.  SPNET_IR_MERGE_SIBLINGS=0: layer by layer.
+        # group of the network.
         self.groups, self._wm_jobs, self._wm_ver = [], None, -1
-        fuse_sums = os.environ.get("SPNET_IR_FUSE_BNSUMS", "1") != "0"
-        if os.environ.get("SPNET_IR_MERGE_SIBLINGS", "1") != "0" and (fuse_sums or not eng.train_capable):
-            consumer = {}
-            for o in self.ops:
-                for t in o.srcs():
-                    consumer[id(t)] = o
-            by_src = OrderedDict()
-            for o in self.ops:
-                if isinstance(o, _IRConv) and o.direct and not o.bias and not o.small and o.relu:
-                    by_src.setdefault(id(o.src), []).append(o)
-            for ms in by_src.values():
-                ok = len(ms) >= 2
-                for m in ms:
-                    c = consumer.get(id(m.out))
-                    ok = ok and m.out.consumers == 1 and (isinstance(c, _IRConcat) or
-                                                          (isinstance(c, _IRConv) and not c.direct and not c.small))
-                if ok:
-                    self.groups.append(_IRGroup(eng, self, ms))
-            for o in self.ops:        # (a consumer that counted on the implicit forward now reads a column block: patch matrix)
-                if isinstance(o, _IRConv) and not o.direct and not o.small and o.col is None:
-                    if not o.src.buf.is_contiguous():
-                        o.col = eng.new(o.M, o.K)
+        consumer = {}
+        for o in self.ops:
+            for t in o.srcs():
+                consumer[id(t)] = o
+        by_src = OrderedDict()
+        for o in self.ops:
+            if isinstance(o, _IRConv) and o.direct and not o.bias and not o.small and o.relu:
+                by_src.setdefault(id(o.src), []).append(o)
+        for ms in by_src.values():
+            ok = len(ms) >= 2
+            for m in ms:
+                c = consumer.get(id(m.out))
+                ok = ok and m.out.consumers == 1 and (isinstance(c, _IRConcat) or
+                                                      (isinstance(c, _IRConv) and not c.direct and not c.small))
+            if ok:
+                self.groups.append(_IRGroup(eng, self, ms))
         # A conv2d_bn branch whose only consumer is a Concatenate writes its output straight into that buffer (its
         # BatchNorm apply pass gets the row stride of the concatenated tensor): no copy pass in forward.  The tensor
         # stays a strided view for everyone who looks at it (the Concatenate backward reads the ReLU mask from it).
-        # SPNET_IR_DIRECT_CONCAT=0: branch buffers + copies.
-        if os.environ.get("SPNET_IR_DIRECT_CONCAT", "1") != "0":
-            for o in self.ops:
-                if not isinstance(o, _IRConcat):
-                    continue
-                ct, off = sum(o.cs), 0
-                for i, (t, c) in enumerate(zip(o.srcs_, o.cs)):
-                    p = t.owner
-                    if isinstance(p, _IRConv) and not p.bias and not p.small and t.consumers == 1 and p.group is None:
-                        t.buf = o.out.buf[..., off:off + c]
-                        p.ldy = ct
-                        o.direct[i] = True
-                    off += c
+        for o in self.ops:
+            if not isinstance(o, _IRConcat):
+                continue
+            ct, off = sum(o.cs), 0
+            for i, (t, c) in enumerate(zip(o.srcs_, o.cs)):
+                p = t.owner
+                if isinstance(p, _IRConv) and not p.bias and not p.small and t.consumers == 1 and p.group is None:
+                    t.buf = o.out.buf[..., off:off + c]
+                    p.ldy = ct
+                    o.direct[i] = True
+                off += c
         # A conv2d_bn output with ONE consumer that is a k x k convolution or a Concatenate gets its BatchNorm-backward
         # sums from that consumer's gradient pass (spnet_patches_bwd_bnsums / spnet_copy_cols_bnsums) instead of a
-        # reduction pass of its own (SPNET_IR_FUSE_BNSUMS=0: stand-alone reductions).
-        if eng.train_capable and os.environ.get("SPNET_IR_FUSE_BNSUMS", "1") != "0":
+        # reduction pass of its own.
+        if eng.train_capable:
             for o in self.ops:
                 for t in o.srcs():
                     p = t.owner
@@ -1742,9 +1725,9 @@ class IRv2Backbone(Node):
         # 244 convolutions) are deferred to the end of backward and run as ONE batched GEMM per shape with a K split
         # (spnet_gemm_f32_batched_splitk) instead of a small split-K GEMM + slab reduce per layer: their operands --
         # the patch matrix / block input and the BatchNorm-backward output left in the gradient accumulator -- stay
-        # untouched until the next step.  SPNET_IR_BATCH_WGRAD=0: per-layer launches.
+        # untouched until the next step.
         self.wg_groups, self.wg_ws, self._wg_trigger = [], None, None
-        if eng.train_capable and os.environ.get("SPNET_IR_BATCH_WGRAD", "1") != "0":
+        if eng.train_capable:
             by_shape = {}
             for o in self.ops:
                 if isinstance(o, _IRConv) and not o.small:
@@ -1805,9 +1788,8 @@ class IRv2Backbone(Node):
             pos = {id(o): i for i, o in enumerate(self.ops)}
             lead = lambda m: m if m.group is None else m.group.members[0]
             self._wg_trigger = {}
-            eager = os.environ.get("SPNET_IR_EAGER_WGRAD", "1") != "0"
             for g in self.wg_groups:
-                i = min(pos[id(lead(m))] for m in g["members"]) if eager else 0
+                i = min(pos[id(lead(m))] for m in g["members"])
                 self._wg_trigger.setdefault(i, []).append(g)
         for i in range(len(self.ops) - 1, -1, -1):
             self.ops[i].bwd(self)
@@ -1910,20 +1892,15 @@ class _IRGroup:
     def fwd(self, training):
         e, Ct, x = self.e, self.Ct, self.src.buf
         act = ACT_RELU
-        if training and e.bn_fold:
+        if training:
             rows = _gemm_colstats(x, self.cin, self.Wm, Ct, self.yp, Ct, self.M, Ct, self.cin, e)
             L.spnet_bn_finalize_apply_ld(e.ws_ptr(WS_BNP), rows, L.ptr(self.yp), self.M, Ct, L.ptr(self.ones), L.ptr(self.beta),
                                          L.ptr(self.mm), L.ptr(self.mv), L.ptr(self.save), self.save[Ct:].data_ptr(),
                                          L.ptr(self.ss), act, None, L.ptr(self.y), Ct, BN_EPS, BN_MOMENTUM, _stream())
             return
         _gemm(x, K_MAJOR, self.cin, self.Wm, OUT_MAJOR, Ct, self.yp, Ct, self.M, Ct, self.cin, e)
-        if training:
-            L.spnet_bn_fwd_train_ld(L.ptr(self.yp), self.M, Ct, L.ptr(self.ones), L.ptr(self.beta), L.ptr(self.mm),
-                                    L.ptr(self.mv), L.ptr(self.save), self.save[Ct:].data_ptr(), L.ptr(self.ss), act, None, 0,
-                                    L.ptr(self.y), Ct, BN_EPS, BN_MOMENTUM, e.ws_ptr(WS_MISC), _stream())
-        else:
-            L.spnet_bn_fwd_infer_ld(L.ptr(self.yp), self.M, Ct, L.ptr(self.ones), L.ptr(self.beta), L.ptr(self.mm),
-                                    L.ptr(self.mv), L.ptr(self.ss), act, None, 0, L.ptr(self.y), Ct, BN_EPS, _stream())
+        L.spnet_bn_fwd_infer_ld(L.ptr(self.yp), self.M, Ct, L.ptr(self.ones), L.ptr(self.beta), L.ptr(self.mm),
+                                L.ptr(self.mv), L.ptr(self.ss), act, None, 0, L.ptr(self.y), Ct, BN_EPS, _stream())
 
     def bwd(self, net):
         """Runs where the group's FIRST member stands in the program, i.e. last of the block in backward order: every
@@ -1946,7 +1923,7 @@ class _IRGroup:
                 with torch.cuda.stream(side):
                     wgrads(WS_GEMM2)
         src = self.src
-        if src.g is not None and e.ir_acc_epilogue:
+        if src.g is not None:
             prof = e.prof
             t0 = prof.start() if prof is not None else None
             L.spnet_gemm_f32_accumulate(L.ptr(g), K_MAJOR, Ct, L.ptr(self.Wm), K_MAJOR, Ct, L.ptr(src.g), self.cin, self.M,
@@ -1976,23 +1953,15 @@ class _IRConv:
         self.deferred_wgrad = False                  # set by IRv2Backbone: dW comes out of a batched launch per shape
         self.sum_rows, self.sum_part = 0, None       # set by IRv2Backbone: my BatchNorm-backward sums come from my consumer
         self.ldy = cout                              # row stride of my output (IRv2Backbone: the Concatenate's width)
-        # SPNET_IR_IMPLICIT_FWD=1: k x k convolutions forward as an implicit GEMM (spnet_conv_fwd_implicit: no patch
-        # matrix on the forward path; the one the weight-gradient GEMM reads is gathered in backward, on the
-        # weight-gradient stream).  Off by default: measured SLOWER at these sizes (training 756 -> 695 images/s,
-        # inference 2,145 -> 1,842 frames/s at batch 16) -- a patch gather of a 9,744 x 288 matrix is an 8 us launch, and
-        # the tuned GEMM behind it beats the gathered 64x64-tile kernel by more than that.
-        self.implicit = (not self.direct and not self.small and cin % 16 == 0 and self.kh * self.kw <= 32 and
-                         os.environ.get("SPNET_IR_IMPLICIT_FWD", "0") == "1")
-        # Round 3, second attempt, ON by default (SPNET_IR_GATHER_FWD=0: patch gather + GEMM): the same convolution on the
-        # TUNED GEMM kernel with its A tiles gathered while they are staged (spnet_conv_gemm_f32: same tiles, same
-        # pipeline, same bits; cin a multiple of the 32-deep K tile) -- the forward patch gather launch disappears from
-        # the main stream's chain; the weight gradient gathers its patch matrix itself, on its own stream.
-        self.gathered = (not self.direct and not self.small and not self.implicit and cin % 32 == 0 and
-                         os.environ.get("SPNET_IR_GATHER_FWD", "1") != "0")
+        # k x k convolutions with cin a multiple of the 32-deep K tile run forward on the TUNED GEMM kernel with its A
+        # tiles gathered while they are staged (spnet_conv_gemm_f32: same tiles, same pipeline, same bits as patch gather
+        # + GEMM) -- no patch gather launch on the main stream's chain; the weight gradient gathers its patch matrix
+        # itself, on its own stream.  The rest (cin = 48, 80 ...) gathers a patch matrix first.  (A separate 64x64-tile
+        # implicit kernel was measured slower than gather + GEMM in round 3 and removed in round 4.)
+        self.gathered = not self.direct and not self.small and cin % 32 == 0
         self.w = eng.P(cname + "/kernel")
-        # (an inference plan whose convolution runs as an implicit GEMM never needs the patch matrix)
-        no_col = self.direct or self.small or (not eng.train_capable and
-                                               (self.gathered or (self.implicit and src.buf.is_contiguous())))
+        # (an inference plan whose convolution gathers its A tiles never needs the patch matrix)
+        no_col = self.direct or self.small or (not eng.train_capable and self.gathered)
         self.col = None if no_col else eng.new(self.M, self.K)
         self.col_floats = 0 if (self.direct or self.small) else self.M * self.K
         self.out = _T(eng.new(B, OH, OW, cout))
@@ -2036,8 +2005,8 @@ class _IRConv:
                 G.sum_part.data_ptr() + c4, G.Ct, G.rows, G.g.data_ptr() + c4, G.Ct)
 
     def gather_patches(self):
-        """The patch matrix of my input, for the weight-gradient GEMM (implicit-forward convolutions skipped it in forward)."""
-        if self.gathered or (self.implicit and self.src.buf.is_contiguous()):
+        """The patch matrix of my input, for the weight-gradient GEMM (gathered-A convolutions skipped it in forward)."""
+        if self.gathered:
             L.spnet_patches_ld(L.ptr(self.src.buf), self.src.buf.stride(2), L.ptr(self.col), self.e.B, self.H, self.W,
                                self.cin, self.kh, self.kw, self.stride, self.same, _stream())
 
@@ -2053,7 +2022,7 @@ class _IRConv:
             L.spnet_conv3x3_small(0, 3, C, self.stride, 0, L.ptr(self.src.buf), L.ptr(self.w), L.ptr(dst), e.B, self.H,
                                   self.W, e.ws_ptr(WS_MISC), WS_MISC[1], _stream())
         elif self.gathered:
-            stats = training and not self.bias and e.bn_fold
+            stats = training and not self.bias
             prof = e.prof
             t0 = prof.start() if prof is not None else None
             L.spnet_conv_gemm_f32(L.ptr(self.src.buf), self.src.buf.stride(2), L.ptr(self.w), L.ptr(dst), C, e.B, self.H,
@@ -2071,27 +2040,11 @@ class _IRConv:
                                              self.save[C:].data_ptr(), L.ptr(self.ss), ACT_RELU if self.relu else ACT_NONE,
                                              None, L.ptr(y), self.ldy, BN_EPS, BN_MOMENTUM, _stream())
                 return
-        elif self.implicit and self.src.buf.is_contiguous():
-            stats = training and not self.bias and e.bn_fold
-            prof = e.prof
-            t0 = prof.start() if prof is not None else None
-            L.spnet_conv_fwd_implicit(L.ptr(self.src.buf), L.ptr(self.w), L.ptr(dst), e.B, self.H, self.W, self.cin, C,
-                                      self.kh, self.kw, self.stride, self.same, L.ptr(self.b) if self.bias else None,
-                                      e.ws_ptr(WS_BNP) if stats else None,
-                                      __import__("ctypes").addressof(_stat_rows) if stats else None, _stream())
-            if prof is not None:
-                prof.stop("gemm", t0, 2.0 * self.M * C * self.K, ("conv implicit", self.M, C, self.K))
-            if stats:
-                L.spnet_bn_finalize_apply_ld(e.ws_ptr(WS_BNP), _stat_rows.value, L.ptr(self.yp), self.M, C, L.ptr(self.ones),
-                                             L.ptr(self.beta), L.ptr(self.mm), L.ptr(self.mv), L.ptr(self.save),
-                                             self.save[C:].data_ptr(), L.ptr(self.ss), ACT_RELU if self.relu else ACT_NONE,
-                                             None, L.ptr(y), self.ldy, BN_EPS, BN_MOMENTUM, _stream())
-                return
         else:
             if not self.direct:       # (the input may be one member's column block of a sibling group's output)
                 L.spnet_patches_ld(L.ptr(self.src.buf), self.src.buf.stride(2), L.ptr(self.col), e.B, self.H, self.W,
                                    self.cin, self.kh, self.kw, self.stride, self.same, _stream())
-            if training and not self.bias and e.bn_fold:
+            if training and not self.bias:
                 # BatchNorm statistics out of the GEMM accumulators, finalize + normalise + ReLU in one more launch
                 # (two when the GEMM leaves more than 128 partial rows): no reduction pass over yp
                 rows = _gemm_colstats(self._A(), self.K, self.w, C, dst, C, self.M, C, self.K, e)
@@ -2105,7 +2058,7 @@ class _IRConv:
         if self.bias:
             return
         act = ACT_RELU if self.relu else ACT_NONE
-        if training:
+        if training:      # (only the 3-channel first convolution gets here in training: its GEMM-free kernel leaves no sums)
             L.spnet_bn_fwd_train_ld(L.ptr(self.yp), self.M, C, L.ptr(self.ones), L.ptr(self.beta), L.ptr(self.mm),
                                     L.ptr(self.mv), L.ptr(self.save), self.save[C:].data_ptr(), L.ptr(self.ss), act, None, 0,
                                     L.ptr(y), self.ldy, BN_EPS, BN_MOMENTUM, e.ws_ptr(WS_MISC), _stream())
@@ -2154,7 +2107,7 @@ class _IRConv:
         if self.small:
             L.spnet_conv3x3_small(1, 3, C, self.stride, 0, L.ptr(g), L.ptr(self.w), L.ptr(self.dx), e.B, self.H, self.W,
                                   e.ws_ptr(WS_MISC), WS_MISC[1], _stream())
-        elif self.direct and self.src.g is not None and e.ir_acc_epilogue:
+        elif self.direct and self.src.g is not None:
             # another consumer of my input has already left its gradient in the accumulator: add mine in the GEMM's
             # epilogue (C += dY W^T) instead of a GEMM into dx + an accumulation pass -- same sum, same rounding
             prof = e.prof

@@ -371,7 +371,9 @@ class Model:
         One static launch plan per batch size, replayed as a hipGraph (Engine.predict_step).  Host frames are STREAMED:
         batch k+1 travels host -> pinned ring -> HBM on a copy stream while batch k is being computed, so neither
         the whole set nor a second copy of it has to fit anywhere and the PCIe transfer hides behind the forward
-        passes; device-resident frames are read in place."""
+        passes; device-resident frames are read in place.  uint8 frames -- host arrays or device tensors alike -- are grey
+        levels 0..255 and are scaled to [-1,1] on the device (an addition of this build: Keras would cast them unscaled);
+        float frames are taken as they are."""
         torch = _torch()
         N = int(X.shape[0])
         bs = max(1, min(int(batch_size), max(N, 1)))
@@ -386,10 +388,18 @@ class Model:
         if resident is not None and not resident.is_cuda:
             resident = resident.to(dev)
 
+        from . import _lib as L
+
         def run(lo, hi, frames):
-            """frames: device tensor holding hi-lo frames"""
+            """frames: device tensor holding hi-lo frames; float32 in [-1,1], or uint8 grey levels, which are scaled on
+            the device exactly as the input codec scales them on the host (spnet_u8_to_input: utils.py:340-342) --
+            the same frames give the same predictions whatever container they arrive in"""
             n = hi - lo
-            if n == bs:
+            if frames.dtype == torch.uint8:
+                L.spnet_u8_to_input(frames.data_ptr(), eng.x_in.data_ptr(), n * self.H * self.W, L.current_stream())
+                if n < bs:                           # ragged tail: pad with the last frame, drop the extras
+                    eng.x_in[n:].copy_(eng.x_in[n - 1:n].expand(bs - n, -1, -1, -1))
+            elif n == bs:
                 eng.x_in.copy_(frames.reshape(eng.x_in.shape))
             else:                                   # ragged tail: pad with the last frame, drop the extras
                 eng.x_in[:n].copy_(frames.reshape(n, self.H, self.W, 1))
@@ -398,6 +408,7 @@ class Model:
             out[lo:hi].copy_(y[:n])
 
         if resident is not None:
+            resident = resident.contiguous()
             for lo in range(0, N, bs):
                 hi = min(N, lo + bs)
                 run(lo, hi, resident[lo:hi])
@@ -419,16 +430,6 @@ class Model:
             self._rings[key] = ring
             self._copy_stream = torch.cuda.Stream(device=dev)
         main = torch.cuda.current_stream()
-        from . import _lib as L
-
-        def run_u8(lo, hi, frames):
-            n = hi - lo
-            L.spnet_u8_to_input(frames.data_ptr(), eng.x_in.data_ptr(), n * self.H * self.W, main.cuda_stream)
-            if n < bs:                               # ragged tail: pad with the last frame, drop the extras
-                eng.x_in[n:].copy_(eng.x_in[n - 1:n].expand(bs - n, -1, -1, -1))
-            y = eng.predict_step()
-            out[lo:hi].copy_(y[:n])
-
         for k, lo in enumerate(range(0, N, bs)):
             hi = min(N, lo + bs)
             n = hi - lo
@@ -441,7 +442,7 @@ class Model:
                 devbuf[:n].copy_(host[:n], non_blocking=True)
                 landed.record(self._copy_stream)
             main.wait_event(landed)
-            (run_u8 if u8 else run)(lo, hi, devbuf[:n])
+            run(lo, hi, devbuf[:n])
             consumed.record(main)
         return out.cpu().numpy()
 

@@ -10,9 +10,15 @@ from oracle import torch_ref as T
 # Tolerances of the end-to-end parity tests, set from what is OBSERVED (round 4): every case logs its worst figure
 # through observe() (SPNET_PARITY_LOG=<file>: one JSON line per figure; profiles/r04_parity_observed.txt is the GPU
 # suite's log), and each bound below is about 10x the worst value any case of the suite produced.
-GRAD_TOL = 5e-3          # max|dgrad - ref| / max|ref| per parameter tensor (fp64 oracle on the device's decisions)
-OUT_REL_TOL = 5e-4       # the same measure on the network output of a training forward
-FWD_MSE_FACTOR = 1e-8    # inference forward: MSE <= factor * max(mean(ref^2), 1)   (north-star tolerance: 1e-4)
+# Observed over the 16 end-to-end cases of the GPU suite (three backbones, 9 geometries, batch 1-3 + 384x512):
+#   worst per-tensor gradient error 1.03e-4 (MobileNet conv_pw_1_bn/gamma; Xception <= 9.4e-5, typical 1e-5)
+#   worst training-output error 3.3e-5, worst inference MSE / scale 1.45e-12
+GRAD_TOL = 1e-3          # max|dgrad - ref| / max|ref| per parameter tensor (fp64 oracle on the device's decisions)
+GRAD_TOL_VANISHING = 5e-3  # tensors whose true gradient vanishes identically (max|ref| < 1e-6 of the model's largest
+#                            gradient entry: a bias in front of a training-mode BatchNorm), measured against that floor:
+#                            observed 1.9e-3 (Inception-ResNet's block8_10_conv/bias), i.e. 2e-9 of the largest entry
+OUT_REL_TOL = 3.5e-4     # the same measure on the network output of a training forward
+FWD_MSE_FACTOR = 2e-11   # inference forward: MSE <= factor * max(mean(ref^2), 1)   (north-star tolerance: 1e-4)
 
 
 def observe(kind, value, detail=""):
@@ -176,8 +182,10 @@ def assert_gradients_match(eng, P, X, Y, mask, tol=None, tie=1e-5, loss_type="sa
     for k in g64:
         ref = g64[k].numpy()
         e = float(np.abs(gd[k].numpy().astype(np.float64) - ref).max()) / max(float(np.abs(ref).max()), floor)
-        worst = max(worst, (e, k))
-        if e > tol:
+        vanishing = float(np.abs(ref).max()) < floor
+        if not vanishing:
+            worst = max(worst, (e, k))
+        if e > (max(tol, GRAD_TOL_VANISHING) if vanishing else tol):
             bad[k] = e
     observe("grad_rel_err_worst_tensor", worst[0], worst[1])
     observe("decisions_overridden", n_over, "of %d; largest gap %.3g" % (dec.n_decisions, max([f[2] for f in dec.flips] or [0.0])))

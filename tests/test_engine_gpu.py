@@ -1,6 +1,7 @@
 """End-to-end parity of the HIP engine against the torch-CPU oracle on identical weights and frames:
 inference forward, training forward (batch statistics + dropout), every parameter gradient, several
 optimizer steps; plus the device augmentation against golden frames produced by the reference."""
+import os
 import random
 
 import numpy as np
@@ -13,6 +14,12 @@ from oracle import numpy_ref as R
 from oracle import torch_ref as T
 
 H, W, B = 96, 128, 2
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _need_gpu():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
 
 
 from tests.parity_util import assert_forward_mse, dropout_mask  # noqa: E402,F401  (dropout_mask re-exported for the other test modules)
@@ -190,3 +197,27 @@ def test_graph_replayed_training_invalidates_inference_coefficients():
         assert float((out - first).abs().max()) > 1e-6        # four steps at lr 1e-3 moved the prediction
         outs.append(out.cpu())
     np.testing.assert_allclose(outs[1].numpy(), outs[0].numpy(), rtol=0, atol=1e-5)
+
+
+def test_graph_capture_survives_garbage_of_an_earlier_plan():
+    """The abort of round 3 (`Fatal Python error: Aborted ... Garbage-collecting` under predict_step), reproduced on
+    purpose in a child process: an earlier plan's graph / streams / events reachable only through reference cycles, the
+    cyclic collector set to run on nearly every allocation, then a capture.  tests/helpers/capture_gc.py."""
+    _need_gpu()
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "helpers", "capture_gc.py")], capture_output=True,
+                       text=True, timeout=600)
+    assert r.returncode == 0 and "CAPTURE_GC_OK" in r.stdout, (r.returncode, r.stdout[-2000:], r.stderr[-4000:])
+
+
+def test_stream_accessor_matches_the_public_handle():
+    """_lib.current_stream (torch's private raw accessor, resolved once) returns the handle of the public API, on the
+    default stream and inside a `with torch.cuda.stream(...)` block."""
+    _need_gpu()
+    from spnet_amd import _lib as L
+    assert L.current_stream() == torch.cuda.current_stream().cuda_stream
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        assert L.current_stream() == side.cuda_stream == torch.cuda.current_stream().cuda_stream
+    assert L.current_stream() == torch.cuda.current_stream().cuda_stream

@@ -291,6 +291,37 @@ def test_bench_self_launches_its_ranks_on_gloo():
     assert r.returncode != 0 and "WORLD_SIZE" in (r.stderr + r.stdout)
 
 
+def test_bench_launches_eight_ranks_and_reports_a_failing_rank():
+    """What the first 8-GPU run will do before any kernel: `bench.py --gpus 8` starts eight ranks, they rendezvous and
+    count each other with one all-reduce (gloo here; --launch-check runs no kernels).  And when ONE rank of a job dies,
+    the parent's stderr ends with that rank's own last stderr lines (SPNET_BENCH_FAIL_RANK: a test hook that makes the
+    named rank raise after the rendezvous), not only with torchrun's summary."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--launch-check"],
+                       capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+    assert out["n_gpus"] == 8 and out["n_ranks_seen"] == 8 and out["collective_backend"] == "gloo"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "3", "--launch-check"],
+                       capture_output=True, text=True, timeout=600, env=dict(env, SPNET_BENCH_FAIL_RANK="2"))
+    assert r.returncode != 0
+    tail = r.stderr[-6000:]
+    assert "rank 2 of 3 failed" in tail and "SPNET_BENCH_FAIL_RANK" in tail and "last" in tail and "stderr lines of" in tail
+    assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]      # no result line from a failed job
+
+
+def test_stream_accessor_resolves_with_a_public_fallback(monkeypatch):
+    """Every kernel launch takes its stream from _lib.current_stream: torch's private raw accessor when it exists, the
+    public torch.cuda.current_stream().cuda_stream otherwise (tests/test_engine_gpu.py: both give the same handle)."""
+    import torch
+    from spnet_amd import _lib
+    assert _lib.STREAM_ACCESSOR in ("raw", "public")
+    monkeypatch.delattr(torch._C, "_cuda_getCurrentRawStream", raising=False)
+    fn, kind = _lib._resolve_current_stream()
+    assert kind == "public" and fn is _lib._public_stream
+
+
 def test_fork_is_refused_under_a_preloaded_profiler(monkeypatch):
     """rocprofv3 initialises the HIP runtime before Python starts (torch.cuda.is_initialized() stays False): the
     frame generator and the PNG loader must not fork then."""

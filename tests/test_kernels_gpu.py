@@ -151,18 +151,22 @@ def test_gemm_bf16x3_probe_accuracy(L, M, N, K):
     """The bf16x3 probe (fp32 operands as three bf16 pieces, six bf16 MFMAs, fp32 accumulation; NOT on the product path):
     its error against float64 is of the size of the exact fp32 kernel's own -- within 3x of it, and below 2e-6 of the
     row / column norms product -- on random operands with a wide dynamic range; the weight planes reproduce W exactly."""
+    from tools.probes import probe_lib
+    if not probe_lib.available():
+        pytest.skip("tools/probes/lib/libspnet_probe.so not built (make -C tools/probes)")
+    PL = probe_lib.load()
     rs = np.random.RandomState(M + N)
     A = (rs.randn(M, K) * np.exp(rs.randn(M, K))).astype(np.float32)
     W = (rs.randn(K, N) * 0.1 * np.exp(rs.randn(K, N))).astype(np.float32)
     a, w = dev(A), dev(W)
-    Kp = int(L.spnet_bf16x3_kp(K))
+    Kp = int(PL.spnet_bf16x3_kp(K))
     planes = torch.zeros(3 * N * Kp, dtype=torch.int16, device="cuda")
-    L.spnet_split_bf16x3(w.data_ptr(), planes.data_ptr(), K, N, st())
+    assert 0 == PL.spnet_split_bf16x3(w.data_ptr(), planes.data_ptr(), K, N, st())
     pl = planes.view(torch.bfloat16).reshape(3, N, Kp).float().cpu().double()
     assert torch.equal((pl[0] + pl[1] + pl[2])[:, :K].T.contiguous(), torch.from_numpy(W).double())     # h + m + l == w exactly
     assert float(pl[:, :, K:].abs().max()) == 0.0 if Kp > K else True
     c3 = torch.full((M, N), float("nan"), device="cuda")
-    L.spnet_gemm_bf16x3_fwd(a.data_ptr(), K, planes.data_ptr(), c3.data_ptr(), N, M, N, K, st())
+    assert 0 == PL.spnet_gemm_bf16x3_fwd(a.data_ptr(), K, planes.data_ptr(), c3.data_ptr(), N, M, N, K, st())
     c1 = torch.empty(M, N, device="cuda")
     L.spnet_gemm_f32(a.data_ptr(), 0, K, w.data_ptr(), 1, N, c1.data_ptr(), N, M, N, K, 1, None, 0, None, 0, st())
     ref = A.astype(np.float64) @ W.astype(np.float64)
@@ -271,11 +275,43 @@ def test_gemm_rejects_misaligned(L):
         L.spnet_gemm_f32(a.data_ptr(), 0, 6, a.data_ptr(), 1, 6, a.data_ptr(), 6, 8, 6, 6, 0, None, 0, None, 0, st())
 
 
+class _DwForm:
+    """The two implementations of the stride-1 depthwise layer behind one call shape: 'tiled' (LDS tiles) and
+    'stream' / 'stream5' (row-marching waves; rows per wave chosen by the library / forced to 5, which cuts every test
+    plane taller than 5 rows into segments with a ragged last one)."""
+
+    def __init__(self, L, form):
+        self.L, self.form = L, form
+        self.rps = {"tiled": None, "stream": 0, "stream5": 5}[form]
+
+    def rows(self, B, H, W, C):
+        if self.rps is None:
+            return self.L.spnet_dwconv3x3_tiled_rows(B, H, W, C)
+        return self.L.spnet_dwconv3x3_stream_rows(B, H, W, C, self.rps)
+
+    def ws(self, B, H, W, C):
+        if self.rps is None:
+            return self.L.spnet_dwconv3x3_tiled_bwd_ws(B, H, W, C)
+        return self.L.spnet_dwconv3x3_stream_bwd_ws(B, H, W, C, self.rps)
+
+    def fwd(self, x, w, y, B, H, W, C, relu_in, sc, sh):
+        if self.rps is None:
+            return self.L.spnet_dwconv3x3_tiled_fwd(x, w, y, B, H, W, C, relu_in, sc, sh, st())
+        return self.L.spnet_dwconv3x3_stream_fwd(x, w, y, B, H, W, C, relu_in, sc, sh, self.rps, st())
+
+    def bwd(self, dy, x, w, dx, dw, B, H, W, C, relu_in, add, ws, sc, sh, mu, inv, bnp, bnx):
+        if self.rps is None:
+            return self.L.spnet_dwconv3x3_tiled_bwd(dy, x, w, dx, dw, B, H, W, C, relu_in, add, ws, sc, sh, mu, inv, bnp, bnx, st())
+        return self.L.spnet_dwconv3x3_stream_bwd(dy, x, w, dx, dw, B, H, W, C, relu_in, add, ws, sc, sh, mu, inv, bnp, bnx,
+                                                 self.rps, st())
+
+
 @pytest.mark.parametrize("B,H,W,C", [(2, 12, 16, 728), (3, 7, 5, 64), (1, 93, 125, 128), (2, 6, 8, 1536), (1, 1, 1, 8),
                                      (2, 24, 32, 256), (1, 47, 63, 128), (2, 13, 17, 40)])
 @pytest.mark.parametrize("relu_in", [0, 1])
 @pytest.mark.parametrize("fused_bn", [0, 1])
-def test_dwconv_tiled(L, B, H, W, C, relu_in, fused_bn):
+@pytest.mark.parametrize("form", ["tiled", "stream", "stream5"])
+def test_dwconv_tiled(L, B, H, W, C, relu_in, fused_bn, form):
     """LDS-tiled forward and FUSED backward (data + weight gradient) -- the forms the engine uses.
     fused_bn=1: the input is a PRE-BatchNorm tensor whose affine is applied on load, and the backward
     also emits that BatchNorm's two backward sums."""
@@ -305,14 +341,15 @@ def test_dwconv_tiled(L, B, H, W, C, relu_in, fused_bn):
         scd, shd, mud, isd = sc.cuda(), sh.cuda(), mu.detach().cuda(), invstd.detach().cuda()
     P = lambda t: None if t is None else t.data_ptr()
     yd = torch.full_like(xd, float("nan"))
-    L.spnet_dwconv3x3_tiled_fwd(xd.data_ptr(), wd.data_ptr(), yd.data_ptr(), B, H, W, C, relu_in, P(scd), P(shd), st())
+    F = _DwForm(L, form)
+    F.fwd(xd.data_ptr(), wd.data_ptr(), yd.data_ptr(), B, H, W, C, relu_in, P(scd), P(shd))
     close(yd, y.detach(), rtol=1e-5, atol=2e-5)
-    ws = torch.empty(L.spnet_dwconv3x3_tiled_bwd_ws(B, H, W, C), device="cuda")
-    rows = L.spnet_dwconv3x3_tiled_rows(B, H, W, C)
+    ws = torch.empty(F.ws(B, H, W, C), device="cuda")
+    rows = F.rows(B, H, W, C)
     bnp = torch.full((rows, 2, C), float("nan"), device="cuda") if fused_bn else None
     dxd, dwd = torch.full_like(xd, float("nan")), torch.full((3, 3, C), float("nan"), device="cuda")
-    L.spnet_dwconv3x3_tiled_bwd(dyd.data_ptr(), xd.data_ptr(), wd.data_ptr(), dxd.data_ptr(), dwd.data_ptr(), B, H, W, C,
-                                relu_in, addd.data_ptr(), ws.data_ptr(), P(scd), P(shd), P(mud), P(isd), P(bnp), None, st())
+    F.bwd(dyd.data_ptr(), xd.data_ptr(), wd.data_ptr(), dxd.data_ptr(), dwd.data_ptr(), B, H, W, C,
+          relu_in, addd.data_ptr(), ws.data_ptr(), P(scd), P(shd), P(mud), P(isd), P(bnp), None)
     if fused_bn:
         # dx is the gradient wrt the BatchNorm OUTPUT a (incl. the added branch); the two sums are dbeta / dgamma/gamma-free
         close(dxd, a.grad, rtol=1e-5, atol=2e-5)
@@ -321,14 +358,25 @@ def test_dwconv_tiled(L, B, H, W, C, relu_in, fused_bn):
         close(sums[1], (a.grad * xhat.detach()).reshape(-1, C).sum(0), rtol=1e-4, atol=2e-4 * np.sqrt(B * H * W))
     else:
         close(dxd, x.grad + add, rtol=1e-5, atol=1e-5)
-        L.spnet_dwconv3x3_tiled_bwd(dyd.data_ptr(), xd.data_ptr(), wd.data_ptr(), dxd.data_ptr(), dwd.data_ptr(), B, H, W,
-                                    C, relu_in, None, ws.data_ptr(), None, None, None, None, None, None, st())
+        F.bwd(dyd.data_ptr(), xd.data_ptr(), wd.data_ptr(), dxd.data_ptr(), dwd.data_ptr(), B, H, W,
+              C, relu_in, None, ws.data_ptr(), None, None, None, None, None, None)
         close(dxd, x.grad, rtol=1e-5, atol=1e-5)
     close(dwd, w.grad, rtol=1e-4, atol=1e-4 * np.sqrt(B * H * W))
+    if form != "tiled":      # y and dx of the streaming kernels are the tile kernels' bit for bit (same fmaf order)
+        T_ = _DwForm(L, "tiled")
+        y2, dx2 = torch.full_like(xd, float("nan")), torch.full_like(xd, float("nan"))
+        T_.fwd(xd.data_ptr(), wd.data_ptr(), y2.data_ptr(), B, H, W, C, relu_in, P(scd), P(shd))
+        assert torch.equal(y2, yd)
+        ws2 = torch.empty(T_.ws(B, H, W, C), device="cuda")
+        bnp2 = torch.empty((T_.rows(B, H, W, C), 2, C), device="cuda") if fused_bn else None
+        T_.bwd(dyd.data_ptr(), xd.data_ptr(), wd.data_ptr(), dx2.data_ptr(), dwd.data_ptr(), B, H, W, C, relu_in,
+               addd.data_ptr() if fused_bn else None, ws2.data_ptr(), P(scd), P(shd), P(mud), P(isd), P(bnp2), None)
+        assert torch.equal(dx2, dxd)
 
 
 @pytest.mark.parametrize("B,H,W,C", [(2, 12, 16, 728), (2, 6, 8, 1536), (1, 13, 17, 40)])
-def test_dwconv_tiled_bwd_sums_for_a_block_output(L, B, H, W, C):
+@pytest.mark.parametrize("form", ["tiled", "stream", "stream5"])
+def test_dwconv_tiled_bwd_sums_for_a_block_output(L, B, H, W, C, form):
     """bn_x: the layer reads a block OUTPUT y = BN(yp) + residual (ReLU on load, no affine) and still emits the
     backward sums of that BatchNorm, taking xhat from yp."""
     rs = np.random.RandomState(C + W)
@@ -346,21 +394,21 @@ def test_dwconv_tiled_bwd_sums_for_a_block_output(L, B, H, W, C):
     ((z * dz).sum() + (y * add).sum()).backward()
     g = y.grad                                          # gradient wrt the block output = wrt the BN output
     yd, ypd, wd, dzd, addd = y.detach().cuda(), yp.cuda(), w.cuda(), dz.cuda(), add.cuda()
-    ws = torch.empty(L.spnet_dwconv3x3_tiled_bwd_ws(B, H, W, C), device="cuda")
-    rows = L.spnet_dwconv3x3_tiled_rows(B, H, W, C)
+    F = _DwForm(L, form)
+    ws = torch.empty(F.ws(B, H, W, C), device="cuda")
+    rows = F.rows(B, H, W, C)
     bnp = torch.full((rows, 2, C), float("nan"), device="cuda")
     dxd, dwd = torch.full_like(yd, float("nan")), torch.full((3, 3, C), float("nan"), device="cuda")
     mud, isd = mu.cuda(), invstd.cuda()
-    L.spnet_dwconv3x3_tiled_bwd(dzd.data_ptr(), yd.data_ptr(), wd.data_ptr(), dxd.data_ptr(), dwd.data_ptr(), B, H, W, C, 1,
-                                addd.data_ptr(), ws.data_ptr(), None, None, mud.data_ptr(), isd.data_ptr(), bnp.data_ptr(),
-                                ypd.data_ptr(), st())
+    F.bwd(dzd.data_ptr(), yd.data_ptr(), wd.data_ptr(), dxd.data_ptr(), dwd.data_ptr(), B, H, W, C, 1,
+          addd.data_ptr(), ws.data_ptr(), None, None, mud.data_ptr(), isd.data_ptr(), bnp.data_ptr(), ypd.data_ptr())
     close(dxd, g, rtol=1e-5, atol=2e-5)
     sums = bnp.sum(0).cpu()
     close(sums[0], g.reshape(-1, C).sum(0), rtol=1e-4, atol=1e-4 * np.sqrt(B * H * W))
     close(sums[1], (g * xhat).reshape(-1, C).sum(0), rtol=1e-4, atol=2e-4 * np.sqrt(B * H * W))
     with pytest.raises(L.HipError):                     # bn_x without bn_partial makes no sense
-        L.spnet_dwconv3x3_tiled_bwd(dzd.data_ptr(), yd.data_ptr(), wd.data_ptr(), dxd.data_ptr(), dwd.data_ptr(), B, H, W, C,
-                                    1, None, ws.data_ptr(), None, None, None, None, None, ypd.data_ptr(), st())
+        F.bwd(dzd.data_ptr(), yd.data_ptr(), wd.data_ptr(), dxd.data_ptr(), dwd.data_ptr(), B, H, W, C,
+              1, None, ws.data_ptr(), None, None, None, None, None, ypd.data_ptr())
 
 
 @pytest.mark.parametrize("M,C,P,act,res", [(6144, 728, 64, 0, 1), (1536, 2048, 12, 1, 0), (700, 36, 128, 0, 1), (300, 260, 3, 2, 0)])

@@ -264,5 +264,8 @@ def test_uint8_frames_are_scaled_on_the_device_bit_for_bit():
     y_u = model.predict(U, batch_size=4)
     y_u2 = model.predict_u8(U[..., None], batch_size=4)
     assert np.array_equal(y_f, y_u) and np.array_equal(y_u, y_u2)
+    # the same frames as a device-RESIDENT uint8 tensor take the same scaling (one meaning of uint8 for every container)
+    y_r = model.predict(torch.from_numpy(U).cuda(), batch_size=4)
+    assert np.array_equal(y_r, y_u)
     with pytest.raises(TypeError):
         model.predict_u8(U.astype(np.float32))
