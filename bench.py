@@ -326,7 +326,7 @@ def predict_measure(X_pool, dev, steps, warmup, host_frames=1024):
                      "bound": "mfma", "achieved": round(gemm_tflops, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                      "frac": round(gemm_tflops / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
                      "launches_per_step": g_n / n_prof, "ms_per_step": round(g_ms / n_prof, 3), "measured": note},
-        "roofline_secondary": {"kernel": "dw3x3_tile_fwd_kernel (34 depthwise layers, forward)", "bound": "hbm",
+        "roofline_secondary": {"kernel": "dw3x3_stream_fwd_kernel (34 depthwise layers, forward)", "bound": "hbm",
                                "achieved": round(dw_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                "frac": round(dw_gbs / HBM_PEAK_GBS, 4), "traffic": None,
                                "launches_per_step": d_n / n_prof, "ms_per_step": round(d_ms / n_prof, 3), "measured": note},
@@ -767,7 +767,7 @@ def run(args):
                          "algorithmic_flops_per_launch": round(g_flop / g_n),
                          "avg_launch_us": round(1e3 * g_ms / g_n, 2), "launches_per_step": g_n / args.steps,
                          "ms_per_step": round(g_ms / args.steps, 3)}
-            roof_dw = {"kernel": "dw3x3_tile_fwd_kernel + dw3x3_tile_bwd_kernel (34 depthwise layers, fwd + fused bwd)",
+            roof_dw = {"kernel": "dw3x3_{stream,tile}_fwd_kernel + dw3x3_{stream,tile}_bwd_kernel (34 depthwise layers, fwd + fused bwd: streaming form on the entry-flow planes, LDS-tiled form with the folded BatchNorm finalize on the 12x16 / 6x8 planes)",
                        "bound": "hbm", "achieved": round(dw_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                        "frac": round(dw_gbs / HBM_PEAK_GBS, 4),
                        "traffic": None if d_traffic is None else round(d_traffic),

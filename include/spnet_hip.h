@@ -136,7 +136,10 @@ int spnet_dwconv3x3_tiled_bwd(const float* dy, const float* x_fwd, const float* 
  * every plane of the batch-128 inference plan; call site spnet/models.py:357-359): a wave owns 8 columns x 32 channels
  * and marches down its rows with its loads 3-4 rows ahead in registers; no LDS tile, no barrier, no row halo.
  * rows_per_seg: rows per wave (<= 0: the library's choice); the backward's partial buffers have
- * spnet_dwconv3x3_stream_rows() rows.  y and dx are bit-identical to the tiled kernels' (same fmaf order). */
+ * spnet_dwconv3x3_stream_rows() rows.  H*W*C*4 < 2^31 per image (32-bit buffer offsets).  y and dx are bit-identical
+ * to the tiled kernels' (same fmaf order).  spnet_dwconv3x3_prefers_stream: 1 where the streaming form is the faster
+ * one for this plane (the engine asks once per layer). */
+long spnet_dwconv3x3_prefers_stream(int B, int H, int W, int C, int backward);
 long spnet_dwconv3x3_stream_rows(int B, int H, int W, int C, int rows_per_seg);
 long spnet_dwconv3x3_stream_bwd_ws(int B, int H, int W, int C, int rows_per_seg);
 int spnet_dwconv3x3_stream_fwd(const float* x, const float* w, float* y, int B, int H, int W, int C, int relu_in,

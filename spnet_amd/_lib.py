@@ -46,6 +46,7 @@ _SIGS = {
     "spnet_dwconv3x3_tiled_bwd_ws": (c_long, [c_int, c_int, c_int, c_int]),
     "spnet_dwconv3x3_tiled_rows": (c_long, [c_int, c_int, c_int, c_int]),
     "spnet_dwconv3x3_tiled_bwd": (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, P, P, P, P, P, P, P, P, P]),
+    "spnet_dwconv3x3_prefers_stream": (c_long, [c_int, c_int, c_int, c_int, c_int]),
     "spnet_dwconv3x3_stream_rows": (c_long, [c_int, c_int, c_int, c_int, c_int]),
     "spnet_dwconv3x3_stream_bwd_ws": (c_long, [c_int, c_int, c_int, c_int, c_int]),
     "spnet_dwconv3x3_stream_fwd": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, P, P, c_int, P]),

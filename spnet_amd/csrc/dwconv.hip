@@ -372,17 +372,40 @@ __global__ __launch_bounds__(256) void dw3x3_tile_bwd_kernel(
 // Three running rows of partial sums turn every input row into one output row: no tile, no H halo (except at the row
 // segments the host cuts long planes into to fill the chip), the same fmaf order as the tile kernels (bit-identical).
 // ================================================================================================
-__device__ __forceinline__ float4 f4_shfl_up(const float4 v, int d) {
-  return make_float4(__shfl_up(v.x, d, 64), __shfl_up(v.y, d, 64), __shfl_up(v.z, d, 64), __shfl_up(v.w, d, 64));
+// (native 4-float vectors: selects and loads on them stay single dwordx4 / v_cndmask operations; every load below is
+// UNCONDITIONAL on a clamped, always-valid address and masked afterwards, so the loop bodies are branch-free and the
+// compiler's waitcnt insertion keeps PD rows of loads in flight instead of draining the queue at every block boundary)
+typedef float v4f __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ v4f v4_ld(const float* p) { return *reinterpret_cast<const v4f*>(p); }
+__device__ __forceinline__ void v4_st(float* p, const v4f v) { *reinterpret_cast<v4f*>(p) = v; }
+__device__ __forceinline__ v4f v4_shfl_up(const v4f v, int d) {
+  return v4f{__shfl_up(v.x, d, 64), __shfl_up(v.y, d, 64), __shfl_up(v.z, d, 64), __shfl_up(v.w, d, 64)};
 }
-__device__ __forceinline__ float4 f4_shfl_down(const float4 v, int d) {
-  return make_float4(__shfl_down(v.x, d, 64), __shfl_down(v.y, d, 64), __shfl_down(v.z, d, 64), __shfl_down(v.w, d, 64));
+__device__ __forceinline__ v4f v4_shfl_down(const v4f v, int d) {
+  return v4f{__shfl_down(v.x, d, 64), __shfl_down(v.y, d, 64), __shfl_down(v.z, d, 64), __shfl_down(v.w, d, 64)};
 }
-__device__ __forceinline__ float4 f4_affine(const float4 v, const float4 sc, const float4 sh) {
-  return make_float4(fmaf(v.x, sc.x, sh.x), fmaf(v.y, sc.y, sh.y), fmaf(v.z, sc.z, sh.z), fmaf(v.w, sc.w, sh.w));
+__device__ __forceinline__ v4f v4_fma(const v4f a, const v4f b, const v4f c) {
+  return v4f{fmaf(a.x, b.x, c.x), fmaf(a.y, b.y, c.y), fmaf(a.z, b.z, c.z), fmaf(a.w, b.w, c.w)};
 }
-__device__ __forceinline__ float4 f4_mul(const float4 x, const float4 w) {
-  return make_float4(x.x * w.x, x.y * w.y, x.z * w.z, x.w * w.w);
+__device__ __forceinline__ v4f v4_relu(const v4f v) {
+  return v4f{fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f)};
+}
+__device__ __forceinline__ v4f v4_sel(bool c, const v4f a, const v4f b) { return c ? a : b; }
+// The streamed tensors go through raw BUFFER loads / stores (one descriptor per image): a lane whose byte offset lies
+// beyond the descriptor's range reads zeros / stores nothing WITHOUT touching memory and without a branch -- lanes outside
+// the image or the channel range, and the 48 lanes that take no part in the edge-column load, are switched off by
+// giving them DW_OOB as their offset.  The row advance travels in the scalar offset (not range-checked: rows are
+// clamped to the image and masked afterwards).  32-bit offsets: the entry points require H*W*C*4 < 2^31 per image.
+typedef unsigned int v4u __attribute__((ext_vector_type(4)));
+constexpr int DW_OOB = 0x7ffffff0;
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t dw_rsrc(const float* p, int bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p), 0, bytes, 0x00020000);
+}
+__device__ __forceinline__ v4f dw_bl(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
+  return __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
+}
+__device__ __forceinline__ void dw_bs(__amdgpu_buffer_rsrc_t r, const v4f v, int voff, int soff) {
+  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, v), r, voff, soff, 0);
 }
 
 // wave id -> (batch, row segment, column strip, channel chunk), channel chunk fastest: the four waves of a workgroup
@@ -396,76 +419,79 @@ __global__ __launch_bounds__(256) void dw3x3_stream_fwd_kernel(const float* __re
                                                                const float* __restrict__ in_shift, DwStreamGeom g) {
   constexpr int SW = 64 / CL;
   const int lane = threadIdx.x & 63;
-  long gw = (long)xcd_remap(blockIdx.x, gridDim.x) * 4 + (threadIdx.x >> 6);
+  // (the wave index is uniform: readfirstlane tells the compiler, so that descriptors and row offsets live in SGPRs)
+  long gw = (long)xcd_remap(blockIdx.x, gridDim.x) * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   if (gw >= g.waves) return;                          // whole wave
   const int cc = (int)(gw % g.cchunks); gw /= g.cchunks;
   const int strip = (int)(gw % g.strips); gw /= g.strips;
   const int seg = (int)(gw % g.segs);
   const int b = (int)(gw / g.segs);
   const int l = lane % CL, col = lane / CL;
+  const int c4n = C >> 2;
   const int c4 = cc * CL + l, w = strip * SW + col;
-  const bool chan_ok = c4 * 4 < C;
-  const bool own_ok = chan_ok && w < W;
+  const bool own_ok = c4 < c4n && w < W;
   // the one column outside the strip this lane fetches: the left one (lanes of column 0), the right one (column SW-1)
   const int we = col == 0 ? w - 1 : w + 1;
   const bool edge_lane = col == 0 || col == SW - 1;
-  const bool edge_ok = chan_ok && edge_lane && we >= 0 && we < W;
+  const bool edge_ok = c4 < c4n && edge_lane && we >= 0 && we < W;
   const int h_lo = seg * g.rows_per_seg;
   const int h_hi = min(H, h_lo + g.rows_per_seg);     // output rows [h_lo, h_hi)
   const long rstride = (long)W * C;
-  const float* po = in + (long)b * H * rstride + (long)w * C + c4 * 4;      // + row * rstride
-  const float* pe = in + (long)b * H * rstride + (long)we * C + c4 * 4;
-  float* pout = out + (long)b * H * rstride + (long)w * C + c4 * 4;
-  const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
-  float4 k[9];
+  const int rbytes = (int)rstride * 4;                // bytes per image row
+  const __amdgpu_buffer_rsrc_t rs_in = dw_rsrc(in + (long)b * H * rstride, H * rbytes);
+  const __amdgpu_buffer_rsrc_t rs_out = dw_rsrc(out + (long)b * H * rstride, H * rbytes);
+  const int vo = own_ok ? (w * C + c4 * 4) * 4 : DW_OOB;          // byte offsets inside an image row
+  const int ve = edge_ok ? (we * C + c4 * 4) * 4 : DW_OOB;
+  const int c4c = min(c4, c4n - 1) * 4;               // (clamped: per-channel vectors are fetched by every lane)
+  const v4f zero4 = {0.f, 0.f, 0.f, 0.f};
+  v4f k[9];
 #pragma unroll
-  for (int tp = 0; tp < 9; ++tp) k[tp] = chan_ok ? *reinterpret_cast<const float4*>(wt + (long)tp * C + c4 * 4) : zero4;
+  for (int tp = 0; tp < 9; ++tp) k[tp] = v4_ld(wt + (long)tp * C + c4c);
   const bool affine = in_scale != nullptr;
-  float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = zero4;
-  if (affine && chan_ok) {
-    sc = *reinterpret_cast<const float4*>(in_scale + c4 * 4);
-    sh = *reinterpret_cast<const float4*>(in_shift + c4 * 4);
+  v4f sc = {1.f, 1.f, 1.f, 1.f}, sh = zero4;
+  if (affine) {
+    sc = v4_ld(in_scale + c4c);
+    sh = v4_ld(in_shift + c4c);
   }
-  // input rows r_first .. r_last (clipped to the image: rows outside contribute zeros = SAME padding)
-  const int r_first = h_lo - 1, r_last = h_hi;        // inclusive; r_last may be H (outside)
-  float4 ring[PD], ering[PD];
+  // input rows r_first .. r_last feed output rows h_lo .. h_hi-1; rows outside the image contribute zeros (SAME
+  // padding); loads beyond r_last (the ring runs PD rows ahead) re-read the last row and are never used
+  const int r_first = h_lo - 1, r_last = h_hi;
+  const int r_max = min(r_last, H - 1);
+  v4f ring[PD], ering[PD];
 #pragma unroll
   for (int d = 0; d < PD; ++d) {
-    const int r = r_first + d;
-    const bool rv = r >= 0 && r < H && r <= r_last;
-    ring[d] = (rv && own_ok) ? *reinterpret_cast<const float4*>(po + (long)r * rstride) : zero4;
-    ering[d] = (rv && edge_ok) ? *reinterpret_cast<const float4*>(pe + (long)r * rstride) : zero4;
+    const int ro = min(max(r_first + d, 0), r_max) * rbytes;
+    ring[d] = dw_bl(rs_in, vo, ro);
+    ering[d] = dw_bl(rs_in, ve, ro);
   }
-  float4 a_prev = zero4, a_cur = zero4;
-  for (int r0 = r_first; r0 <= r_last; r0 += PD) {
+  v4f a_prev = zero4, a_cur = zero4;
+  const int niter = (r_last - r_first + PD) / PD;     // ceil(rows / PD)
+  for (int it = 0; it < niter; ++it) {
 #pragma unroll
     for (int d = 0; d < PD; ++d) {
-      const int r = r0 + d;
-      if (r > r_last) break;                          // wave-uniform
-      float4 v1 = ring[d], e = ering[d];
+      const int r = r_first + it * PD + d;
+      v4f v1 = ring[d], e = ering[d];
       {                                               // refill the slot with the row PD ahead
-        const int rn = r + PD;
-        const bool rv = rn < H && rn <= r_last;       // (rn >= 0 always: r >= -1, PD >= 1)
-        ring[d] = (rv && own_ok) ? *reinterpret_cast<const float4*>(po + (long)rn * rstride) : zero4;
-        ering[d] = (rv && edge_ok) ? *reinterpret_cast<const float4*>(pe + (long)rn * rstride) : zero4;
+        const int ro = min(r + PD, r_max) * rbytes;
+        ring[d] = dw_bl(rs_in, vo, ro);
+        ering[d] = dw_bl(rs_in, ve, ro);
       }
-      const bool rin = r >= 0 && r < H;
+      const bool rin = r >= 0 && r < H;               // wave-uniform
       // zero padding must stay zero: the affine / relu only apply to pixels inside the image
-      if (affine) {
-        v1 = (rin && own_ok) ? f4_affine(v1, sc, sh) : zero4;
-        e = (rin && edge_ok) ? f4_affine(e, sc, sh) : zero4;
-      }
-      if (relu_in) { v1 = f4_relu(v1); e = f4_relu(e); }
-      float4 v0 = f4_shfl_up(v1, CL), v2 = f4_shfl_down(v1, CL);
-      if (col == 0) v0 = e;
-      if (col == SW - 1) v2 = e;
+      if (affine) { v1 = v4_fma(v1, sc, sh); e = v4_fma(e, sc, sh); }
+      if (relu_in) { v1 = v4_relu(v1); e = v4_relu(e); }
+      v1 = v4_sel(rin && own_ok, v1, zero4);
+      e = v4_sel(rin && edge_ok, e, zero4);
+      v4f v0 = v4_shfl_up(v1, CL), v2 = v4_shfl_down(v1, CL);
+      v0 = v4_sel(col == 0, e, v0);
+      v2 = v4_sel(col == SW - 1, e, v2);
       // output row t = sum_kh in[t+kh-1] . k[kh]; input row r feeds t = r+1 (kh 0), r (kh 1), r-1 (kh 2)
-      f4_fma(a_prev, v0, k[6]); f4_fma(a_prev, v1, k[7]); f4_fma(a_prev, v2, k[8]);
-      f4_fma(a_cur, v0, k[3]); f4_fma(a_cur, v1, k[4]); f4_fma(a_cur, v2, k[5]);
-      float4 a_next = f4_mul(v0, k[0]);
-      f4_fma(a_next, v1, k[1]); f4_fma(a_next, v2, k[2]);
+      a_prev = v4_fma(v0, k[6], a_prev); a_prev = v4_fma(v1, k[7], a_prev); a_prev = v4_fma(v2, k[8], a_prev);
+      a_cur = v4_fma(v0, k[3], a_cur); a_cur = v4_fma(v1, k[4], a_cur); a_cur = v4_fma(v2, k[5], a_cur);
+      v4f a_next = v0 * k[0];
+      a_next = v4_fma(v1, k[1], a_next); a_next = v4_fma(v2, k[2], a_next);
       const int t = r - 1;                            // completed output row
-      if (t >= h_lo && t < h_hi && own_ok) *reinterpret_cast<float4*>(pout + (long)t * rstride) = a_prev;
+      dw_bs(rs_out, a_prev, (t >= h_lo && t < h_hi) ? vo : DW_OOB, min(max(t, 0), H - 1) * rbytes);
       a_prev = a_cur;
       a_cur = a_next;
     }
@@ -487,7 +513,8 @@ __global__ __launch_bounds__(256) void dw3x3_stream_bwd_kernel(
     const float* __restrict__ bn_invstd, float* __restrict__ bn_partial, const float* __restrict__ bn_x, DwStreamGeom g) {
   constexpr int SW = 64 / CL;
   const int lane = threadIdx.x & 63;
-  long gw = (long)xcd_remap(blockIdx.x, gridDim.x) * 4 + (threadIdx.x >> 6);
+  // (the wave index is uniform: readfirstlane tells the compiler, so that descriptors and row offsets live in SGPRs)
+  long gw = (long)xcd_remap(blockIdx.x, gridDim.x) * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   if (gw >= g.waves) return;                          // whole wave
   const int cc = (int)(gw % g.cchunks); gw /= g.cchunks;
   const long sp = gw;                                 // partial row: (batch, segment, strip)
@@ -495,8 +522,9 @@ __global__ __launch_bounds__(256) void dw3x3_stream_bwd_kernel(
   const int seg = (int)(gw % g.segs);
   const int b = (int)(gw / g.segs);
   const int l = lane % CL, col = lane / CL;
+  const int c4n = C >> 2;
   const int c4 = cc * CL + l, w = strip * SW + col;
-  const bool chan_ok = c4 * 4 < C;
+  const bool chan_ok = c4 < c4n;
   const bool own_ok = chan_ok && w < W;
   const int we = col == 0 ? w - 1 : w + 1;
   const bool edge_lane = col == 0 || col == SW - 1;
@@ -504,106 +532,110 @@ __global__ __launch_bounds__(256) void dw3x3_stream_bwd_kernel(
   const int h_lo = seg * g.rows_per_seg;
   const int h_hi = min(H, h_lo + g.rows_per_seg);     // output rows [h_lo, h_hi)
   const long rstride = (long)W * C;
-  const long obase = (long)b * H * rstride + (long)w * C + c4 * 4;          // own column, + row * rstride
-  const float* pz = dz + obase;
-  const float* pze = dz + (long)b * H * rstride + (long)we * C + c4 * 4;
-  const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
-  float4 k[9], accw[9];
+  const int rbytes = (int)rstride * 4;                // bytes per image row
+  const long ibase = (long)b * H * rstride;
+  const __amdgpu_buffer_rsrc_t rs_dz = dw_rsrc(dz + ibase, H * rbytes), rs_x = dw_rsrc(x + ibase, H * rbytes);
+  const __amdgpu_buffer_rsrc_t rs_dx = dw_rsrc(dx + ibase, H * rbytes);
+  const __amdgpu_buffer_rsrc_t rs_add = dw_rsrc(ADD ? add + ibase : x, ADD ? H * rbytes : 0);
+  const __amdgpu_buffer_rsrc_t rs_bx = dw_rsrc(BNX ? bn_x + ibase : x, BNX ? H * rbytes : 0);
+  const int vo = own_ok ? (w * C + c4 * 4) * 4 : DW_OOB;          // byte offsets inside an image row
+  const int ve = edge_ok ? (we * C + c4 * 4) * 4 : DW_OOB;
+  const int c4c = min(c4, c4n - 1) * 4;               // (clamped: per-channel vectors are fetched by every lane)
+  const v4f zero4 = {0.f, 0.f, 0.f, 0.f};
+  v4f k[9], accw[9];
 #pragma unroll
   for (int tp = 0; tp < 9; ++tp) {
-    k[tp] = chan_ok ? *reinterpret_cast<const float4*>(wt + (long)tp * C + c4 * 4) : zero4;
+    k[tp] = v4_ld(wt + (long)tp * C + c4c);
     accw[tp] = zero4;
   }
-  float4 bsg = zero4, bsgx = zero4;
+  v4f bsg = zero4, bsgx = zero4;
   const bool affine = in_scale != nullptr;
-  float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = zero4, mu = zero4, is = zero4;
-  if (affine && chan_ok) {
-    sc = *reinterpret_cast<const float4*>(in_scale + c4 * 4);
-    sh = *reinterpret_cast<const float4*>(in_shift + c4 * 4);
+  v4f sc = {1.f, 1.f, 1.f, 1.f}, sh = zero4, mu = zero4, is = zero4;
+  if (affine) {
+    sc = v4_ld(in_scale + c4c);
+    sh = v4_ld(in_shift + c4c);
   }
-  if (bn_partial && chan_ok) {
-    mu = *reinterpret_cast<const float4*>(bn_mean + c4 * 4);
-    is = *reinterpret_cast<const float4*>(bn_invstd + c4 * 4);
+  if (bn_partial) {
+    mu = v4_ld(bn_mean + c4c);
+    is = v4_ld(bn_invstd + c4c);
   }
   // dz rows r_first .. r_last feed output rows h_lo .. h_hi-1 (row r completes output row r-1); the centre tensors of
-  // output row t travel in slot (t - h_lo) % PD, fetched when dz row t+1-PD ... i.e. PD output rows ahead
+  // output row t = r - 1 travel in the slot of dz row r (the two rows in front of h_lo are fetched and ignored: the
+  // loop body stays branch-free)
   const int r_first = h_lo - 1, r_last = h_hi;
-  float4 zr[PD], ze[PD], xr[PD], ar[PD], br[PD];
+  const int r_max = min(r_last, H - 1);
+  v4f zr[PD], ze[PD], xr[PD], ar[PD], br[PD];
 #pragma unroll
   for (int d = 0; d < PD; ++d) {
-    const int r = r_first + d;
-    const bool rv = r >= 0 && r < H && r <= r_last;
-    zr[d] = (rv && own_ok) ? *reinterpret_cast<const float4*>(pz + (long)r * rstride) : zero4;
-    ze[d] = (rv && edge_ok) ? *reinterpret_cast<const float4*>(pze + (long)r * rstride) : zero4;
-    const int t = h_lo + d;                           // centre tensors: output rows h_lo .. h_lo+PD-1
-    const bool tv = t < h_hi && own_ok;
-    xr[d] = tv ? *reinterpret_cast<const float4*>(x + obase + (long)t * rstride) : zero4;
-    if (ADD) ar[d] = tv ? *reinterpret_cast<const float4*>(add + obase + (long)t * rstride) : zero4;
-    if (BNX) br[d] = tv ? *reinterpret_cast<const float4*>(bn_x + obase + (long)t * rstride) : zero4;
+    const int ro = min(max(r_first + d, 0), r_max) * rbytes;
+    zr[d] = dw_bl(rs_dz, vo, ro);
+    ze[d] = dw_bl(rs_dz, ve, ro);
+    const int to = min(max(r_first + d - 1, 0), h_hi - 1) * rbytes;       // centre tensors of output row r - 1
+    xr[d] = dw_bl(rs_x, vo, to);
+    if (ADD) ar[d] = dw_bl(rs_add, vo, to);
+    if (BNX) br[d] = dw_bl(rs_bx, vo, to);
   }
-  float4 m0 = zero4, m1 = zero4, m2 = zero4, c0 = zero4, c1 = zero4, c2 = zero4;
-  // slot bookkeeping: dz row r sits in slot (r - r_first) % PD, output row t in slot (t - h_lo) % PD; row r completes
-  // t = r - 1 = h_lo + (r - r_first) - 2, i.e. centre slot (d + PD - 2 % PD) % PD when r is in dz slot d: static per d
-  for (int r0 = r_first; r0 <= r_last; r0 += PD) {
+  // the 3-row dz window as a ring of its own: the row that arrives in step d is written to win[d % 3]; the centre row
+  // is then win[(d+2) % 3] and the previous one win[(d+1) % 3] -- static roles (PD % 3 == 0), no register moves
+  static_assert(PD % 3 == 0, "window roles rotate with the unrolled steps");
+  v4f win[3][3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) win[i][0] = win[i][1] = win[i][2] = zero4;
+  const int niter = (r_last - r_first + PD) / PD;     // ceil(rows / PD)
+  for (int it = 0; it < niter; ++it) {
 #pragma unroll
     for (int d = 0; d < PD; ++d) {
-      const int r = r0 + d;
-      if (r > r_last) break;                          // wave-uniform
-      const float4 n1 = zr[d];
-      const float4 e = ze[d];
+      const int r = r_first + it * PD + d;
+      v4f n1 = zr[d], e = ze[d];
       {
-        const int rn = r + PD;
-        const bool rv = rn < H && rn <= r_last;
-        zr[d] = (rv && own_ok) ? *reinterpret_cast<const float4*>(pz + (long)rn * rstride) : zero4;
-        ze[d] = (rv && edge_ok) ? *reinterpret_cast<const float4*>(pze + (long)rn * rstride) : zero4;
+        const int ro = min(r + PD, r_max) * rbytes;
+        zr[d] = dw_bl(rs_dz, vo, ro);
+        ze[d] = dw_bl(rs_dz, ve, ro);
       }
-      float4 n0 = f4_shfl_up(n1, CL), n2 = f4_shfl_down(n1, CL);
-      if (col == 0) n0 = e;
-      if (col == SW - 1) n2 = e;
+      const bool rin = r >= 0 && r < H;               // wave-uniform (lanes outside the image already read zeros)
+      n1 = v4_sel(rin, n1, zero4);
+      e = v4_sel(rin, e, zero4);
+      v4f n0 = v4_shfl_up(n1, CL), n2 = v4_shfl_down(n1, CL);
+      n0 = v4_sel(col == 0, e, n0);
+      n2 = v4_sel(col == SW - 1, e, n2);
+      win[d % 3][0] = n0; win[d % 3][1] = n1; win[d % 3][2] = n2;
+      const v4f c0 = win[(d + 2) % 3][0], c1 = win[(d + 2) % 3][1], c2 = win[(d + 2) % 3][2];
+      const v4f m0 = win[(d + 1) % 3][0], m1 = win[(d + 1) % 3][1], m2 = win[(d + 1) % 3][2];
       const int t = r - 1;
-      if (t >= h_lo) {                                // wave-uniform; t < h_hi holds since r <= r_last = h_hi
-        constexpr int PDm = PD;
-        const int cs = (d + 2 * PDm - 2) % PDm;       // centre slot of output row t (see above)
-        const float4 raw = xr[cs];
-        float4 ad = zero4, pre = raw;
-        if (ADD) ad = ar[cs];
-        if (BNX) pre = br[cs];
-        {
-          const int tn = t + PD;
-          const bool tv = tn < h_hi && own_ok;
-          xr[cs] = tv ? *reinterpret_cast<const float4*>(x + obase + (long)tn * rstride) : zero4;
-          if (ADD) ar[cs] = tv ? *reinterpret_cast<const float4*>(add + obase + (long)tn * rstride) : zero4;
-          if (BNX) br[cs] = tv ? *reinterpret_cast<const float4*>(bn_x + obase + (long)tn * rstride) : zero4;
-        }
-        float4 a = raw;
-        if (affine) a = f4_affine(raw, sc, sh);
-        const float4 xin = relu_in ? f4_relu(a) : a;
-        // dz[q-d]: kh = 0 -> next row (n*), 1 -> centre (c*), 2 -> previous (m*); kw = 0 -> right (index 2), 2 -> left (0)
-        float4 res = f4_mul(n2, k[0]);
-        f4_fma(res, n1, k[1]); f4_fma(res, n0, k[2]);
-        f4_fma(res, c2, k[3]); f4_fma(res, c1, k[4]); f4_fma(res, c0, k[5]);
-        f4_fma(res, m2, k[6]); f4_fma(res, m1, k[7]); f4_fma(res, m0, k[8]);
-        if (own_ok) {                                 // (lanes outside the image / the channel range hold zeros: skip)
-          f4_fma(accw[0], xin, n2); f4_fma(accw[1], xin, n1); f4_fma(accw[2], xin, n0);
-          f4_fma(accw[3], xin, c2); f4_fma(accw[4], xin, c1); f4_fma(accw[5], xin, c0);
-          f4_fma(accw[6], xin, m2); f4_fma(accw[7], xin, m1); f4_fma(accw[8], xin, m0);
-          if (relu_in) {
-            res.x = a.x > 0.f ? res.x : 0.f; res.y = a.y > 0.f ? res.y : 0.f;
-            res.z = a.z > 0.f ? res.z : 0.f; res.w = a.w > 0.f ? res.w : 0.f;
-          }
-          if (ADD) { res.x += ad.x; res.y += ad.y; res.z += ad.z; res.w += ad.w; }
-          *reinterpret_cast<float4*>(dx + obase + (long)t * rstride) = res;
-          if (bn_partial) {   // res = dL/d(BN output of the producer); xhat from the pre-BN value
-            bsg.x += res.x; bsg.y += res.y; bsg.z += res.z; bsg.w += res.w;
-            bsgx.x = fmaf(res.x, (pre.x - mu.x) * is.x, bsgx.x);
-            bsgx.y = fmaf(res.y, (pre.y - mu.y) * is.y, bsgx.y);
-            bsgx.z = fmaf(res.z, (pre.z - mu.z) * is.z, bsgx.z);
-            bsgx.w = fmaf(res.w, (pre.w - mu.w) * is.w, bsgx.w);
-          }
-        }
+      const v4f raw = xr[d];
+      v4f ad = zero4, pre = raw;
+      if (ADD) ad = ar[d];
+      if (BNX) pre = br[d];
+      {                                               // refill the centre slot with the row PD ahead
+        const int to = min(max(t + PD, 0), h_hi - 1) * rbytes;
+        xr[d] = dw_bl(rs_x, vo, to);
+        if (ADD) ar[d] = dw_bl(rs_add, vo, to);
+        if (BNX) br[d] = dw_bl(rs_bx, vo, to);
       }
-      m0 = c0; m1 = c1; m2 = c2;
-      c0 = n0; c1 = n1; c2 = n2;
+      const bool tin = t >= h_lo && t < h_hi;         // wave-uniform: the first two rows only fill the window
+      v4f a = raw;
+      if (affine) a = v4_fma(raw, sc, sh);
+      const v4f xin = v4_sel(tin && own_ok, relu_in ? v4_relu(a) : a, zero4);
+      // dz[q-d]: kh = 0 -> next row (n*), 1 -> centre (c*), 2 -> previous (m*); kw = 0 -> right (index 2), 2 -> left (0)
+      v4f res = n2 * k[0];
+      res = v4_fma(n1, k[1], res); res = v4_fma(n0, k[2], res);
+      res = v4_fma(c2, k[3], res); res = v4_fma(c1, k[4], res); res = v4_fma(c0, k[5], res);
+      res = v4_fma(m2, k[6], res); res = v4_fma(m1, k[7], res); res = v4_fma(m0, k[8], res);
+      // (xin is zero for lanes / rows that are not output pixels: their tap sums stay untouched)
+      accw[0] = v4_fma(xin, n2, accw[0]); accw[1] = v4_fma(xin, n1, accw[1]); accw[2] = v4_fma(xin, n0, accw[2]);
+      accw[3] = v4_fma(xin, c2, accw[3]); accw[4] = v4_fma(xin, c1, accw[4]); accw[5] = v4_fma(xin, c0, accw[5]);
+      accw[6] = v4_fma(xin, m2, accw[6]); accw[7] = v4_fma(xin, m1, accw[7]); accw[8] = v4_fma(xin, m0, accw[8]);
+      if (relu_in) {
+        res.x = a.x > 0.f ? res.x : 0.f; res.y = a.y > 0.f ? res.y : 0.f;
+        res.z = a.z > 0.f ? res.z : 0.f; res.w = a.w > 0.f ? res.w : 0.f;
+      }
+      if (ADD) res += ad;
+      dw_bs(rs_dx, res, tin ? vo : DW_OOB, min(max(t, 0), H - 1) * rbytes);
+      if (bn_partial) {   // res = dL/d(BN output of the producer); xhat from the pre-BN value
+        const v4f rm = v4_sel(tin && own_ok, res, zero4);
+        bsg += rm;
+        bsgx = v4_fma(rm, (pre - mu) * is, bsgx);
+      }
     }
   }
   // fold the 9 + 2 sums over the SW columns of the wave (butterfly over the column bits of the lane id: fixed order)
@@ -621,10 +653,10 @@ __global__ __launch_bounds__(256) void dw3x3_stream_bwd_kernel(
   }
   if (col == 0 && chan_ok) {
 #pragma unroll
-    for (int tp = 0; tp < 9; ++tp) *reinterpret_cast<float4*>(partial + (sp * 9 + tp) * C + c4 * 4) = accw[tp];
+    for (int tp = 0; tp < 9; ++tp) v4_st(partial + (sp * 9 + tp) * C + c4 * 4, accw[tp]);
     if (bn_partial) {
-      *reinterpret_cast<float4*>(bn_partial + (sp * 2 + 0) * C + c4 * 4) = bsg;
-      *reinterpret_cast<float4*>(bn_partial + (sp * 2 + 1) * C + c4 * 4) = bsgx;
+      v4_st(bn_partial + (sp * 2 + 0) * C + c4 * 4, bsg);
+      v4_st(bn_partial + (sp * 2 + 1) * C + c4 * 4, bsgx);
     }
   }
 }
@@ -959,6 +991,9 @@ extern "C" int spnet_dwconv3x3_tiled_fwd_bnfin(const float* x, const float* w, f
 }
 
 // ---------------------------------------------------------------- streaming entry points
+// Loads in flight per lane: forward 4 rows (own + edge column), backward 3 (dz own + edge, x [, add, bn_x]).  Measured
+// (tools/dw_stream_sweep.py, profiles/r04_b_diag_dw_stream_sweep.txt): twice the depth (8 / 6 rows, 170 / 310+ VGPRs) is
+// never faster, not even on the 12-row planes -- occupancy costs more than the extra round trips save.
 constexpr int DWS_CL = 8, DWS_SW = 64 / DWS_CL, DWS_PD_FWD = 4, DWS_PD_BWD = 3;
 
 // rows_per_seg <= 0: the library's choice -- whole columns unless the plane then gives fewer than ~16 waves per CU, in
@@ -981,6 +1016,19 @@ static DwStreamGeom dw_stream_geom(int B, int H, int W, int C, int rows_per_seg)
   return g;
 }
 
+// Which form is faster for this plane (measured on MI355X with operands beyond the Infinity Cache, tiled / streaming,
+// us at batch 32; profiles/r04_b_diag_dw_stream_sweep.txt):
+//   forward   93x125x64 55 / 39   93x125x128 103 / 71   47x63x128 29 / 23   47x63x256 54 / 40   24x32x256 17 / 15
+//             24x32x728 44 / 37   12x16x728 14.2 / 13.6   6x8x1024 9.0 / 7.4   6x8x1536 10.0 / 8.2      -> always
+//   backward  93x125x64 72 / 59   93x125x128 125 / 113  47x63x128 37 / 34   47x63x256 70 / 63   24x32x256 20.8 / 20.5
+//             24x32x728 54 / 54   12x16x728 17.4 / 19.9   6x8x1536 12.3 / 13.4            -> planes of >= 2,048 pixels
+// (the forward form with the folded BatchNorm finalize, spnet_dwconv3x3_tiled_fwd_bnfin, exists in the tiled form only)
+extern "C" long spnet_dwconv3x3_prefers_stream(int B, int H, int W, int C, int backward) {
+  (void)B; (void)C;
+  if (!backward) return 1;
+  return (long)H * W >= 2048 ? 1 : 0;
+}
+
 // rows of the [rows][9][C] weight-gradient / [rows][2][C] BatchNorm partial buffers the streaming backward leaves
 extern "C" long spnet_dwconv3x3_stream_rows(int B, int H, int W, int C, int rows_per_seg) {
   const DwStreamGeom g = dw_stream_geom(B, H, W, C, rows_per_seg);
@@ -996,6 +1044,7 @@ extern "C" int spnet_dwconv3x3_stream_fwd(const float* x, const float* w, float*
                                           int relu_in, const float* in_scale, const float* in_shift, int rows_per_seg,
                                           void* stream) {
   if ((C & 3) || B < 1 || H < 1 || W < 1) return (int)hipErrorInvalidValue;
+  if ((long)H * W * C * 4 >= (1L << 31)) return (int)hipErrorInvalidValue;       // 32-bit byte offsets inside an image
   const DwStreamGeom g = dw_stream_geom(B, H, W, C, rows_per_seg);
   if ((g.waves + 3) / 4 > 0x7fffffffL) return (int)hipErrorInvalidValue;
   hipLaunchKernelGGL((dw3x3_stream_fwd_kernel<DWS_CL, DWS_PD_FWD>), dim3((unsigned)((g.waves + 3) / 4)), dim3(256), 0,
@@ -1013,6 +1062,7 @@ extern "C" int spnet_dwconv3x3_stream_bwd(const float* dy, const float* x_fwd, c
   if (bn_partial && (!bn_mean || !bn_invstd)) return (int)hipErrorInvalidValue;
   if (bn_x && !bn_partial) return (int)hipErrorInvalidValue;
   if ((C & 3) || B < 1 || H < 1 || W < 1 || !workspace) return (int)hipErrorInvalidValue;
+  if ((long)H * W * C * 4 >= (1L << 31)) return (int)hipErrorInvalidValue;       // 32-bit byte offsets inside an image
   const DwStreamGeom g = dw_stream_geom(B, H, W, C, rows_per_seg);
   if ((g.waves + 3) / 4 > 0x7fffffffL) return (int)hipErrorInvalidValue;
 #define DWS_BWD(ADD, BNX)                                                                                              \

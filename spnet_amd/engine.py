@@ -1363,6 +1363,41 @@ class Ref:
         self.stats_bn, self.stats_x = stats_bn, stats_x
 
 
+def _dw_fwd(x, w, y, B, H, W, C, relu_in, scale_ptr, shift_ptr):
+    """Stride-1 depthwise forward y = dw3x3(relu?(x * scale + shift)): the streaming kernel where the library prefers it
+    (every plane: spnet_dwconv3x3_prefers_stream), else the LDS-tiled one -- same bits either way."""
+    if L.spnet_dwconv3x3_prefers_stream(B, H, W, C, 0):
+        L.spnet_dwconv3x3_stream_fwd(L.ptr(x), L.ptr(w), L.ptr(y), B, H, W, C, relu_in, scale_ptr, shift_ptr, 0, _stream())
+    else:
+        L.spnet_dwconv3x3_tiled_fwd(L.ptr(x), L.ptr(w), L.ptr(y), B, H, W, C, relu_in, scale_ptr, shift_ptr, _stream())
+
+
+class _DwBwdPlan:
+    """Which fused depthwise backward a layer runs (decided once, when the plan is built) and the sizes that follow from
+    it: streaming for planes of >= 2,048 pixels, LDS-tiled below.  rows = partial rows of the [rows][9][C] weight-gradient
+    and [rows][2][C] BatchNorm-sum buffers, ws_floats = floats of the weight-gradient workspace."""
+
+    def __init__(self, B, H, W, C):
+        self.B, self.H, self.W, self.C = B, H, W, C
+        self.stream = bool(L.spnet_dwconv3x3_prefers_stream(B, H, W, C, 1))
+        if self.stream:
+            self.rows = int(L.spnet_dwconv3x3_stream_rows(B, H, W, C, 0))
+            self.ws_floats = int(L.spnet_dwconv3x3_stream_bwd_ws(B, H, W, C, 0))
+        else:
+            self.rows = int(L.spnet_dwconv3x3_tiled_rows(B, H, W, C))
+            self.ws_floats = int(L.spnet_dwconv3x3_tiled_bwd_ws(B, H, W, C))
+
+    def run(self, dz, x, w, dx, relu_in, add, wpart, scale_ptr, shift_ptr, mean_ptr, invstd_ptr, bn_partial_ptr, bn_x):
+        """dx, the weight-gradient partial rows (left in wpart for the batched reduction) and, with bn_partial_ptr, the
+        producer BatchNorm's backward sums."""
+        a = (L.ptr(dz), L.ptr(x), L.ptr(w), L.ptr(dx), None, self.B, self.H, self.W, self.C, relu_in, L.ptr(add),
+             L.ptr(wpart), scale_ptr, shift_ptr, mean_ptr, invstd_ptr, bn_partial_ptr, L.ptr(bn_x))
+        if self.stream:
+            L.spnet_dwconv3x3_stream_bwd(*a, 0, _stream())
+        else:
+            L.spnet_dwconv3x3_tiled_bwd(*a, _stream())
+
+
 class SepConvBN:
     """[affine on load] -> relu? -> depthwise 3x3 -> pointwise (+BN sums in the GEMM epilogue) -> BN.
 
@@ -1385,7 +1420,8 @@ class SepConvBN:
         self.pw = Pointwise(eng, self.M, cin, cout, name + "/pointwise_kernel", defer_wgrad=defer_wgrad)
         self.bn = BN(eng, cout, self.M, name + "_bn")
         self.y = eng.new(B, H, W, cout) if mode == "apply" else None
-        self.rows_src = L.spnet_dwconv3x3_tiled_rows(B, H, W, cin)   # partial rows this unit emits for src.bn
+        self.dwb = _DwBwdPlan(B, H, W, cin)
+        self.rows_src = self.dwb.rows                                # partial rows this unit emits for src.bn
         if self.rows_src * 2 * cin > WS_BNP[1]:
             raise RuntimeError("workspace regions too small for %s" % name)
         self.consumer_rows = 0              # set by the consumer (lazy mode)
@@ -1397,7 +1433,7 @@ class SepConvBN:
             self.dx = eng.new(B, H, W, cin)
             # This unit's depthwise weight-gradient partial sums [rows][9][cin]: kept in a buffer of its own so
             # that ALL units' reductions run as one launch at the end of backward, off the dependency chain.
-            self.wpart = eng.new(L.spnet_dwconv3x3_tiled_bwd_ws(B, H, W, cin))
+            self.wpart = eng.new(self.dwb.ws_floats)
             eng.dw_reduce_jobs.append((self.wpart, self.gwd, self.rows_src, 9 * cin))
             # BatchNorm-backward output dy: written once by the blending data-gradient GEMM for the weight gradient
             # (units with an activation behind their BN take the unfused path and use dbn / the incoming buffer)
@@ -1430,8 +1466,8 @@ class SepConvBN:
                                               sb.invstd_ptr, L.ptr(sb.ss), BN_EPS, BN_MOMENTUM, _stream())
             owner.pending_rows = 0
         else:
-            L.spnet_dwconv3x3_tiled_fwd(L.ptr(self.src.t), L.ptr(self.wd), L.ptr(self.z), e.B, self.H, self.W, self.cin,
-                                        self.relu_in, sb.scale_ptr if sb else None, sb.shift_ptr if sb else None, _stream())
+            _dw_fwd(self.src.t, self.wd, self.z, e.B, self.H, self.W, self.cin, self.relu_in,
+                    sb.scale_ptr if sb else None, sb.shift_ptr if sb else None)
         if prof is not None:
             prof.stop("dw", t0, 2.0 * 4 * self.M * self.cin, ("dw fwd", self.H, self.W, self.cin))   # read x + write z
         if training:
@@ -1475,11 +1511,10 @@ class SepConvBN:
         prof = e.prof
         if prof is not None:
             t0 = prof.start()
-        L.spnet_dwconv3x3_tiled_bwd(L.ptr(self.dz), L.ptr(self.src.t), L.ptr(self.wd), L.ptr(self.dx), None,
-                                    e.B, self.H, self.W, self.cin, self.relu_in, L.ptr(add), L.ptr(self.wpart),
-                                    sb.scale_ptr if sb else None, sb.shift_ptr if sb else None,
-                                    st.mean_ptr if st else None, st.invstd_ptr if st else None,
-                                    e.ws_ptr(WS_BNP) if st else None, L.ptr(self.src.stats_x), _stream())
+        self.dwb.run(self.dz, self.src.t, self.wd, self.dx, self.relu_in, add, self.wpart,
+                     sb.scale_ptr if sb else None, sb.shift_ptr if sb else None,
+                     st.mean_ptr if st else None, st.invstd_ptr if st else None,
+                     e.ws_ptr(WS_BNP) if st else None, self.src.stats_x)
         if prof is not None:
             prof.stop("dw", t0, 3.0 * 4 * self.M * self.cin, ("dw bwd", self.H, self.W, self.cin))   # read dz, read x, write dx
         return self.dx
@@ -2277,16 +2312,16 @@ class MobileBlock(Node):
             self.da = eng.new(B, OH, OW, cin)
             self.dx = eng.new(B, H, W, cin)
             if stride == 1:
-                self.wpart = eng.new(L.spnet_dwconv3x3_tiled_bwd_ws(B, H, W, cin))
-                eng.dw_reduce_jobs.append((self.wpart, self.gwd, L.spnet_dwconv3x3_tiled_rows(B, H, W, cin), 9 * cin))
+                self.dwb = _DwBwdPlan(B, H, W, cin)
+                self.wpart = eng.new(self.dwb.ws_floats)
+                eng.dw_reduce_jobs.append((self.wpart, self.gwd, self.dwb.rows, 9 * cin))
             else:
                 self.ws = eng.new(L.spnet_dwconv3x3_strided_ws(B, H, W, cin, stride))
 
     def fwd(self, training):
         e = self.e
         if self.stride == 1:
-            L.spnet_dwconv3x3_tiled_fwd(L.ptr(self.x), L.ptr(self.wd), L.ptr(self.z), e.B, self.H, self.W, self.cin, 0,
-                                        None, None, _stream())
+            _dw_fwd(self.x, self.wd, self.z, e.B, self.H, self.W, self.cin, 0, None, None)
         else:
             L.spnet_dwconv3x3_strided(0, L.ptr(self.x), L.ptr(self.wd), L.ptr(self.z), e.B, self.H, self.W, self.cin,
                                       self.stride, None, _stream())
@@ -2304,9 +2339,7 @@ class MobileBlock(Node):
         self.pw.bwd(self.bn_dw.y, dy, self.da)
         dz = self.bn_dw.bwd(self.da)
         if self.stride == 1:
-            L.spnet_dwconv3x3_tiled_bwd(L.ptr(dz), L.ptr(self.x), L.ptr(self.wd), L.ptr(self.dx), None, e.B, self.H,
-                                        self.W, self.cin, 0, None, L.ptr(self.wpart), None, None, None, None, None, None,
-                                        _stream())
+            self.dwb.run(dz, self.x, self.wd, self.dx, 0, None, self.wpart, None, None, None, None, None, None)
         else:
             L.spnet_dwconv3x3_strided(1, L.ptr(dz), L.ptr(self.wd), L.ptr(self.dx), e.B, self.H, self.W, self.cin,
                                       self.stride, None, _stream())

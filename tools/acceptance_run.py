@@ -123,13 +123,17 @@ def run_variant(args, tag, adam_eps, data, t_start, t_data, count_range):
     class Clock(callbacks.Callback):
         def __init__(self):
             super().__init__()
-            self.t, self.rows = [], []
+            self.t, self.rows, self.l2 = [], [], []
 
         def on_epoch_begin(self, epoch, logs=None):
             self.t0 = time.time()
 
         def on_epoch_end(self, epoch, logs=None):
             self.t.append(time.time() - self.t0)
+            # 1e-4 * sum(w^2) of each regularised kernel (which of them carry the decay of the l2 penalty)
+            r = self.model._root
+            self.l2.append({n: 1e-4 * float(r.theta[off:off + cnt].double().square().sum().item())
+                            for n, (off, cnt, _) in r.p_off.items() if off < r.l2_n})
             if args.time_budget > 0 and (time.time() - t_start) + 1.3 * max(self.t) + 45 > args.time_budget:
                 print("time budget: stopping after epoch", epoch, flush=True)
                 self.model.stop_training = True
@@ -205,7 +209,7 @@ def run_variant(args, tag, adam_eps, data, t_start, t_data, count_range):
               "seconds": {"data": t_data, "fit": t_fit, "per_epoch_median": float(np.median(clock.t)), "total": time.time() - t_start},
               "train_images_per_sec_incl_validation_and_augmentation": args.train * len(rows) / t_fit,
               "columns": ["epoch", "train_total", "val_total", "my_val_loss", "center", "size", "angle", "noobj", "rings"],
-              "rows": rows, "lr_at_epoch_end": lr_end, "final": final, "bands": dict(BANDS, loss_max_ratio=lm),
+              "rows": rows, "lr_at_epoch_end": lr_end, "l2_by_kernel_at_epoch_end": clock.l2, "final": final, "bands": dict(BANDS, loss_max_ratio=lm),
               "checks": checks, "all_ok": all(c["ok"] for c in checks.values()),
               "reference": {"final": REF["final"], "epoch_rows": {str(k): v for k, v in REF["epoch_rows"].items()}}}
     with open(os.path.join(args.out, "acceptance%s.json" % tag), "w") as f:
@@ -228,6 +232,11 @@ def run_variant(args, tag, adam_eps, data, t_start, t_data, count_range):
         lines.append("%5d %5d | %.3e  %.3e | %.3e  %.3e | %.3e %.3e | %s" % (
             e, ref_ep, r[1], q[0], r[2], q[1], r[2] - sum(r[4:9]), q[1] - sum(q[2:]),
             "  ".join("%.2e/%.2e" % (r[4 + j], q[2 + j]) for j in range(5))))
+    names = list(clock.l2[0]) if clock.l2 else []
+    lines += ["", "l2 penalty by kernel at epoch end (1e-4 * sum w^2): " + "  ".join(n.split("/")[0] for n in names)]
+    for e in sorted(set([0, 1, 2, 3, 4] + list(range(9, len(clock.l2), 10)) + [len(clock.l2) - 1])):
+        if 0 <= e < len(clock.l2):
+            lines.append("  %3d  %s   total %.4f" % (e, "  ".join("%.4f" % clock.l2[e][n] for n in names), sum(clock.l2[e].values())))
     lines += ["", "checks (ours / reference / band):"]
     for k, c in checks.items():
         lines.append("  %-18s %.5g / %.5g   %s" % (k, c["ours"], c["reference"], "ok" if c["ok"] else "OUT OF BAND"))

@@ -19,7 +19,18 @@ shapes = [("b2u1", 93, 125, 64), ("b2u2", 93, 125, 128), ("b3u1", 47, 63, 128), 
           ("b4u2", 24, 32, 728), ("mid", 12, 16, 728), ("b14u1", 6, 8, 1024), ("b14u2", 6, 8, 1536)]
 if os.environ.get("DW_ONLY"):
     shapes = [s_ for s_ in shapes if s_[0] in os.environ["DW_ONLY"].split(",")]
-RPS = [int(v) for v in os.environ.get("DW_RPS", "0,1000,48,24,12").split(",")]
+# rows per wave[:prefetch depth override] (0 = the library's choice)
+def _code(tok):
+    r, _, d = tok.partition(":")
+    return (int(r) & 0xffff) | (int(d or 0) << 16)
+
+
+RPS = [_code(v) for v in os.environ.get("DW_RPS", "0,1000,48,24,12").split(",")]
+RPS_B = [_code(v) for v in os.environ.get("DW_RPS_BWD", os.environ.get("DW_RPS", "0,1000,48,24,12")).split(",")]
+
+
+def _lab(c):
+    return "s%d%s" % (c & 0xffff, (":%d" % (c >> 16)) if c >> 16 else "")
 
 
 def timeit(fn, nrot, iters=30):
@@ -50,31 +61,31 @@ for name, H, W, C in shapes:
                                                           sc.data_ptr(), sh.data_ptr(), st()), nrot)
         line += " fwd tiled %6.1fus %.2fTB/s |" % (t0, 2 * T / t0)
         for rps in RPS:
-            if rps > H and rps != 1000:
+            if (rps & 0xffff) > H and (rps & 0xffff) != 1000:
                 continue
             t1 = timeit(lambda i: L.spnet_dwconv3x3_stream_fwd(xs[i].data_ptr(), w.data_ptr(), ys[i].data_ptr(), B, H, W, C, 1,
                                                                sc.data_ptr(), sh.data_ptr(), rps, st()), nrot)
-            line += " s%-4d %6.1fus %.2f |" % (rps, t1, 2 * T / t1)
+            line += " %-7s %6.1fus %.2f |" % (_lab(rps), t1, 2 * T / t1)
     print(line, flush=True)
     if what in ("bwd", "both"):
         dys = [torch.randn(B, H, W, C, device="cuda") for _ in range(nrot)]
         dxs = [torch.empty_like(xs[0]) for _ in range(nrot)]
         ws = torch.empty(max(L.spnet_dwconv3x3_tiled_bwd_ws(B, H, W, C),
-                             max(L.spnet_dwconv3x3_stream_bwd_ws(B, H, W, C, r) for r in RPS)), device="cuda")
-        rows = max(L.spnet_dwconv3x3_tiled_rows(B, H, W, C), max(L.spnet_dwconv3x3_stream_rows(B, H, W, C, r) for r in RPS))
+                             max(L.spnet_dwconv3x3_stream_bwd_ws(B, H, W, C, r) for r in RPS_B)), device="cuda")
+        rows = max(L.spnet_dwconv3x3_tiled_rows(B, H, W, C), max(L.spnet_dwconv3x3_stream_rows(B, H, W, C, r) for r in RPS_B))
         bnp = torch.empty(rows * 2 * C, device="cuda")
         line = "%-6s %28s |" % (name, "")
         t0 = timeit(lambda i: L.spnet_dwconv3x3_tiled_bwd(dys[i].data_ptr(), xs[i].data_ptr(), w.data_ptr(), dxs[i].data_ptr(), None, B,
                                                           H, W, C, 1, None, ws.data_ptr(), sc.data_ptr(), sh.data_ptr(),
                                                           mu.data_ptr(), isd.data_ptr(), bnp.data_ptr(), None, st()), nrot)
         line += " bwd tiled %6.1fus %.2fTB/s |" % (t0, 3 * T / t0)
-        for rps in RPS:
-            if rps > H and rps != 1000:
+        for rps in RPS_B:
+            if (rps & 0xffff) > H and (rps & 0xffff) != 1000:
                 continue
             t1 = timeit(lambda i: L.spnet_dwconv3x3_stream_bwd(dys[i].data_ptr(), xs[i].data_ptr(), w.data_ptr(), dxs[i].data_ptr(), None,
                                                                B, H, W, C, 1, None, ws.data_ptr(), sc.data_ptr(), sh.data_ptr(),
                                                                mu.data_ptr(), isd.data_ptr(), bnp.data_ptr(), None, rps, st()), nrot)
-            line += " s%-4d %6.1fus %.2f |" % (rps, t1, 3 * T / t1)
+            line += " %-7s %6.1fus %.2f |" % (_lab(rps), t1, 3 * T / t1)
         print(line, flush=True)
         del dys, dxs
     del xs, ys
