@@ -401,6 +401,9 @@ constexpr int DW_OOB = 0x7ffffff0;
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t dw_rsrc(const float* p, int bytes) {
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p), 0, bytes, 0x00020000);
 }
+// (cache policy left at the default: nontemporal stores bought +5 % on the 93x125 / 47x63 planes in isolation and cost
+// 7-25 % on the 24x32 / 12x16 ones, nontemporal loads cost everywhere -- the edge columns and row-segment halos live
+// on cache hits; profiles/r04_b_diag_dw_stream_sweep.txt)
 __device__ __forceinline__ v4f dw_bl(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
   return __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
 }
@@ -996,18 +999,19 @@ extern "C" int spnet_dwconv3x3_tiled_fwd_bnfin(const float* x, const float* w, f
 // never faster, not even on the 12-row planes -- occupancy costs more than the extra round trips save.
 constexpr int DWS_CL = 8, DWS_SW = 64 / DWS_CL, DWS_PD_FWD = 4, DWS_PD_BWD = 3;
 
-// rows_per_seg <= 0: the library's choice -- whole columns unless the plane then gives fewer than ~16 waves per CU, in
-// which case the rows are cut into segments (2 halo rows re-read per segment) of at least 8 rows
-static DwStreamGeom dw_stream_geom(int B, int H, int W, int C, int rows_per_seg) {
+// rows_per_seg <= 0: the library's choice.  Backward: whole columns always (a segment re-reads 2 halo rows of dz AND adds
+// a partial row; measured slower on every plane).  Forward: whole columns from 8 waves per CU on; below that the rows are
+// cut into segments (2 halo rows re-read per segment, served by the cache) of at least 6 rows until the launch has ~16
+// waves per CU (93x125x64 at batch 32: 46 -> 39 us with 24-row segments; 12x16x728: 13.6 -> 12.5 us with 6-row ones).
+static DwStreamGeom dw_stream_geom(int B, int H, int W, int C, int rows_per_seg, bool backward) {
   DwStreamGeom g;
   g.strips = (W + DWS_SW - 1) / DWS_SW;
   g.cchunks = (C / 4 + DWS_CL - 1) / DWS_CL;
   const long base = (long)B * g.strips * g.cchunks;
   if (rows_per_seg <= 0) {
-    long segs = (4096 + base - 1) / base;
-    if (segs < 1) segs = 1;
+    long segs = (backward || base >= 2048) ? 1 : (4096 + base - 1) / base;
     rows_per_seg = (int)((H + segs - 1) / segs);
-    if (rows_per_seg < 8) rows_per_seg = 8;
+    if (rows_per_seg < 6) rows_per_seg = 6;
   }
   if (rows_per_seg > H) rows_per_seg = H;
   g.rows_per_seg = rows_per_seg;
@@ -1031,7 +1035,7 @@ extern "C" long spnet_dwconv3x3_prefers_stream(int B, int H, int W, int C, int b
 
 // rows of the [rows][9][C] weight-gradient / [rows][2][C] BatchNorm partial buffers the streaming backward leaves
 extern "C" long spnet_dwconv3x3_stream_rows(int B, int H, int W, int C, int rows_per_seg) {
-  const DwStreamGeom g = dw_stream_geom(B, H, W, C, rows_per_seg);
+  const DwStreamGeom g = dw_stream_geom(B, H, W, C, rows_per_seg, true);
   return (long)B * g.segs * g.strips;
 }
 
@@ -1045,7 +1049,7 @@ extern "C" int spnet_dwconv3x3_stream_fwd(const float* x, const float* w, float*
                                           void* stream) {
   if ((C & 3) || B < 1 || H < 1 || W < 1) return (int)hipErrorInvalidValue;
   if ((long)H * W * C * 4 >= (1L << 31)) return (int)hipErrorInvalidValue;       // 32-bit byte offsets inside an image
-  const DwStreamGeom g = dw_stream_geom(B, H, W, C, rows_per_seg);
+  const DwStreamGeom g = dw_stream_geom(B, H, W, C, rows_per_seg, false);
   if ((g.waves + 3) / 4 > 0x7fffffffL) return (int)hipErrorInvalidValue;
   hipLaunchKernelGGL((dw3x3_stream_fwd_kernel<DWS_CL, DWS_PD_FWD>), dim3((unsigned)((g.waves + 3) / 4)), dim3(256), 0,
                      (hipStream_t)stream, x, w, y, H, W, C, relu_in, in_scale, in_shift, g);
@@ -1063,7 +1067,7 @@ extern "C" int spnet_dwconv3x3_stream_bwd(const float* dy, const float* x_fwd, c
   if (bn_x && !bn_partial) return (int)hipErrorInvalidValue;
   if ((C & 3) || B < 1 || H < 1 || W < 1 || !workspace) return (int)hipErrorInvalidValue;
   if ((long)H * W * C * 4 >= (1L << 31)) return (int)hipErrorInvalidValue;       // 32-bit byte offsets inside an image
-  const DwStreamGeom g = dw_stream_geom(B, H, W, C, rows_per_seg);
+  const DwStreamGeom g = dw_stream_geom(B, H, W, C, rows_per_seg, true);
   if ((g.waves + 3) / 4 > 0x7fffffffL) return (int)hipErrorInvalidValue;
 #define DWS_BWD(ADD, BNX)                                                                                              \
   hipLaunchKernelGGL((dw3x3_stream_bwd_kernel<DWS_CL, DWS_PD_BWD, ADD, BNX>), dim3((unsigned)((g.waves + 3) / 4)),     \
