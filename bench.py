@@ -398,6 +398,60 @@ def layout_331_measure(dev, steps=20, warmup=3):
     return out
 
 
+def backbone_leg(dev, backbone, batch, steps=20, warmup=5, predict=False):
+    """The other two backbones of BASELINE.json's configs in the driver-witnessed line: configs[3] (Inception-ResNet-v2,
+    batch 16) and configs[0]'s model on the GPU (MobileNet, batch 8), 512x384 frames (spnet/models.py:346-359,
+    spnet/config.py:50-52).  Full train steps (forward, custom_loss, backward, Adam + l2) on uniform-noise frames; the
+    GEMM family against the fp32 MFMA peak from HIP events; optionally the inference forward of the same batch size."""
+    import torch
+    from spnet_amd.engine import Engine
+    eng = Engine(H, W, batch, device=str(dev), seed=0, backbone=backbone)
+    X = torch.rand(batch, H, W, 1, device=dev) * 2 - 1
+    Y = torch.rand(batch, 576, device=dev)
+
+    def step():
+        eng.train_step(X, Y, 1e-5)
+
+    for _ in range(warmup):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    out = {"workload": "%s, 512x384 frames, batch %d, full train step, uniform-noise frames" % (backbone, batch),
+           "train_images_per_sec": round(batch * steps / dt, 1), "ms_per_step": round(1e3 * dt / steps, 3), "steps": steps,
+           "batch": batch}
+    tot = time_families(eng, step, max(5, steps // 2), torch.cuda.synchronize).totals()
+    n_prof = max(5, steps // 2)
+    if "gemm" in tot:
+        g_n, g_ms, g_flop = tot["gemm"]
+        tf = g_flop / (g_ms * 1e-3) / 1e12
+        out["roofline"] = {"kernel": "fp32 MFMA GEMM family (every convolution / dense layer of this backbone)",
+                           "bound": "mfma", "achieved": round(tf, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                           "frac": round(tf / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                           "launches_per_step": g_n / n_prof, "ms_per_step": round(g_ms / n_prof, 3),
+                           "algorithmic_flops_per_step": round(g_flop / n_prof),
+                           "measured": "HIP events around every GEMM launch during %d extra steps, each behind two untimed ones" % n_prof}
+    del eng
+    torch.cuda.empty_cache()
+    if predict:
+        eng = Engine(H, W, batch, device=str(dev), seed=0, backbone=backbone, train=False)
+        eng.x_in.copy_(X)
+        for _ in range(warmup):
+            eng.predict_step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            eng.predict_step()
+        torch.cuda.synchronize()
+        out["predict_frames_per_sec"] = round(batch * steps / (time.perf_counter() - t0), 1)
+        del eng
+        torch.cuda.empty_cache()
+    return out
+
+
 def bf16x3_alt_measure(dev, iters=200):
     """`roofline_alt` (optional part): the bf16x3 operand-split probe (tools/probes/gemm_bf16x3.hip, a library of its own: six bf16
     MFMAs with fp32 accumulation per product block) beside the exact fp32 MFMA kernel on the network's dominant forward
@@ -808,6 +862,8 @@ def run(args):
             torch.cuda.empty_cache()
             result["predict"] = predict_measure(X_pool[:min(args.pool, 2048) // 128 * 128], dev, 10, 2)
             result["layout_331"] = layout_331_measure(dev)
+            result["irv2"] = backbone_leg(dev, "InceptionResNetV2", 16, predict=True)          # BASELINE configs[3]
+            result["mobilenet"] = backbone_leg(dev, "MobileNet", 8)                            # configs[0]'s model
             from tools.probes import probe_lib
             if probe_lib.available():      # (the probe library is not part of the product: tools/probes/Makefile)
                 result["roofline_alt"] = bf16x3_alt_measure(dev)

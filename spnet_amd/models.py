@@ -133,6 +133,11 @@ class InterleaveColumns:
 ADAM_EPS = 1e-7
 
 
+def _l2_coef():
+    from .engine import L2_COEF
+    return L2_COEF
+
+
 class _Optimizer:
     def __init__(self, lr=1e-5):
         self.lr = lr
@@ -515,7 +520,12 @@ class Model:
             logs = {"loss": data_loss + float(ls[1])}         # Keras reports data loss + regularisation
             if validation_data is not None and rank == 0:
                 Xv, Yv = validation_data[0], validation_data[1]
-                logs["val_loss"] = custom_loss(Yv, self.predict(Xv, batch_size=batch_size)) + float(ls[1])
+                # Keras evaluates the validation loss at the END of the epoch with the weights as they then are: the
+                # regularisation term of val_loss is the l2 penalty of the current kernels (round 4: it used to be the
+                # epoch MEAN of the training steps' penalties, which made the logged penalty lag half an epoch behind the
+                # reference's -- 0.2415 logged against 0.2171 actual after epoch 1, reference log 0.2204)
+                l2_now = _l2_coef() * float(eng.theta[:eng.l2_n].double().square().sum().item())
+                logs["val_loss"] = custom_loss(Yv, self.predict(Xv, batch_size=batch_size)) + l2_now
             history["loss"].append(logs["loss"])
             history["val_loss"].append(logs.get("val_loss"))
             if chatty:

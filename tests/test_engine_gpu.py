@@ -199,6 +199,28 @@ def test_graph_replayed_training_invalidates_inference_coefficients():
     np.testing.assert_allclose(outs[1].numpy(), outs[0].numpy(), rtol=0, atol=1e-5)
 
 
+def test_one_stream_step_equals_two_stream_step(monkeypatch):
+    """SPNET_OVERLAP_WGRAD=0 (weight gradients on the main stream instead of the side stream that is joined before
+    Adam; what bench.py's roofline leg runs): the same arithmetic in another launch order -- weights, Adam moments and
+    losses of three steps are bit-identical to the two-stream plan's."""
+    _need_gpu()
+    from spnet_amd.engine import Engine
+    h, w, b = 96, 128, 2
+    rs = np.random.RandomState(8)
+    X = torch.tensor(rs.rand(b, h, w, 1) * 2 - 1, dtype=torch.float32).cuda()
+    Y = torch.tensor(rs.rand(b, 576), dtype=torch.float32).cuda()
+    res = []
+    for overlap in ("1", "0"):
+        monkeypatch.setenv("SPNET_OVERLAP_WGRAD", overlap)
+        eng = Engine(h, w, b, device="cuda:0", seed=13)
+        assert (eng.wgrad_stream is not None) == (overlap == "1")
+        losses = [eng.train_step(X, Y, 1e-3).clone() for _ in range(3)]
+        torch.cuda.synchronize()
+        res.append((eng.theta.clone(), eng.m.clone(), eng.v.clone(), torch.stack(losses)))
+    for a, c in zip(res[0], res[1]):
+        assert torch.equal(a, c)
+
+
 def test_graph_capture_survives_garbage_of_an_earlier_plan():
     """The abort of round 3 (`Fatal Python error: Aborted ... Garbage-collecting` under predict_step), reproduced on
     purpose in a child process: an earlier plan's graph / streams / events reachable only through reference cycles, the

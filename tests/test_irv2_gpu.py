@@ -237,6 +237,67 @@ def test_irv2_forward_and_gradients(H, W, B, seed):
             np.testing.assert_allclose(sd[k].numpy(), P64[k].numpy(), rtol=1e-4, atol=1e-5, err_msg=k)
 
 
+def test_irv2_bench_geometry():
+    """BASELINE configs[3] at the geometry bench.py runs it: Inception-ResNet-v2, 384x512 frames, batch 16.  The batch-16
+    plans are the only ones that execute the in-step autotuned entries of spnet_amd/gemm_tiles.json (32x64 / 32x32 tiles,
+    the gathered-A convolutions on them).  Inference: frames 0-1 against the oracle, all 16 against the batch-2 plan of
+    the same weights (other tiles for most GEMMs: equal to rounding, not to the bit), captured replay == eager.
+    Training (the fp64 oracle on the device's decisions checks every gradient at 288x224 / 235x301, batch 2-3; at this
+    size it would take minutes): the batch-16 plan gives finite gradients, reproduces itself bit for bit from the same
+    state, and reduces the loss over six optimizer steps."""
+    _need_gpu()
+    from spnet_amd.engine import Engine, TILE_TABLE
+    H, W = 384, 512
+    P, X2, _, _, _ = make_case(H, W, 2, 5, basemodel="InceptionResNetV2")
+    rs = np.random.RandomState(6)
+    X = torch.tensor(rs.rand(16, H, W, 1) * 2 - 1, dtype=torch.float32)
+    X[:2] = X2
+    e16 = Engine(H, W, 16, device="cuda:0", seed=1, backbone="InceptionResNetV2", train=False)
+    e16.load_state_dict(P)
+    y16 = e16.forward(X.cuda(), training=False).cpu().clone()
+    assert y16.shape == (16, 576) and bool(torch.isfinite(y16).all())
+    want = T.forward(P, X2, training=False)
+    assert_forward_mse(y16[:2], want)
+    e2 = Engine(H, W, 2, device="cuda:0", seed=1, backbone="InceptionResNetV2", train=False)
+    e2.load_state_dict(P)
+    scale = float(y16.abs().max())
+    for lo in range(0, 16, 2):
+        y2 = e2.forward(X[lo:lo + 2].cuda(), training=False).cpu()
+        np.testing.assert_allclose(y16[lo:lo + 2].numpy(), y2.numpy(), rtol=1e-4, atol=1e-5 * scale)
+    # the batch-16 plan really runs autotuned tiles (the table is keyed by M = 16 x pixels: nothing at batch 2 hits it)
+    net = [n for n in e16.nodes if hasattr(n, "ops")][0]
+    Ms = {o.M for o in net.ops if hasattr(o, "M")}
+    assert any(k[3] in Ms for k in TILE_TABLE), "no autotuned entry matches the batch-16 plan"
+    # captured replay == eager, twice
+    e16.x_in.copy_(X.cuda())
+    a = e16.predict_step().clone()
+    b = e16.predict_step().clone()
+    assert torch.equal(a, b) and torch.equal(a.cpu(), y16)
+    del e2, e16
+    torch.cuda.empty_cache()
+    # training plan at batch 16: finite loss / gradients, deterministic, and the loss falls over a few steps
+    t16 = Engine(H, W, 16, device="cuda:0", seed=1, backbone="InceptionResNetV2")
+    t16.load_state_dict(P)
+    Y = torch.tensor(rs.rand(16, 576), dtype=torch.float32)
+    Y[:, 6::8] = (Y[:, 6::8] > 0.5).float()
+    t16.set_drop_seed(11)
+    t16.forward(X.cuda(), training=True)
+    l0 = t16.loss(Y.cuda()).clone()
+    t16.backward()
+    torch.cuda.synchronize()
+    g0 = t16.grad.clone()
+    assert bool(torch.isfinite(g0).all()) and float(g0.abs().max()) > 0
+    t16.load_state_dict(P)                      # moving statistics back to P: the second pass must reproduce the first
+    t16.set_drop_seed(11)
+    t16.forward(X.cuda(), training=True)
+    l1 = t16.loss(Y.cuda()).clone()
+    t16.backward()
+    torch.cuda.synchronize()
+    assert torch.equal(l0, l1) and torch.equal(g0, t16.grad)
+    losses = [float(t16.train_step(X.cuda(), Y.cuda(), 3e-4)[5]) for _ in range(6)]
+    assert np.all(np.isfinite(losses)) and losses[-1] < losses[0], losses
+
+
 def test_irv2_trains_through_the_model_api():
     """BASELINE configs[3] plumbing: cf.basemodel = 'InceptionResNetV2', batch 16 -- a few optimizer steps through
     Model.fit reduce the loss; predict is deterministic."""
