@@ -128,8 +128,9 @@ class InterleaveColumns:
 
 # ----------------------------------------------------------------------------- model object
 # epsilon of keras.optimizers.Adam as the reference constructs it (Adam(lr=0.00001), spnet/models.py:494): Keras 2.1.3's
-# default is epsilon=None -> K.epsilon() = 1e-7 (earlier releases: 1e-8).  Unpinned by any Keras run here; DESIGN.md
-# section 1b records which value the early training dynamics of the reference's published run select.
+# default is epsilon=None -> K.epsilon() = 1e-7 (earlier releases: 1e-8).  No Keras run can pin it here; the early
+# training dynamics of the reference's published run select 1e-7 (l2 penalty after epoch 1: 0.2203 against the log's
+# 0.2204, 0.2187 with 1e-8; DESIGN.md section 1c, profiles/r04_early2_d06_*).
 ADAM_EPS = 1e-7
 
 
