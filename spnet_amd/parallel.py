@@ -49,6 +49,12 @@ def init_distributed(backend=None, force=False):
             backend = os.environ.get("SPNET_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
+        if backend == "nccl":
+            # a failed RCCL init / collective then says why in this rank's stderr (bench.py relays the failing rank's tail).
+            # The channel count is left at RCCL's default: what a collective costs the step underneath it depends on how
+            # LONG it holds CUs, hardly on how many (tools/channel_hog.py) -- fewer channels = a longer
+            # collective = more of the backward disturbed.
+            os.environ.setdefault("NCCL_DEBUG", "WARN")
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, local_rank, world
 
