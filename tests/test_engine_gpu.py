@@ -214,7 +214,7 @@ def test_one_stream_step_equals_two_stream_step(monkeypatch):
         monkeypatch.setenv("SPNET_OVERLAP_WGRAD", overlap)
         eng = Engine(h, w, b, device="cuda:0", seed=13)
         assert (eng.wgrad_stream is not None) == (overlap == "1")
-        losses = [eng.train_step(X, Y, 1e-3).clone() for _ in range(3)]
+        losses = [eng.train_step(X, Y, 1e-3)[:7].clone() for _ in range(3)]      # (slot 7 of loss_out is unused)
         torch.cuda.synchronize()
         res.append((eng.theta.clone(), eng.m.clone(), eng.v.clone(), torch.stack(losses)))
     for a, c in zip(res[0], res[1]):
