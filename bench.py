@@ -686,7 +686,7 @@ def run(args):
         i = it[0]
         it[0] += 1
         aug.apply(drawn[0], eng.x_in)
-        torch.index_select(Y_pool, 0, aug.index_dev, out=eng.y_true)      # the indices travelled with the parameters
+        L.gather_rows(Y_pool, aug.index_dev, eng.y_true)      # the indices travelled with the parameters
         out = eng.train_step(None, None, float(lrs[i % len(lrs)]), reducer=reducer)
         drawn[0] = aug.draw(batch_indices(i + 1))
         return out

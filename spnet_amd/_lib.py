@@ -104,6 +104,7 @@ _SIGS = {
     "spnet_calc_errors": (c_int, [P, P, c_long, c_int, P, P, P]),
     "spnet_adam_step": (c_int, [P, P, P, P, c_long, c_long, c_float, c_float, c_float, c_float, c_float, c_float, P, P, P, P, P]),
     "spnet_u8_to_input": (c_int, [P, P, c_long, P]),
+    "spnet_gather_rows": (c_int, [P, c_long, P, c_int, P, c_int, c_long, P]),
     "spnet_minmax": (c_int, [P, c_int, c_long, P, P, P]),
     "spnet_cutout": (c_int, [P, P, P, c_int, c_int, c_int, P, P, P, P]),
     "spnet_saltpepper": (c_int, [P, c_int, c_int, c_int, P, c_int, c_int, P, P, P]),
@@ -158,6 +159,17 @@ def _resolve_current_stream():
 
 
 current_stream, STREAM_ACCESSOR = _resolve_current_stream()
+
+
+def gather_rows(src, index, dst):
+    """dst[i] = src[index[i]] over the leading axis (device tensors; fp32 rows, int32 / int64 index) on the current stream."""
+    n = int(index.numel())
+    rows = int(src.shape[0])
+    L_ = src.numel() // max(rows, 1)
+    if dst.numel() != n * L_ or src.dtype != torch.float32 or dst.dtype != torch.float32 or not (src.is_contiguous() and dst.is_contiguous()):
+        raise ValueError("gather_rows: shape / dtype / layout mismatch")
+    ib = {torch.int32: 4, torch.int64: 8}[index.dtype]
+    spnet_gather_rows(src.data_ptr(), rows, index.data_ptr(), ib, dst.data_ptr(), n, L_, current_stream())
 
 
 def ptr(t):

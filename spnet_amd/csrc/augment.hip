@@ -320,3 +320,35 @@ extern "C" int spnet_u8_to_input(const unsigned char* src, float* dst, long n, v
   hipLaunchKernelGGL(u8_to_input_kernel, dim3(spnet_ew_grid((n + 15) / 16, 256)), dim3(256), 0, (hipStream_t)stream, src, dst, n);
   SPNET_RETURN_LAUNCH_STATUS();
 }
+
+// ------------------------------------------------------------------------------------------------
+// Batch assembly: dst[i][:] = src[index[i]][:] for n rows of L floats (L % 4 == 0) -- the minibatch of frames / targets
+// picked out of the resident training set by the epoch's shuffled index (Keras' fit does this on the host:
+// train_spnet.py:75,81).  index: int32 or int64 (idx_bytes 4 | 8) on the device.  Pure copy: 16 bytes per lane.
+// ------------------------------------------------------------------------------------------------
+template <class IT>
+__global__ __launch_bounds__(256) void gather_rows_kernel(const float* __restrict__ src, const IT* __restrict__ index,
+                                                          float* __restrict__ dst, int n, long l4, long src_rows) {
+  const long total = (long)n * l4;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long r = i / l4, c = i - r * l4;
+    long s = (long)index[r];
+    s = s < 0 ? 0 : (s >= src_rows ? src_rows - 1 : s);        // (an out-of-range index must not fault the device)
+    reinterpret_cast<float4*>(dst)[i] = reinterpret_cast<const float4*>(src)[s * l4 + c];
+  }
+}
+
+extern "C" int spnet_gather_rows(const float* src, long src_rows, const void* index, int idx_bytes, float* dst, int n, long L,
+                                 void* stream) {
+  if (!src || !index || !dst || n < 0 || L < 4 || (L & 3) || src_rows < 1 || (idx_bytes != 4 && idx_bytes != 8) ||
+      (((uintptr_t)src | (uintptr_t)dst) & 15))
+    return (int)hipErrorInvalidValue;
+  if (n == 0) return 0;
+  const long l4 = L / 4;
+  const dim3 grid(spnet_ew_grid((long)n * l4, 256));
+  if (idx_bytes == 4)
+    hipLaunchKernelGGL(gather_rows_kernel<int>, grid, dim3(256), 0, (hipStream_t)stream, src, (const int*)index, dst, n, l4, src_rows);
+  else
+    hipLaunchKernelGGL(gather_rows_kernel<long long>, grid, dim3(256), 0, (hipStream_t)stream, src, (const long long*)index, dst, n, l4, src_rows);
+  SPNET_RETURN_LAUNCH_STATUS();
+}

@@ -481,6 +481,7 @@ class Model:
         world, rank = self.world, self.rank
         reducer = eng.make_reducer() if world > 1 else None
         Yd = torch.from_numpy(np.ascontiguousarray(Y, dtype=np.float32)).to(eng.dev) if isinstance(Y, np.ndarray) else Y
+        Yd = Yd.to(eng.dev).float().contiguous()
         N = Yd.shape[0]
         chatty = verbose and rank == 0
         for cb in callbacks:
@@ -497,6 +498,8 @@ class Model:
             for cb in callbacks:
                 cb.on_epoch_begin(epoch, {})
             Xd = self._device_frames(X)
+            if Xd.dtype != torch.float32 or not Xd.is_contiguous():
+                Xd = Xd.float().contiguous()
             if world > 1:
                 index = self.epoch_indices
             else:
@@ -510,8 +513,8 @@ class Model:
                 for cb in callbacks:
                     cb.on_batch_begin(b, {})
                 idx = upload("idx", index[b * batch_size:(b + 1) * batch_size])
-                torch.index_select(Xd, 0, idx, out=eng.x_in)
-                torch.index_select(Yd, 0, idx, out=eng.y_true)
+                L.gather_rows(Xd, idx, eng.x_in)
+                L.gather_rows(Yd, idx, eng.y_true)
                 out = eng.train_step(None, None, float(self.optimizer.lr), reducer=reducer)
                 loss_sum += out[5:7].double()
                 if chatty and (b % max(1, nb // 20) == 0 or b == nb - 1):

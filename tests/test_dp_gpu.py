@@ -11,6 +11,14 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    """A TCP port that is free right now on 127.0.0.1 (fixed rendezvous ports collide when two suites share a host)."""
+    import socket
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        return str(so.getsockname()[1])
 HELPER = os.path.join(ROOT, "tests", "helpers", "dp_train_small.py")
 
 
@@ -23,7 +31,7 @@ def test_two_rank_data_parallel_equals_single_process(tmp_path):
     r = subprocess.run([sys.executable, HELPER, single, "3"], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
-                        "--master-addr", "127.0.0.1", "--master-port", "29713", HELPER, dp, "3"],
+                        "--master-addr", "127.0.0.1", "--master-port", _free_port(), HELPER, dp, "3"],
                        env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     a, b = np.load(single), np.load(dp)
@@ -41,7 +49,7 @@ def test_bucketed_allreduce_through_rccl_on_one_rank(tmp_path):
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
     env = dict(os.environ, PYTHONPATH=ROOT, HSA_ENABLE_IPC_MODE_LEGACY="0", RANK="0", LOCAL_RANK="0", WORLD_SIZE="1",
-               MASTER_ADDR="127.0.0.1", MASTER_PORT="29717")
+               MASTER_ADDR="127.0.0.1", MASTER_PORT=_free_port())
     env.pop("SPNET_DIST_BACKEND", None)
     single, rccl = str(tmp_path / "single.npz"), str(tmp_path / "rccl.npz")
     r = subprocess.run([sys.executable, HELPER, single, "3"], env=env, capture_output=True, text=True, timeout=600)
@@ -70,7 +78,7 @@ def test_two_rank_training_through_train_network(tmp_path):
     env = dict(os.environ, PYTHONPATH=ROOT, SPNET_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0",
                SPNET_DUMP_WEIGHT_SUM=str(work / "wsum"))
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
-                        "--master-addr", "127.0.0.1", "--master-port", "29719", os.path.join(ROOT, "train_spnet.py"),
+                        "--master-addr", "127.0.0.1", "--master-port", _free_port(), os.path.join(ROOT, "train_spnet.py"),
                         "-d", str(data), "-b", "8", "-e", "2", "--name", "dp"], cwd=str(work), env=env,
                        capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + "\n" + r.stderr[-3000:]

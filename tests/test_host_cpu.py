@@ -13,6 +13,14 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def _free_port():
+    """A TCP port that is free right now on 127.0.0.1 (fixed rendezvous ports collide when two suites share a host)."""
+    import socket
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        return str(so.getsockname()[1])
+
+
 def test_library_exports_every_declared_symbol():
     from spnet_amd import _lib
     hdr = open(os.path.join(ROOT, "include", "spnet_hip.h")).read()
@@ -217,9 +225,10 @@ def test_gradient_allreduce_and_sharding_on_gloo(tmp_path, world):
     script = tmp_path / "w.py"
     script.write_text(_WORKER)
     procs = []
+    port = _free_port()
     for r in range(world):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
-                   MASTER_PORT="29631")
+                   MASTER_PORT=port)
         procs.append(subprocess.Popen([sys.executable, str(script), ROOT], env=env, stdout=subprocess.PIPE,
                                       stderr=subprocess.STDOUT, text=True))
     outs = [p.communicate(timeout=180)[0] for p in procs]
@@ -285,7 +294,7 @@ def test_bench_self_launches_its_ranks_on_gloo():
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["n_ranks_seen"] == 2 and out["collective_backend"] == "gloo"
     # a rank that fails makes the parent fail (the WORLD_SIZE / --gpus mismatch inside a launched job)
-    env2 = dict(env, WORLD_SIZE="3", RANK="0", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29631")
+    env2 = dict(env, WORLD_SIZE="3", RANK="0", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=_free_port())
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--launch-check"],
                        capture_output=True, text=True, timeout=120, env=dict(env2, WORLD_SIZE="1"))
     assert r.returncode != 0 and "WORLD_SIZE" in (r.stderr + r.stdout)

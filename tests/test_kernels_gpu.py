@@ -1041,3 +1041,21 @@ def test_calc_errors_on_device_matches_host(L):
     assert host[:7] == devr[:7] and sum(host[:7]) > 0
     np.testing.assert_allclose(devr[7], host[7], rtol=1e-6)
     assert host[8] == devr[8]
+
+
+@pytest.mark.parametrize("idx_dtype", [torch.int32, torch.int64])
+def test_gather_rows(L, idx_dtype):
+    """Batch assembly (the minibatch gather of Model.fit / bench.py): dst[i] = src[index[i]], bit for bit; indices
+    outside the set are clamped instead of faulting; misaligned rows are refused."""
+    rs = np.random.RandomState(4)
+    src = dev(rs.randn(37, 6, 10, 2))                     # rows of 120 floats
+    idx = torch.tensor(rs.randint(0, 37, 16), dtype=idx_dtype, device="cuda")
+    dst = torch.full((16, 6, 10, 2), float("nan"), device="cuda")
+    L.gather_rows(src, idx, dst)
+    assert torch.equal(dst, src[idx.long()])
+    bad = torch.tensor([-3, 99, 5], dtype=idx_dtype, device="cuda")
+    d3 = torch.full((3, 6, 10, 2), float("nan"), device="cuda")
+    L.gather_rows(src, bad, d3)
+    assert torch.equal(d3, src[torch.tensor([0, 36, 5], device="cuda")])
+    with pytest.raises(L.HipError):                       # rows of 6 floats: not a multiple of 4
+        L.spnet_gather_rows(src.data_ptr(), 37, idx.data_ptr(), idx.element_size(), dst.data_ptr(), 16, 6, st())
