@@ -1134,13 +1134,15 @@ class BatchNorm(Node):
 class Dropout(Node):
     def __init__(self, eng, x, rate):
         self.e, self.x, self.rate = eng, x, rate
-        self.y = eng.new(*x.shape)
+        # an inference-only plan has no use for a second buffer: Dropout is the identity there (a 75 MB copy per forward
+        # of the batch-128 predict plan otherwise)
+        self.y = eng.new(*x.shape) if eng.train_capable else x
         self.seed = 0
 
     def fwd(self, training):
         if training:      # the seed of this step lives in device memory (engine.step_params[1]) -> graph-replayable
             L.spnet_dropout(L.ptr(self.x), L.ptr(self.y), self.x.numel(), 0, self.rate, self.e.seed_ptr, _stream())
-        else:
+        elif self.y is not self.x:
             self.y.copy_(self.x)
 
     def bwd(self, g):
