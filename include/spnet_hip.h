@@ -332,8 +332,8 @@ int spnet_adam_step(float* p, const float* g, float* m, float* v, long n, long l
 /* uint8 grey levels -> float32 network input, dst = (src / 255 - 0.5) * 2 with numpy's float32 roundings (bit-identical
  * to the host conversion); n pixels, pointers 16-byte aligned.  Lets frames cross PCIe as bytes. */
 int spnet_u8_to_input(const unsigned char* src, float* dst, long n, void* stream);
-/* Batch assembly: dst[i][0..L) = src[index[i]][0..L), n rows of L floats (L % 4 == 0, 16-byte aligned), index int32 |
- * int64 on the device (idx_bytes 4 | 8), clamped to [0, src_rows) -- the minibatch gather Keras' fit does on the host
+/* Batch assembly: dst[i][0..L) = src[index[i]][0..L), n rows of L floats (16 bytes per lane when L % 4 == 0 and both
+ * buffers are 16-byte aligned, 4 otherwise), index int32 | int64 on the device (idx_bytes 4 | 8), clamped to [0, src_rows) -- the minibatch gather Keras' fit does on the host
  * (train_spnet.py:75,81: model.fit(X_train, Y_train, batch_size, shuffle=True)). */
 int spnet_gather_rows(const float* src, long src_rows, const void* index, int idx_bytes, float* dst, int n, long L,
                       void* stream);

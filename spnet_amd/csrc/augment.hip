@@ -322,33 +322,37 @@ extern "C" int spnet_u8_to_input(const unsigned char* src, float* dst, long n, v
 }
 
 // ------------------------------------------------------------------------------------------------
-// Batch assembly: dst[i][:] = src[index[i]][:] for n rows of L floats (L % 4 == 0) -- the minibatch of frames / targets
-// picked out of the resident training set by the epoch's shuffled index (Keras' fit does this on the host:
-// train_spnet.py:75,81).  index: int32 or int64 (idx_bytes 4 | 8) on the device.  Pure copy: 16 bytes per lane.
+// Batch assembly: dst[i][:] = src[index[i]][:] for n rows of L floats -- the minibatch of frames / targets picked out of
+// the resident training set by the epoch's shuffled index (Keras' fit does this on the host: train_spnet.py:75,81).
+// index: int32 or int64 (idx_bytes 4 | 8) on the device.  Pure copy: 16 bytes per lane where rows are 16-byte multiples
+// (L % 4 == 0), 4 bytes per lane otherwise (the reference layout's 331 x 331 frames: 109,561 floats per row).
 // ------------------------------------------------------------------------------------------------
-template <class IT>
-__global__ __launch_bounds__(256) void gather_rows_kernel(const float* __restrict__ src, const IT* __restrict__ index,
-                                                          float* __restrict__ dst, int n, long l4, long src_rows) {
-  const long total = (long)n * l4;
+template <class IT, class VT>
+__global__ __launch_bounds__(256) void gather_rows_kernel(const VT* __restrict__ src, const IT* __restrict__ index,
+                                                          VT* __restrict__ dst, int n, long lv, long src_rows) {
+  const long total = (long)n * lv;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    const long r = i / l4, c = i - r * l4;
+    const long r = i / lv, c = i - r * lv;
     long s = (long)index[r];
     s = s < 0 ? 0 : (s >= src_rows ? src_rows - 1 : s);        // (an out-of-range index must not fault the device)
-    reinterpret_cast<float4*>(dst)[i] = reinterpret_cast<const float4*>(src)[s * l4 + c];
+    dst[i] = src[s * lv + c];
   }
 }
 
 extern "C" int spnet_gather_rows(const float* src, long src_rows, const void* index, int idx_bytes, float* dst, int n, long L,
                                  void* stream) {
-  if (!src || !index || !dst || n < 0 || L < 4 || (L & 3) || src_rows < 1 || (idx_bytes != 4 && idx_bytes != 8) ||
-      (((uintptr_t)src | (uintptr_t)dst) & 15))
+  if (!src || !index || !dst || n < 0 || L < 1 || src_rows < 1 || (idx_bytes != 4 && idx_bytes != 8) ||
+      (((uintptr_t)src | (uintptr_t)dst) & 3))
     return (int)hipErrorInvalidValue;
   if (n == 0) return 0;
-  const long l4 = L / 4;
-  const dim3 grid(spnet_ew_grid((long)n * l4, 256));
-  if (idx_bytes == 4)
-    hipLaunchKernelGGL(gather_rows_kernel<int>, grid, dim3(256), 0, (hipStream_t)stream, src, (const int*)index, dst, n, l4, src_rows);
-  else
-    hipLaunchKernelGGL(gather_rows_kernel<long long>, grid, dim3(256), 0, (hipStream_t)stream, src, (const long long*)index, dst, n, l4, src_rows);
+  hipStream_t st = (hipStream_t)stream;
+  const bool vec = (L & 3) == 0 && ((((uintptr_t)src | (uintptr_t)dst) & 15) == 0);
+  const long lv = vec ? L / 4 : L;
+  const dim3 grid(spnet_ew_grid((long)n * lv, 256));
+#define GR(IT, VT) hipLaunchKernelGGL((gather_rows_kernel<IT, VT>), grid, dim3(256), 0, st, (const VT*)src, (const IT*)index, \
+                                      (VT*)dst, n, lv, src_rows)
+  if (vec) { if (idx_bytes == 4) GR(int, float4); else GR(long long, float4); }
+  else { if (idx_bytes == 4) GR(int, float); else GR(long long, float); }
+#undef GR
   SPNET_RETURN_LAUNCH_STATUS();
 }

@@ -1046,7 +1046,7 @@ def test_calc_errors_on_device_matches_host(L):
 @pytest.mark.parametrize("idx_dtype", [torch.int32, torch.int64])
 def test_gather_rows(L, idx_dtype):
     """Batch assembly (the minibatch gather of Model.fit / bench.py): dst[i] = src[index[i]], bit for bit; indices
-    outside the set are clamped instead of faulting; misaligned rows are refused."""
+    outside the set are clamped instead of faulting; rows of any length."""
     rs = np.random.RandomState(4)
     src = dev(rs.randn(37, 6, 10, 2))                     # rows of 120 floats
     idx = torch.tensor(rs.randint(0, 37, 16), dtype=idx_dtype, device="cuda")
@@ -1057,5 +1057,11 @@ def test_gather_rows(L, idx_dtype):
     d3 = torch.full((3, 6, 10, 2), float("nan"), device="cuda")
     L.gather_rows(src, bad, d3)
     assert torch.equal(d3, src[torch.tensor([0, 36, 5], device="cuda")])
-    with pytest.raises(L.HipError):                       # rows of 6 floats: not a multiple of 4
-        L.spnet_gather_rows(src.data_ptr(), 37, idx.data_ptr(), idx.element_size(), dst.data_ptr(), 16, 6, st())
+    # rows that are not 16-byte multiples (the reference layout's 331 x 331 x 1 frames) take the 4-byte path
+    odd = dev(rs.randn(9, 331, 331, 1))
+    i2 = torch.tensor(rs.randint(0, 9, 5), dtype=idx_dtype, device="cuda")
+    d2 = torch.full((5, 331, 331, 1), float("nan"), device="cuda")
+    L.gather_rows(odd, i2, d2)
+    assert torch.equal(d2, odd[i2.long()])
+    with pytest.raises(L.HipError):                       # idx_bytes other than 4 | 8
+        L.spnet_gather_rows(src.data_ptr(), 37, idx.data_ptr(), 2, dst.data_ptr(), 16, 120, st())
