@@ -239,43 +239,6 @@ __device__ __forceinline__ void gemm_epilogue(f32x4 (&acc)[TM][TN], float* __res
                                               int accumulate = 0) {
   const int p = lane & 15, jq = lane >> 4;
   const int mw = m0 + wm * (TM * 16), nw = n0 + wn * (TN * 16);
-  if (colstats) {
-    float* sred = smem;                       // [2][WM][BN], the staging buffers are idle now
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-      float sv = 0.f, qv = 0.f;
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int row = mw + SA::pos(i, 4 * jq + r);
-          const float v = row < M ? acc[i][j][r] : 0.f;
-          sv += v;
-          qv = fmaf(v, v, qv);
-        }
-      sv += __shfl_xor(sv, 16, 64);
-      qv += __shfl_xor(qv, 16, 64);
-      sv += __shfl_xor(sv, 32, 64);
-      qv += __shfl_xor(qv, 32, 64);
-      if (lane < 16) {
-        const int cl = wn * (TN * 16) + SB::pos(j, p);
-        sred[(0 * WM + wm) * BN + cl] = sv;
-        sred[(1 * WM + wm) * BN + cl] = qv;
-      }
-    }
-    __syncthreads();
-    for (int c = tid; c < 2 * BN; c += 256) {
-      const int q = c / BN, cl = c % BN;
-      const int col = n0 + cl;
-      if (col < N) {
-        float t = sred[(q * WM) * BN + cl];
-#pragma unroll
-        for (int w = 1; w < WM; ++w) t += sred[(q * WM + w) * BN + cl];
-        colstats[((long)tm * 2 + q) * N + col] = t;
-      }
-    }
-  }
-
   float* Cz = C + (long)z * slab_stride;
   constexpr int VW = SB::VWO;                // consecutive columns held by one lane
 #pragma unroll
@@ -318,6 +281,46 @@ __device__ __forceinline__ void gemm_epilogue(f32x4 (&acc)[TM][TN], float* __res
       }
     }
   }
+  // BatchNorm column sums of this tile AFTER its stores have been issued: the shuffles, the LDS round trip and the
+  // barrier below then run while the stores drain (they were in front of the stores until round 4: every wave held its
+  // output back behind the barrier).  Same arithmetic, same order: bit-identical sums.
+  if (colstats) {
+    float* sred = smem;                       // [2][WM][BN], the staging buffers are idle now
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      float sv = 0.f, qv = 0.f;
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = mw + SA::pos(i, 4 * jq + r);
+          const float v = row < M ? acc[i][j][r] : 0.f;
+          sv += v;
+          qv = fmaf(v, v, qv);
+        }
+      sv += __shfl_xor(sv, 16, 64);
+      qv += __shfl_xor(qv, 16, 64);
+      sv += __shfl_xor(sv, 32, 64);
+      qv += __shfl_xor(qv, 32, 64);
+      if (lane < 16) {
+        const int cl = wn * (TN * 16) + SB::pos(j, p);
+        sred[(0 * WM + wm) * BN + cl] = sv;
+        sred[(1 * WM + wm) * BN + cl] = qv;
+      }
+    }
+    __syncthreads();
+    for (int c = tid; c < 2 * BN; c += 256) {
+      const int q = c / BN, cl = c % BN;
+      const int col = n0 + cl;
+      if (col < N) {
+        float t = sred[(q * WM) * BN + cl];
+#pragma unroll
+        for (int w = 1; w < WM; ++w) t += sred[(q * WM + w) * BN + cl];
+        colstats[((long)tm * 2 + q) * N + col] = t;
+      }
+    }
+  }
+
 }
 
 // All MFMAs of one K tile for one wave: NCH chunks of 16 reduction steps out of the LDS buffer `cur`
