@@ -382,3 +382,15 @@ def test_irv2_sibling_groups_and_parameter_packs():
             seen.add(n)
         kinds = {n.split("/")[1] for n in p}
         assert len(kinds) == 1 and kinds <= {"beta", "moving_mean", "moving_variance"}
+
+
+def test_fake_espi_object_density_of_the_published_dataset():
+    """gen_fake_espi.py:250-251 draws 1-7 antinodes per frame since Nov 2020 (its own comment); the published Dataset-A
+    run's sets hold 14,965 / 14,952 objects in 4,992 frames = 3.0 per frame, i.e. random.randint(0, 6).  count_range
+    selects the generator version; the default stays the current reference's, frame by frame."""
+    from spnet_amd import fake_espi as F
+    n_new = [len(F.draw_params(s)[1]) for s in range(1500)]
+    n_old = [len(F.draw_params(s, (0, 6))[1]) for s in range(1500)]
+    assert min(n_new) >= 1 and max(n_new) <= 7 and 3.8 < np.mean(n_new) < 4.1
+    assert min(n_old) == 0 and max(n_old) <= 6 and 2.85 < np.mean(n_old) < 3.1          # the log: 2.998 / 2.995
+    assert [n[:6] for n in F.draw_params(5)[1]] == [n[:6] for n in F.draw_params(5, (1, 7))[1]]
