@@ -506,6 +506,57 @@ def bf16x3_alt_measure(dev, iters=200):
             "iters": iters}
 
 
+def bf16x3_step_measure(dev, X_pool, steps=20, warmup=5):
+    """`roofline_alt.train_step`: the whole benchmark train step (Xception, batch 32, 512x384, without
+    the augmentation kernels) with the forward and data-gradient GEMMs of every pointwise convolution on the bf16x3
+    probe kernel (tools/probes/bf16x3_hook.py: weights split once per optimizer step, activations while staged; forward
+    incl. the BatchNorm column sums in its epilogue), beside the SAME engine on the exact fp32 kernels: images/s and the
+    GEMM family's time from HIP events.  Weight gradients, the blended data-gradient GEMMs of blocks 2-3, block1_conv2
+    and the Dense head are the exact kernels in both columns.  Never `value`: not the k-ordered fp32 chain."""
+    import torch
+    from spnet_amd.engine import Engine
+    from tools.probes.bf16x3_hook import Bf16x3Pointwise
+    eng = Engine(H, W, BATCH, device=str(dev), seed=0)
+    X = X_pool[:BATCH].contiguous()
+    Y = torch.rand(BATCH, 576, device=dev)
+    hook = Bf16x3Pointwise(eng)
+
+    def step():
+        eng.train_step(X, Y, 1e-6)
+
+    out = {}
+    for name, alt in (("exact_fp32", None), ("bf16x3_fwd_dgrad", hook), ("exact_fp32_again", None)):
+        eng.pw_alt = alt
+        for _ in range(warmup):
+            step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        side = eng.wgrad_stream
+        eng.wgrad_stream = None                      # family times on one stream, as the main roofline leg
+        step()
+        tot = time_families(eng, step, max(5, steps // 2), torch.cuda.synchronize).totals()
+        eng.wgrad_stream = side
+        n_prof = max(5, steps // 2)
+        g_n, g_ms, g_flop = tot["gemm"]
+        out[name] = {"images_per_sec": round(BATCH * steps / dt, 1), "ms_per_step": round(1e3 * dt / steps, 3),
+                     "gemm_family_ms_per_step": round(g_ms / n_prof, 3),
+                     "gemm_family_tflops": round(g_flop / (g_ms * 1e-3) / 1e12, 1),
+                     "gemm_launches_per_step": g_n / n_prof}
+    eng.pw_alt = None
+    out["step_speedup"] = round(out["exact_fp32"]["ms_per_step"] / out["bf16x3_fwd_dgrad"]["ms_per_step"], 4)
+    out["gemm_family_speedup"] = round(out["exact_fp32"]["gemm_family_ms_per_step"] /
+                                       out["bf16x3_fwd_dgrad"]["gemm_family_ms_per_step"], 4)
+    out["note"] = ("same engine, same frames; 72 of the step's GEMM launches (34 pointwise forward + statistics, 4 residual "
+                   "forward, their data gradients except the blended ones) run on the probe kernel, one batched weight split per step")
+    del eng, hook
+    torch.cuda.empty_cache()
+    return out
+
+
 def rccl_version():
     try:
         import torch
@@ -867,6 +918,7 @@ def run(args):
             from tools.probes import probe_lib
             if probe_lib.available():      # (the probe library is not part of the product: tools/probes/Makefile)
                 result["roofline_alt"] = bf16x3_alt_measure(dev)
+                result["roofline_alt"]["train_step"] = bf16x3_step_measure(dev, X_pool)
             eng = aug = None
         if world == 1 and not args.no_cpu_baseline:
             del eng, aug, X_pool

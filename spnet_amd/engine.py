@@ -380,6 +380,10 @@ class Engine:
         # batch size continues Adam's bias correction and the dropout seed sequence instead of restarting them.
         self._opt = share_from._opt if share_from is not None else {"t": 0, "drop_seed": 12345 + 7919 * int(rank)}
         self.prof = None                # KernelTimer or None
+        # Measurement hook (None in the product): an object that takes over the forward / data-gradient GEMMs of the
+        # pointwise convolutions -- tools/probes/bf16x3_hook.py runs them on the bf16 matrix cores by operand splitting for
+        # bench.py's `roofline_alt` leg (same results to fp32 accuracy, not the same bits; tests/test_engine_gpu.py).
+        self.pw_alt = None
         self.deferred_wgrads = []       # (x, dy, gw, cin, cout, M) of layers whose dW waits for the batched launch
         self.dw_reduce_jobs = []        # (partials, grad, rows, 9*C) of every depthwise layer
         self._dw_reduce_table = None
@@ -1156,6 +1160,7 @@ class Pointwise:
     def __init__(self, eng, M, cin, cout, wname, defer_wgrad=False, allow_blend=True):
         self.e, self.M, self.cin, self.cout = eng, M, cin, cout
         self.w = eng.P(wname)
+        self.wname = wname
         self.gw = eng.G(wname) if eng.train_capable else None
         # BatchNorm backward blended into the data-gradient GEMM's A operand (bwd_blend) instead of an elementwise
         # pass of its own.  The blend reads BOTH g and yp once per COLUMN tile of dX, so it only pays while dX has
@@ -1166,10 +1171,14 @@ class Pointwise:
         self.defer_wgrad = defer_wgrad      # dW is left to Engine.flush_deferred_wgrads() (one batched launch)
 
     def fwd(self, x, y):
+        if self.e.pw_alt is not None:
+            return self.e.pw_alt.fwd(self, x, y)
         _gemm(x, K_MAJOR, self.cin, self.w, OUT_MAJOR, self.cout, y, self.cout, self.M, self.cout, self.cin, self.e)
 
     def fwd_colstats(self, x, y, region=WS_BNP):
         """Forward + BatchNorm column sums of y left in `region`; returns the partial row count."""
+        if self.e.pw_alt is not None:
+            return self.e.pw_alt.fwd_colstats(self, x, y, region)
         return _gemm_colstats(x, self.cin, self.w, self.cout, y, self.cout, self.M, self.cout, self.cin, self.e,
                               region=region)
 
@@ -1189,7 +1198,9 @@ class Pointwise:
             with torch.cuda.stream(side):
                 _gemm(x, OUT_MAJOR, self.cin, dy, OUT_MAJOR, self.cout, self.gw, self.cout, self.cin, self.cout,
                       self.M, e, region=WS_GEMM2)
-        if dx is not None:      # dx[M,cin] = dy[M,cout] @ W^T: W read in place as a K-major B operand
+        if dx is not None and e.pw_alt is not None:
+            e.pw_alt.dgrad(self, dy, dx)
+        elif dx is not None:    # dx[M,cin] = dy[M,cout] @ W^T: W read in place as a K-major B operand
             _gemm(dy, K_MAJOR, self.cout, self.w, K_MAJOR, self.cout, dx, self.cin, self.M, self.cin, self.cout, e)
 
 

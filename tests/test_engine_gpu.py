@@ -243,3 +243,38 @@ def test_stream_accessor_matches_the_public_handle():
     with torch.cuda.stream(side):
         assert L.current_stream() == side.cuda_stream == torch.cuda.current_stream().cuda_stream
     assert L.current_stream() == torch.cuda.current_stream().cuda_stream
+
+
+def test_bf16x3_hook_step_matches_oracle(setup):
+    """Engine.pw_alt (a measurement hook, None in the product): with tools/probes/bf16x3_hook.py the forward and
+    data-gradient GEMMs of the pointwise convolutions run on the bf16 matrix cores by operand splitting.  Not the exact
+    kernels' bits -- but the same results to fp32 accuracy: a training forward / backward through the hook meets the
+    suite's own gradient tolerance against the fp64 oracle on the device's decisions, and its output is within 1e-5 of
+    the exact engine's."""
+    _need_gpu()
+    from tools.probes import probe_lib
+    if not probe_lib.available():
+        pytest.skip("tools/probes/lib/libspnet_probe.so not built (make -C tools/probes)")
+    from tools.probes.bf16x3_hook import Bf16x3Pointwise
+    from tests.parity_util import assert_gradients_match, rel_err
+    eng, P, X, Y = setup
+    eng.load_state_dict(P)
+    seed = 99
+    h2, w2 = H // 2, W // 2
+    mask = torch.tensor(dropout_mask(B * h2 * w2 * 3, seed).reshape(B, h2, w2, 3))
+    outs = []
+    try:
+        for alt in (None, Bf16x3Pointwise(eng)):
+            eng.pw_alt = alt
+            eng.load_state_dict(P)                       # moving statistics back to P
+            eng.set_drop_seed(seed)
+            out = eng.forward(X.cuda(), training=True).clone()
+            eng.loss(Y.cuda())
+            eng.backward()
+            torch.cuda.synchronize()
+            outs.append(out.cpu())
+            assert_gradients_match(eng, P, X, Y, mask)
+        assert not torch.equal(outs[0], outs[1])          # another summation: not the same bits ...
+        assert rel_err(outs[1].numpy(), outs[0].numpy()) <= 1e-5      # ... the same numbers
+    finally:
+        eng.pw_alt = None

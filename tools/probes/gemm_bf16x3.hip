@@ -93,7 +93,7 @@ __device__ __forceinline__ void split3_pk(float x0, float x1, unsigned& h, unsig
 __global__ __launch_bounds__(256, 2) void gemm_bf16x3_fwd_kernel(const float* __restrict__ A, int lda,
                                                                  const unsigned short* __restrict__ Bp, int Kp,
                                                                  float* __restrict__ C, int ldc, int M, int N, int K,
-                                                                 int tiles_n) {
+                                                                 int tiles_n, float* __restrict__ colstats) {
   // [buffer][A planes 0..2 | B planes 0..2][row][X3_LDR]
   __shared__ __attribute__((aligned(16))) unsigned short smem[2 * 6 * X3_PLANE];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -220,6 +220,67 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16x3_fwd_kernel(const float* __
         }
       }
     }
+  // BatchNorm column sums of this 96-row tile (sum, sum of squares per output column), as spnet_gemm_f32_colstats leaves
+  // them: colstats[tile row][2][N].  Per lane over its 12 rows, then over the four row groups of the wave (lanes 16
+  // apart), then over the two waves that share the columns (through LDS: the stage buffers are idle now); fixed order.
+  if (colstats) {
+    float* sred = reinterpret_cast<float*>(smem);      // [2 sums][2 wm][96 columns]
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      float sv = 0.f, qv = 0.f;
+#pragma unroll
+      for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = m0 + wm * 48 + i * 16 + kg * 4 + r;
+          const float v = row < M ? acc[i][j][r] : 0.f;
+          sv += v;
+          qv = fmaf(v, v, qv);
+        }
+      sv += __shfl_xor(sv, 16, 64); qv += __shfl_xor(qv, 16, 64);
+      sv += __shfl_xor(sv, 32, 64); qv += __shfl_xor(qv, 32, 64);
+      if (lane < 16) {
+        const int cl = wn * 48 + j * 16 + p16;
+        sred[(0 * 2 + wm) * X3_BN + cl] = sv;
+        sred[(1 * 2 + wm) * X3_BN + cl] = qv;
+      }
+    }
+    __syncthreads();
+    if (tid < 2 * X3_BN) {
+      const int q = tid / X3_BN, cl = tid % X3_BN, col = n0 + cl;
+      if (col < N) colstats[((long)tm * 2 + q) * N + col] = sred[(q * 2 + 0) * X3_BN + cl] + sred[(q * 2 + 1) * X3_BN + cl];
+    }
+  }
+}
+
+// All weight splits of a step in one launch: job j = {W, planes, K, N, sn, sk} (six 64-bit words, device memory): the
+// B operand element (n, k) is W[n * sn + k * sk] -- forward form of a Keras pointwise kernel [cin][cout]: K = cin, N = cout,
+// sn = 1, sk = cout; data-gradient form (dX = dY W^T): K = cout, N = cin, sn = cout, sk = 1.
+__global__ __launch_bounds__(256) void split_bf16x3_batched_kernel(const long long* __restrict__ jobs) {
+  const long long* jb = jobs + 6 * blockIdx.y;
+  const float* __restrict__ W = reinterpret_cast<const float*>(jb[0]);
+  unsigned short* __restrict__ planes = reinterpret_cast<unsigned short*>(jb[1]);
+  const int K = (int)jb[2], N = (int)jb[3];
+  const long sn = jb[4], sk = jb[5];
+  const int Kp = (K + 31) / 32 * 32;
+  const long total = (long)N * Kp;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int k = (int)(i % Kp), n = (int)(i / Kp);
+    unsigned short h = 0, m = 0, l = 0;
+    if (k < K) split3(W[n * sn + k * sk], h, m, l);
+    planes[i] = h;
+    planes[total + i] = m;
+    planes[2 * total + i] = l;
+  }
+}
+
+extern "C" int spnet_split_bf16x3_batched(const void* jobs, int njobs, long max_elems, void* stream) {
+  if (!jobs || njobs < 1 || max_elems < 1) return (int)hipErrorInvalidValue;
+  long gx = (max_elems + 255) / 256;
+  if (gx > 1024) gx = 1024;
+  hipLaunchKernelGGL(split_bf16x3_batched_kernel, dim3((unsigned)gx, njobs), dim3(256), 0, (hipStream_t)stream,
+                     reinterpret_cast<const long long*>(jobs));
+  SPNET_RETURN_LAUNCH_STATUS();
 }
 
 // planes: 3 * N * Kp bf16 (Kp = K rounded up to 32)
@@ -234,13 +295,27 @@ extern "C" int spnet_split_bf16x3(const float* W, void* planes, int K, int N, vo
 }
 
 // C[M][N] = A[M][K] * W[K][N], W given as the planes of spnet_split_bf16x3.  lda % 4 == 0, A 16-byte aligned.
-extern "C" int spnet_gemm_bf16x3_fwd(const float* A, int lda, const void* planes, float* C, int ldc, int M, int N, int K,
-                                     void* stream) {
+static int x3_launch(const float* A, int lda, const void* planes, float* C, int ldc, int M, int N, int K, float* colstats,
+                     int* stat_rows, void* stream) {
   if (!A || !planes || !C || M < 1 || N < 1 || K < 1 || (lda & 3) || (K & 3)) return (int)hipErrorInvalidValue;
   if ((((uintptr_t)A) | ((uintptr_t)planes)) & 15) return (int)hipErrorInvalidValue;
   const int Kp = (int)spnet_bf16x3_kp(K);
   const int tm = spnet_cdiv(M, X3_BM), tn = spnet_cdiv(N, X3_BN);
+  if (stat_rows) *stat_rows = tm;
   hipLaunchKernelGGL(gemm_bf16x3_fwd_kernel, dim3(tm * tn), dim3(256), 0, (hipStream_t)stream, A, lda,
-                     reinterpret_cast<const unsigned short*>(planes), Kp, C, ldc, M, N, K, tn);
+                     reinterpret_cast<const unsigned short*>(planes), Kp, C, ldc, M, N, K, tn, colstats);
   SPNET_RETURN_LAUNCH_STATUS();
+}
+
+extern "C" int spnet_gemm_bf16x3_fwd(const float* A, int lda, const void* planes, float* C, int ldc, int M, int N, int K,
+                                     void* stream) {
+  return x3_launch(A, lda, planes, C, ldc, M, N, K, nullptr, nullptr, stream);
+}
+
+// The same with the BatchNorm column sums of C in the epilogue: colstats[*stat_rows][2][N], *stat_rows = ceil(M / 96)
+// (the layout spnet_gemm_f32_colstats leaves; the consumers take the row count as an argument).
+extern "C" int spnet_gemm_bf16x3_fwd_colstats(const float* A, int lda, const void* planes, float* C, int ldc, int M, int N,
+                                              int K, float* colstats, int* stat_rows, void* stream) {
+  if (!colstats || !stat_rows) return (int)hipErrorInvalidValue;
+  return x3_launch(A, lda, planes, C, ldc, M, N, K, colstats, stat_rows, stream);
 }
