@@ -666,6 +666,8 @@ class Engine:
             self._coeff_ver = -1
         else:
             self._infer_fresh = self._coeff_ver != self._wver[0]
+        if self.pw_alt is not None:         # (operand planes of the current weights: on THIS stream, before any branch)
+            self.pw_alt.ensure_fresh()
         for node in self.nodes:
             node.fwd(training)
         if self.sigmoid_cols is not None:
@@ -701,6 +703,8 @@ class Engine:
         self.deferred_wgrads = []
         if self._wT_ver[0] != self._tver[0]:    # weights were loaded / re-initialised since the last optimizer step
             self.refresh_transposes()
+        if self.pw_alt is not None:
+            self.pw_alt.ensure_fresh()
         for node in reversed(self.nodes):
             g = node.bwd(g)
             if node is self._first_middle:      # (flushing in 2 or 4 smaller batches measured no faster)

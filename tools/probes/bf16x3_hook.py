@@ -59,8 +59,10 @@ class Bf16x3Pointwise:
             if hasattr(node, "pwr"):
                 yield node.pwr
 
-    def _fresh(self):
-        """Planes of the current weights (theta changes with every optimizer step, load or re-initialisation)."""
+    def ensure_fresh(self):
+        """Planes of the current weights (theta changes with every optimizer step, load or re-initialisation).  The engine
+        calls this at the start of forward() / backward(), on the main stream: the split must be ordered in front of
+        every consumer on every stream (a strided block's residual convolution runs on the side stream)."""
         if self.ver != self.e._tver[0]:
             rc = self.lib.spnet_split_bf16x3_batched(self.jobs.data_ptr(), self.njobs, self.max_elems, E._stream())
             assert rc == 0, rc
@@ -79,11 +81,11 @@ class Bf16x3Pointwise:
             prof.stop("gemm", t0, 2.0 * M * N * K, (tag, M, N, K))
 
     def fwd(self, pw, x, y):
-        self._fresh()
+        self.ensure_fresh()
         self._run("bf16x3 aB", x, pw.cin, self.planes[pw.wname][0], y, pw.cout, pw.M, pw.cout, pw.cin)
 
     def fwd_colstats(self, pw, x, y, region):
-        self._fresh()
+        self.ensure_fresh()
         if (pw.M + 95) // 96 * 2 * pw.cout > region[1]:
             raise RuntimeError("BatchNorm partial region too small")
         self._run("bf16x3 aB+stats", x, pw.cin, self.planes[pw.wname][0], y, pw.cout, pw.M, pw.cout, pw.cin,
@@ -91,5 +93,5 @@ class Bf16x3Pointwise:
         return self._rows.value
 
     def dgrad(self, pw, dy, dx):
-        self._fresh()
+        self.ensure_fresh()
         self._run("bf16x3 aA", dy, pw.cout, self.planes[pw.wname][1], dx, pw.cin, pw.M, pw.cin, pw.cout)
