@@ -32,6 +32,13 @@ DW_TRAIN_BYTES_PER_IMAGE = 157.6e6  # depthwise stack, f
 DW_FWD_BYTES_PER_IMAGE = 63.1e6
 
 
+# The arithmetic the path computes in (not a precision claim): fp32 tensors and accumulators everywhere; since round 4 the
+# forward and data-gradient GEMMs of the pointwise convolutions with >= 256 output columns multiply on the bf16 matrix
+# cores with every fp32 operand split exactly into three bf16 pieces (six bf16 MFMAs per product block, fp32 accumulate:
+# error against float64 no larger than the fp32 fmaf chain's, tests/test_kernels_gpu.py); all other GEMMs, the weight
+# gradients included, are fp32 MFMA chains.  `roofline_alt.train_step` carries the all-fp32-chain step beside it.
+DTYPE = "f32 (pointwise fwd/dgrad GEMMs: f32 operands as 3 bf16 pieces on bf16 MFMA, f32 accumulate; all else f32 MFMA/FMA)"
+
 # BASELINE.json's metric string, verbatim
 METRIC = "training images/sec on 512\u00d7384 fake-ESPI, Xception backbone, 1/2/4/8 GPU"
 
@@ -241,7 +248,7 @@ def secondary(args):
     dt = time.perf_counter() - t0
     out = {"metric": "%s images/sec, %s backbone (secondary measurement)" % (args.mode, args.backbone),
            "value": round(b * args.steps / dt, 2), "unit": "images/sec", "n_gpus": 1, "steps": args.steps,
-           "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3), "dtype": "f32",
+           "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3), "dtype": DTYPE if args.backbone != "InceptionResNetV2" else "f32",
            "data": "synthetic (uniform noise)",
            "config": {"workload": "%s, %s, %dx%d frames, batch %d" % (args.mode, args.backbone, w, h, b)}}
     if not args.no_kernel_timers:       # the GEMM family of this configuration against the fp32 MFMA peak (HIP events)
@@ -352,7 +359,7 @@ def predict_bench(args):
                   "(BASELINE configs[4]; secondary to the training metric)",
         "value": r["frames_per_sec"], "unit": "frames/sec", "n_gpus": 1, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": r["ms_per_step"], "higher_is_better": True,
-        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "scaling": "weak", "vs_baseline": None, "dtype": DTYPE, "data": "synthetic",
         "config": {"workload": "configs[4]: inference-only forward, Xception, 512x384 fake-ESPI frames, batch 128, "
                                "hipGraph-captured plan, frames resident in HBM", "batch": PB, "frame_hw": [H, W],
                    "pool_frames": pool, "eager_frames_per_sec": r["eager_frames_per_sec"],
@@ -453,26 +460,23 @@ def backbone_leg(dev, backbone, batch, steps=20, warmup=5, predict=False):
 
 
 def bf16x3_alt_measure(dev, iters=200):
-    """`roofline_alt` (optional part): the bf16x3 operand-split probe (tools/probes/gemm_bf16x3.hip, a library of its own: six bf16
-    MFMAs with fp32 accumulation per product block) beside the exact fp32 MFMA kernel on the network's dominant forward
-    shape, the Xception middle-flow pointwise GEMM at batch 32 (6144 x 728 x 728).  Never part of `value`: the product
-    path stays the k-ordered fp32 chain.  Error of both kernels against float64 (torch.float64 on the device), relative
+    """`roofline_alt`: the bf16x3 kernel (csrc/gemm_bf16x3.hip: six bf16 MFMAs with fp32 accumulation per product block;
+    the product path of the pointwise forward / data-gradient GEMMs since round 4) beside the exact fp32 MFMA kernel on the
+    network's dominant forward shape, the Xception middle-flow pointwise GEMM at batch 32 (6144 x 728 x 728), isolated.  Error of both kernels against float64 (torch.float64 on the device), relative
     to |a_row| * |w_col|."""
     import torch
     from spnet_amd import _lib as L
-    from tools.probes import probe_lib
-    PL = probe_lib.load()
     M, N, K = 6144, 728, 728
     g = torch.Generator(device=dev)
     g.manual_seed(3)
     a = torch.randn(M, K, device=dev, generator=g)
     w = torch.randn(K, N, device=dev, generator=g) * 0.05
-    Kp = int(PL.spnet_bf16x3_kp(K))
+    Kp = int(L.spnet_bf16x3_kp(K))
     planes = torch.zeros(3 * N * Kp, dtype=torch.int16, device=dev)
     c3, c1 = torch.empty(M, N, device=dev), torch.empty(M, N, device=dev)
     st = torch.cuda.current_stream().cuda_stream
-    split = lambda: PL.spnet_split_bf16x3(w.data_ptr(), planes.data_ptr(), K, N, st)
-    f3 = lambda: PL.spnet_gemm_bf16x3_fwd(a.data_ptr(), K, planes.data_ptr(), c3.data_ptr(), N, M, N, K, st)
+    split = lambda: L.spnet_split_bf16x3(w.data_ptr(), planes.data_ptr(), K, N, st)
+    f3 = lambda: L.spnet_gemm_bf16x3_fwd(a.data_ptr(), K, planes.data_ptr(), c3.data_ptr(), N, M, N, K, st)
     f1 = lambda: L.spnet_gemm_f32(a.data_ptr(), 0, K, w.data_ptr(), 1, N, c1.data_ptr(), N, M, N, K, 1, None, 0, None, 0, st)
 
     def t(fn):
@@ -493,7 +497,7 @@ def bf16x3_alt_measure(dev, iters=200):
     e3, e1 = (c3.double() - ref).abs() / scale, (c1.double() - ref).abs() / scale
     fl = 2.0 * M * N * K
     peak = BF16_MFMA_PEAK_TFLOPS / 6.0
-    return {"kernel": "gemm_bf16x3_fwd_kernel (probe, not on the product path): fp32 operands as 3 bf16 pieces, 6 bf16 MFMAs "
+    return {"kernel": "gemm_bf16x3_fwd_kernel, isolated on the dominant shape: fp32 operands as 3 bf16 pieces, 6 bf16 MFMAs "
                       "per product block, fp32 accumulate", "shape": {"M": M, "N": N, "K": K}, "bound": "mfma",
             "achieved": round(fl / t3 / 1e6, 1), "peak": round(peak, 1), "unit": "TFLOP/s (fp32-equivalent)",
             "frac": round(fl / t3 / 1e6 / peak, 4),
@@ -506,27 +510,25 @@ def bf16x3_alt_measure(dev, iters=200):
             "iters": iters}
 
 
-def bf16x3_step_measure(dev, X_pool, steps=20, warmup=5):
-    """`roofline_alt.train_step`: the whole benchmark train step (Xception, batch 32, 512x384, without
-    the augmentation kernels) with the forward and data-gradient GEMMs of every pointwise convolution on the bf16x3
-    probe kernel (tools/probes/bf16x3_hook.py: weights split once per optimizer step, activations while staged; forward
-    incl. the BatchNorm column sums in its epilogue), beside the SAME engine on the exact fp32 kernels: images/s and the
-    GEMM family's time from HIP events.  Weight gradients, the blended data-gradient GEMMs of blocks 2-3, block1_conv2
-    and the Dense head are the exact kernels in both columns.  Never `value`: not the k-ordered fp32 chain."""
+def exact_chain_step_measure(dev, X_pool, steps=20, warmup=5):
+    """`roofline_alt.train_step`: the benchmark train step (Xception, batch 32, 512x384, without the augmentation kernels)
+    on the SAME engine in its two arithmetic modes, alternating: `pointwise="bf16x3"` (the product path since round 4: forward
+    and data-gradient GEMMs of the pointwise convolutions with >= 256 output columns on csrc/gemm_bf16x3.hip) and
+    `pointwise="f32"` (every GEMM the k-ordered fp32 MFMA chain, the product path of rounds 1-3): images/s and the GEMM
+    family's time from HIP events.  Weight gradients, the blended data-gradient GEMMs of blocks 2-3, block1_conv2 and the
+    Dense head are the exact fp32 kernels in both columns."""
     import torch
     from spnet_amd.engine import Engine
-    from tools.probes.bf16x3_hook import Bf16x3Pointwise
     eng = Engine(H, W, BATCH, device=str(dev), seed=0)
     X = X_pool[:BATCH].contiguous()
     Y = torch.rand(BATCH, 576, device=dev)
-    hook = Bf16x3Pointwise(eng)
 
     def step():
         eng.train_step(X, Y, 1e-6)
 
     out = {}
-    for name, alt in (("exact_fp32", None), ("bf16x3_fwd_dgrad", hook), ("exact_fp32_again", None)):
-        eng.pw_alt = alt
+    for name, mode in (("bf16x3", "bf16x3"), ("exact_fp32", "f32"), ("bf16x3_again", "bf16x3")):
+        eng.pointwise = mode
         for _ in range(warmup):
             step()
         torch.cuda.synchronize()
@@ -538,21 +540,22 @@ def bf16x3_step_measure(dev, X_pool, steps=20, warmup=5):
         side = eng.wgrad_stream
         eng.wgrad_stream = None                      # family times on one stream, as the main roofline leg
         step()
-        tot = time_families(eng, step, max(5, steps // 2), torch.cuda.synchronize).totals()
-        eng.wgrad_stream = side
         n_prof = max(5, steps // 2)
-        g_n, g_ms, g_flop = tot["gemm"]
+        tim = time_families(eng, step, n_prof, torch.cuda.synchronize)
+        eng.wgrad_stream = side
+        g_n, g_ms, g_flop = tim.totals()["gemm"]
+        x3 = [v for t, v in tim.tagged().items() if isinstance(t, tuple) and str(t[0]).startswith("x3")]
         out[name] = {"images_per_sec": round(BATCH * steps / dt, 1), "ms_per_step": round(1e3 * dt / steps, 3),
                      "gemm_family_ms_per_step": round(g_ms / n_prof, 3),
                      "gemm_family_tflops": round(g_flop / (g_ms * 1e-3) / 1e12, 1),
-                     "gemm_launches_per_step": g_n / n_prof}
-    eng.pw_alt = None
-    out["step_speedup"] = round(out["exact_fp32"]["ms_per_step"] / out["bf16x3_fwd_dgrad"]["ms_per_step"], 4)
-    out["gemm_family_speedup"] = round(out["exact_fp32"]["gemm_family_ms_per_step"] /
-                                       out["bf16x3_fwd_dgrad"]["gemm_family_ms_per_step"], 4)
-    out["note"] = ("same engine, same frames; 72 of the step's GEMM launches (34 pointwise forward + statistics, 4 residual "
-                   "forward, their data gradients except the blended ones) run on the probe kernel, one batched weight split per step")
-    del eng, hook
+                     "gemm_launches_per_step": g_n / n_prof,
+                     "bf16x3_launches_per_step": sum(v[0] for v in x3) / n_prof,
+                     "bf16x3_ms_per_step": round(sum(v[1] for v in x3) / n_prof, 3)}
+    eng.pointwise = "bf16x3"
+    out["step_speedup_over_exact"] = round(out["exact_fp32"]["ms_per_step"] / out["bf16x3"]["ms_per_step"], 4)
+    out["gemm_family_speedup_over_exact"] = round(out["exact_fp32"]["gemm_family_ms_per_step"] /
+                                                  out["bf16x3"]["gemm_family_ms_per_step"], 4)
+    del eng
     torch.cuda.empty_cache()
     return out
 
@@ -830,7 +833,7 @@ def run(args):
             "metric": METRIC,
             "value": round(ips, 2), "unit": "images/sec", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "scaling": "weak", "vs_baseline": None, "dtype": DTYPE, "data": "synthetic",
             "config": {"workload": "configs[1]: Xception, fake-ESPI 512x384 (HxW 384x512x1, model_type 'big'), "
                                    "batch 32 per GPU, full train step (augment+fwd+custom_loss+bwd+Adam+l2)",
                        "global_batch": BATCH * world, "frame_hw": [H, W], "pool_frames_per_gpu": args.pool,
@@ -863,15 +866,34 @@ def run(args):
             d_n, d_ms, d_bytes = tot["dw"]
             gemm_tflops = g_flop / (g_ms * 1e-3) / 1e12
             dw_gbs = DW_TRAIN_BYTES_PER_IMAGE * BATCH * args.steps / (d_ms * 1e-3) / 1e9
-            roof_gemm = {"kernel": "fp32 MFMA GEMM family: gemm_f32_kernel (pointwise / residual / Dense, fwd+dgrad+wgrad, "
-                                   "incl. split-K slab reduce and the batched middle-flow dW launch) + "
-                                   "conv3x3_{fwd,dgrad,wgrad}_kernel (block1_conv2 implicit GEMMs)",
+            # the family by arithmetic: launches of gemm_bf16x3_fwd_kernel (tags "x3 ...") and the fp32 MFMA kernels
+            x3 = [v for t, v in timer.tagged().items() if isinstance(t, tuple) and str(t[0]).startswith("x3")]
+            x3_n, x3_ms, x3_fl = (sum(v[i] for v in x3) for i in range(3))
+            by_kernel = {
+                "gemm_bf16x3_fwd_kernel (pointwise forward + data gradient, >= 256 output columns)": {
+                    "launches_per_step": x3_n / args.steps, "ms_per_step": round(x3_ms / args.steps, 3),
+                    "achieved_fp32_equivalent_tflops": round(x3_fl / max(x3_ms, 1e-9) / 1e9, 1),
+                    "peak_fp32_equivalent_tflops": round(BF16_MFMA_PEAK_TFLOPS / 6.0, 1),
+                    "frac_of_own_peak": round(x3_fl / max(x3_ms, 1e-9) / 1e9 / (BF16_MFMA_PEAK_TFLOPS / 6.0), 4),
+                    "note": "six bf16 MFMAs per fp32 product block: dense bf16 MFMA peak / 6; the kernel is bound by its "
+                            "operand traffic through L2 (10 B per operand element), DESIGN.md section 3"},
+                "fp32 MFMA kernels (weight gradients, blended data gradients, block1_conv2, Dense, narrow layers)": {
+                    "launches_per_step": (g_n - x3_n) / args.steps, "ms_per_step": round((g_ms - x3_ms) / args.steps, 3),
+                    "achieved_tflops": round((g_flop - x3_fl) / max(g_ms - x3_ms, 1e-9) / 1e9, 1),
+                    "peak_tflops": FP32_MFMA_PEAK_TFLOPS,
+                    "frac": round((g_flop - x3_fl) / max(g_ms - x3_ms, 1e-9) / 1e9 / FP32_MFMA_PEAK_TFLOPS, 4)}}
+            roof_gemm = {"kernel": "GEMM family: gemm_f32_kernel (fp32 MFMA: weight gradients incl. the batched middle-flow dW "
+                                   "launch and split-K slab reduce, blended data gradients, residual / Dense) + "
+                                   "conv3x3_{fwd,dgrad,wgrad}_kernel (block1_conv2 implicit GEMMs) + gemm_bf16x3_fwd_kernel "
+                                   "(pointwise forward / data gradient).  `achieved` = algorithmic fp32 FLOPs of the family / its "
+                                   "time; `peak` = the fp32 MFMA peak, the yardstick of rounds 1-3 (by_kernel: each kernel "
+                                   "against its own)",
                          "bound": "mfma", "achieved": round(gemm_tflops, 2), "peak": FP32_MFMA_PEAK_TFLOPS,
                          "unit": "TFLOP/s", "frac": round(gemm_tflops / FP32_MFMA_PEAK_TFLOPS, 4),
                          "traffic": None if g_traffic is None else round(g_traffic),
                          "algorithmic_flops_per_launch": round(g_flop / g_n),
                          "avg_launch_us": round(1e3 * g_ms / g_n, 2), "launches_per_step": g_n / args.steps,
-                         "ms_per_step": round(g_ms / args.steps, 3)}
+                         "ms_per_step": round(g_ms / args.steps, 3), "by_kernel": by_kernel}
             roof_dw = {"kernel": "dw3x3_{stream,tile}_fwd_kernel + dw3x3_{stream,tile}_bwd_kernel (34 depthwise layers, fwd + fused bwd: streaming form on the entry-flow planes, LDS-tiled form with the folded BatchNorm finalize on the 12x16 / 6x8 planes)",
                        "bound": "hbm", "achieved": round(dw_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                        "frac": round(dw_gbs / HBM_PEAK_GBS, 4),
@@ -915,10 +937,8 @@ def run(args):
             result["layout_331"] = layout_331_measure(dev)
             result["irv2"] = backbone_leg(dev, "InceptionResNetV2", 16, predict=True)          # BASELINE configs[3]
             result["mobilenet"] = backbone_leg(dev, "MobileNet", 8)                            # configs[0]'s model
-            from tools.probes import probe_lib
-            if probe_lib.available():      # (the probe library is not part of the product: tools/probes/Makefile)
-                result["roofline_alt"] = bf16x3_alt_measure(dev)
-                result["roofline_alt"]["train_step"] = bf16x3_step_measure(dev, X_pool)
+            result["roofline_alt"] = bf16x3_alt_measure(dev)
+            result["roofline_alt"]["train_step"] = exact_chain_step_measure(dev, X_pool)
             eng = aug = None
         if world == 1 and not args.no_cpu_baseline:
             del eng, aug, X_pool

@@ -35,6 +35,21 @@ extern "C" {
 int spnet_gemm_f32(const float* A, int a_major, int lda, const float* B, int b_major, int ldb, float* C,
                    int ldc, int M, int N, int K, int split_k, float* workspace, long ws_floats,
                    const float* bias, int tile, void* stream);
+/* ---- fp32 GEMM on the bf16 matrix cores by operand splitting (csrc/gemm_bf16x3.hip): the forward and data-gradient GEMMs
+ * of the pointwise convolutions (keras SeparableConv2D pointwise step / 1x1 Conv2D; spnet/models.py:346-359).  Every fp32
+ * operand is the exact sum of three bf16 pieces; six bf16 MFMAs with fp32 accumulation per product block; error against
+ * float64 no larger than spnet_gemm_f32's, not the same bits.  A [M][K] fp32 (lda % 4 == 0, K % 4 == 0, 16-byte aligned),
+ * planes = 3 * N * spnet_bf16x3_kp(K) bf16 in K-major order, B element (n, k):  C[M][N] = A * B^T-of-planes.
+ * spnet_split_bf16x3: planes of a Keras pointwise kernel W[K][N] in the forward form.  spnet_split_bf16x3_batched: all
+ * splits of a step in one launch, job = {W, planes, K, N, sn, sk} as six 64-bit words in device memory, element (n, k) =
+ * W[n*sn + k*sk] (forward: sn 1, sk cout; data gradient dX = dY W^T: K = cout, N = cin, sn cout, sk 1); max_elems = the
+ * largest N * kp(K).  _colstats: BatchNorm column sums of C as [*stat_rows][2][N] partial rows, *stat_rows = ceil(M/96). */
+long spnet_bf16x3_kp(int K);
+int spnet_split_bf16x3(const float* W, void* planes, int K, int N, void* stream);
+int spnet_split_bf16x3_batched(const void* jobs, int njobs, long max_elems, void* stream);
+int spnet_gemm_bf16x3_fwd(const float* A, int lda, const void* planes, float* C, int ldc, int M, int N, int K, void* stream);
+int spnet_gemm_bf16x3_fwd_colstats(const float* A, int lda, const void* planes, float* C, int ldc, int M, int N, int K,
+                                   float* colstats, int* stat_rows, void* stream);
 /* C += A B, formed in the epilogue (no K split): a data gradient added onto what another consumer of the same tensor
  * has already left in C (the branch convolutions of an inception block; call site spnet/models.py:357-359). */
 int spnet_gemm_f32_accumulate(const float* A, int a_major, int lda, const float* B, int b_major, int ldb, float* C,

@@ -1,4 +1,6 @@
-// fp32 GEMM on the bf16 matrix cores by operand splitting ("bf16x3"): a probe of the road NOT taken by the product path.
+// fp32 GEMM on the bf16 matrix cores by operand splitting ("bf16x3"): the forward and data-gradient GEMMs of the pointwise
+// (1x1) convolutions with >= 256 output columns (keras SeparableConv2D's pointwise step and the residual 1x1 convolutions of
+// Xception, the pointwise layers of MobileNet; call site spnet/models.py:346-359) since round 4.
 //
 // Every fp32 operand is the exact sum of three bf16 numbers, x = h + m + l (h = bf16(x), m = bf16(x - h), l = bf16(x - h - m):
 // 3 x 8 significant bits = the 24 of fp32), and a product a*b is the sum of nine piece products.  Six of them --
@@ -6,23 +8,28 @@
 // -- carry everything down to 2^-24 of the product (the dropped am*bl, al*bm, al*bl are <= 2^-23.4 relative in sum), each
 // piece product is exact in fp32 (8 x 8 bits) and v_mfma_f32_16x16x32_bf16 accumulates in fp32: six bf16 MFMAs (6 x 16
 // cycles for a 16x16x32 block) in place of eight fp32 MFMAs (8 x 32 cycles) -- 2.67x fewer matrix-pipe cycles for a result
-// whose error is of the size of ONE fp32 rounding per product.  It is NOT the k-ordered fmaf chain of spnet_gemm_f32
-// (which the product path keeps: `dtype f32` of the bench line means exactly that), so it is reported as `roofline_alt` only
-// (optional part): forward operand form, the network's dominant shape, error measured against fp64
-// and against the exact kernel in tests/test_kernels_gpu.py.
+// whose error is of the size of ONE fp32 rounding per product: against float64 its error is no larger than that of the
+// k-ordered fmaf chain of spnet_gemm_f32 (tests/test_kernels_gpu.py), but it is not that chain's bits.  Rounds 2-3 kept it
+// as a probe; round 4 measured it in the whole train step (x1.085) and ran the whole GPU suite through it at the tolerances
+// set from the exact kernels' own errors, and made it the product path for these two operand forms (Engine(pointwise=
+// "f32") keeps the exact chain; weight gradients, blended data gradients, k x k convolutions and the Dense head are fp32
+// MFMA kernels as before).  `dtype` of the bench line says so.
 //
-// Forward form: A [M][K] fp32 (activations, split on the fly while the tile is staged), B given as three bf16 planes in
-// K-major order [3][N][Kp] (weights: split ONCE per optimizer step by spnet_split_bf16x3, Kp = K rounded up to 32, zero
-// padded), C [M][N] fp32.  96x96 tile per workgroup (2 x 2 waves of 48x48 = 3x3 MFMA tiles), K step 32 = one MFMA depth,
+// Operand forms: A [M][K] fp32 (activations or gradients, split on the fly while the tile is staged), B given as three bf16
+// planes in K-major order [3][N][Kp] (weights: split ONCE per optimizer step by spnet_split_bf16x3_batched, Kp = K rounded
+// up to 32, zero padded), C [M][N] fp32; forward: B element (n, k) = W[k][n]; data gradient dX = dY W^T: (n, k) = W[n][k].
+// 96x96 tile per workgroup (2 x 2 waves of 48x48 = 3x3 MFMA tiles), K step 32 = one MFMA depth,
 // two LDS buffers with XOR-swizzled 16-byte chunks (conflict-free fragment reads without padding: 72 KB, two workgroups
 // per CU), two register sets so that a K step is in flight for a whole iteration, its split and LDS stores issued in
-// the shadow of the MFMAs (sched_group_barrier), one barrier per step.
+// the shadow of the MFMAs (sched_group_barrier), one barrier per step; optional BatchNorm column sums in the epilogue.
 //
-// Measured (MI355X, 6144 x 728 x 728, profiles/r03_f_diag_bf16x3.txt): 53 us against the exact kernel's 67 us (x1.26), error
-// against fp64 no larger than the exact kernel's.  Knock-out builds of the same kernel: MFMAs + fragment reads alone 32 us,
-// fetch + split + stage alone 32 us, and the two do not overlap -- the 96x96 tile pulls 30 KB per K step through the vector
-// memory path (A as fp32 + B as three planes = 10 B per operand element; 353 MB per launch, 6.6 TB/s from L2 / Infinity
-// Cache), 1.7x the exact kernel's bytes, so the memory path and not the matrix pipe (16.5 us of MFMA at peak) sets the time.
+// Measured (MI355X): 6144 x 728 x 728 in the train step 49.6 us against the exact kernel's 67.7 (x0.73), 24576 x 728 x 728 in
+// the predict plan 174 against 225 us; shapes with 128 output columns lose (a 96-wide tile wastes a third of its second
+// column tile: 168 against 147 us on 372000 x 128 x 128) and stay on the exact kernel.  Knock-out builds: MFMAs + fragment
+// reads alone 32 us, fetch + split + stage alone 32 us, and the two do not overlap -- the 96x96 tile pulls 30 KB per K step
+// through the vector memory path (A as fp32 + B as three planes = 10 B per operand element; 353 MB per launch, 6.6 TB/s
+// from L2 / Infinity Cache), 1.7x the exact kernel's bytes, so the memory path and not the matrix pipe (16.5 us of MFMA at
+// peak) sets the time.
 #include "common.h"
 
 typedef short bf16x8 __attribute__((ext_vector_type(8)));

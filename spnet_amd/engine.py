@@ -359,8 +359,16 @@ def _glorot_fans(name, shape):
 
 class Engine:
     def __init__(self, H, W, batch, n_out=576, device="cuda:0", loss_type="same", seed=0,
-                 train=True, adam_eps=1e-7, share_from=None, rank=0, sigmoid_cols=None, backbone="Xception"):
-        """rank: data-parallel rank, mixed into the initial dropout seed so that replicas draw different masks."""
+                 train=True, adam_eps=1e-7, share_from=None, rank=0, sigmoid_cols=None, backbone="Xception",
+                 pointwise="bf16x3"):
+        """rank: data-parallel rank, mixed into the initial dropout seed so that replicas draw different masks.
+        pointwise: which kernel runs the forward and data-gradient GEMMs of the pointwise (1x1) convolutions with >= 256
+        output columns -- "bf16x3" (csrc/gemm_bf16x3.hip: fp32 operands as three bf16 pieces on the bf16 matrix cores, fp32
+        accumulation, fp32-accurate; the default since round 4) or "f32" (the k-ordered fp32 MFMA chain of spnet_gemm_f32
+        for every GEMM, as in rounds 1-3)."""
+        if pointwise not in ("bf16x3", "f32"):
+            raise ValueError("pointwise must be 'bf16x3' or 'f32'")
+        self.pointwise = pointwise
         if not torch.cuda.is_available():
             raise RuntimeError("spnet_amd.Engine needs a HIP device (no CPU fallback)")
         self.H, self.W, self.B, self.n_out = int(H), int(W), int(batch), int(n_out)
@@ -380,10 +388,7 @@ class Engine:
         # batch size continues Adam's bias correction and the dropout seed sequence instead of restarting them.
         self._opt = share_from._opt if share_from is not None else {"t": 0, "drop_seed": 12345 + 7919 * int(rank)}
         self.prof = None                # KernelTimer or None
-        # Measurement hook (None in the product): an object that takes over the forward / data-gradient GEMMs of the
-        # pointwise convolutions -- tools/probes/bf16x3_hook.py runs them on the bf16 matrix cores by operand splitting for
-        # bench.py's `roofline_alt` leg (same results to fp32 accuracy, not the same bits; tests/test_engine_gpu.py).
-        self.pw_alt = None
+        self._pw_layers = []            # every Pointwise of this plan (their bf16x3 weight planes: _build_planes)
         self.deferred_wgrads = []       # (x, dy, gw, cin, cout, M) of layers whose dW waits for the batched launch
         self.dw_reduce_jobs = []        # (partials, grad, rows, 9*C) of every depthwise layer
         self._dw_reduce_table = None
@@ -410,6 +415,12 @@ class Engine:
         self._tver = share_from._tver if share_from is not None else [0]
         self._wT_ver = share_from._wT_ver if share_from is not None else [-1]
         self._wT_jobs = None
+        # bf16x3 operand planes of the pointwise kernels (name -> (forward planes, data-gradient planes)), shared by all
+        # plans over one weight set; [_planes_ver] = the value of _tver they were last split at
+        self._planes = share_from._planes if share_from is not None else {}
+        self._planes_ver = share_from._planes_ver if share_from is not None else [-1]
+        self._planes_gen = share_from._planes_gen if share_from is not None else [0]      # bumped by every allocation
+        self._planes_jobs = None
         self._igraph = None             # captured inference forward (predict_step)
         self._coeff_ver = -1
         self._infer_fresh = True
@@ -423,6 +434,7 @@ class Engine:
             self._build_params(seed)
         self.update_mask = None         # optional flat 0/1 tensor: frozen parameters are skipped by Adam
         self._build_graph()
+        self._build_planes()
 
     @property
     def t(self):
@@ -666,8 +678,7 @@ class Engine:
             self._coeff_ver = -1
         else:
             self._infer_fresh = self._coeff_ver != self._wver[0]
-        if self.pw_alt is not None:         # (operand planes of the current weights: on THIS stream, before any branch)
-            self.pw_alt.ensure_fresh()
+        self.refresh_planes()               # (on THIS stream, before any branch reads them)
         for node in self.nodes:
             node.fwd(training)
         if self.sigmoid_cols is not None:
@@ -703,8 +714,7 @@ class Engine:
         self.deferred_wgrads = []
         if self._wT_ver[0] != self._tver[0]:    # weights were loaded / re-initialised since the last optimizer step
             self.refresh_transposes()
-        if self.pw_alt is not None:
-            self.pw_alt.ensure_fresh()
+        self.refresh_planes()
         for node in reversed(self.nodes):
             g = node.bwd(g)
             if node is self._first_middle:      # (flushing in 2 or 4 smaller batches measured no faster)
@@ -715,6 +725,47 @@ class Engine:
         self.reduce_depthwise_wgrads()
         if self.wgrad_stream is not None:      # every weight gradient must have landed before the optimizer
             torch.cuda.current_stream().wait_stream(self.wgrad_stream)
+
+    def _build_planes(self):
+        """bf16x3 operand planes for every pointwise kernel of this plan that a bf16x3 launch will read (allocated once per
+        weight set: a later plan over the same weights finds them, and adds the data-gradient planes an inference plan
+        had no use for)."""
+        for pw in self._pw_layers:
+            if not (pw.x3_fwd or pw.x3_dgrad):
+                continue
+            ent = self._planes.setdefault(pw.wname, [None, None])
+            if pw.x3_fwd and ent[0] is None:
+                ent[0] = torch.zeros(3 * pw.cout * int(L.spnet_bf16x3_kp(pw.cin)), dtype=torch.int16, device=self.dev)
+                self._planes_gen[0] += 1
+            if pw.x3_dgrad and ent[1] is None:
+                ent[1] = torch.zeros(3 * pw.cin * int(L.spnet_bf16x3_kp(pw.cout)), dtype=torch.int16, device=self.dev)
+                self._planes_gen[0] += 1
+        if self._planes_jobs is None or self._planes_jobs[1] != self._planes_gen[0]:
+            self._planes_ver[0] = -1
+
+    def refresh_planes(self):
+        """The weights split into their bf16 planes, both operand forms, ONE batched launch -- whenever theta changed since
+        the last split (optimizer step, load, re-initialisation).  Called at the start of forward() / backward() on the
+        main stream: the split is ordered in front of every consumer on every stream (a strided block's residual
+        convolution runs on the side stream)."""
+        if self.pointwise != "bf16x3" or not self._planes or self._planes_ver[0] == self._tver[0]:
+            return
+        if self._planes_jobs is None or self._planes_jobs[1] != self._planes_gen[0]:
+            flat, mx = [], 1
+            for wname, (pf, pd) in self._planes.items():
+                off, n, shape = self.p_off[wname]
+                cin, cout = int(shape[-2]), int(shape[-1])
+                w = self.theta.data_ptr() + 4 * off
+                if pf is not None:      # forward: B element (n = cout, k = cin) = W[k][n]
+                    flat += [w, pf.data_ptr(), cin, cout, 1, cout]
+                    mx = max(mx, pf.numel() // 3)
+                if pd is not None:      # data gradient dX = dY W^T: (n = cin, k = cout) = W[n][k]
+                    flat += [w, pd.data_ptr(), cout, cin, cout, 1]
+                    mx = max(mx, pd.numel() // 3)
+            self._planes_jobs = (torch.tensor(flat, dtype=torch.int64, device=self.dev), self._planes_gen[0], len(flat) // 6, mx)
+        table, _, nj, mx = self._planes_jobs
+        L.spnet_split_bf16x3_batched(table.data_ptr(), nj, mx, _stream())
+        self._planes_ver[0] = self._tver[0]
 
     def transposed(self, wname):
         """W^T buffer ([cout][cin]) of a pointwise kernel; kept current by refresh_transposes()."""
@@ -1166,6 +1217,13 @@ class Pointwise:
         self.w = eng.P(wname)
         self.wname = wname
         self.gw = eng.G(wname) if eng.train_capable else None
+        # bf16x3 kernel (csrc/gemm_bf16x3.hip) for the forward / data-gradient GEMM where its 96-wide tile pays: from 256
+        # output columns on (in-step, us: 6144x728x728 67.7 -> 49.6, 94752x256x256 124 -> 103, 1536x1536x1024 52 -> 42;
+        # 372000x128x128 147 -> 169: stays on the exact kernel)
+        x3 = eng.pointwise == "bf16x3" and cin % 4 == 0 and cout % 4 == 0
+        self.x3_fwd = x3 and cout >= 256
+        self.x3_dgrad = x3 and cin >= 256 and eng.train_capable
+        eng._pw_layers.append(self)
         # BatchNorm backward blended into the data-gradient GEMM's A operand (bwd_blend) instead of an elementwise
         # pass of its own.  The blend reads BOTH g and yp once per COLUMN tile of dX, so it only pays while dX has
         # one or two column tiles; measured on MI355X (tools/gemm_sweep.py blend, us incl. the BN kernels):
@@ -1174,15 +1232,35 @@ class Pointwise:
         self.wT = eng.transposed(wname) if self.blend else None     # [cout][cin]: forward operand form for the blend
         self.defer_wgrad = defer_wgrad      # dW is left to Engine.flush_deferred_wgrads() (one batched launch)
 
+    def _x3(self, tag, A, lda, planes, C, ldc, N, K, colstats_region=None):
+        """One bf16x3 launch: C[M][N] = A[M][K] x planes (+ BatchNorm column sums of C); returns the partial row count."""
+        e = self.e
+        prof = e.prof
+        t0 = prof.start() if prof is not None else None
+        rows = 0
+        if colstats_region is None:
+            L.spnet_gemm_bf16x3_fwd(L.ptr(A), lda, L.ptr(planes), L.ptr(C), ldc, self.M, N, K, _stream())
+        else:
+            if (self.M + 95) // 96 * 2 * N > colstats_region[1]:
+                raise RuntimeError("BatchNorm partial region too small for M=%d N=%d" % (self.M, N))
+            L.spnet_gemm_bf16x3_fwd_colstats(L.ptr(A), lda, L.ptr(planes), L.ptr(C), ldc, self.M, N, K,
+                                             e.ws_ptr(colstats_region), __import__("ctypes").addressof(_stat_rows), _stream())
+            rows = _stat_rows.value
+        if prof is not None:
+            prof.stop("gemm", t0, 2.0 * self.M * N * K, (tag, self.M, N, K))
+        return rows
+
     def fwd(self, x, y):
-        if self.e.pw_alt is not None:
-            return self.e.pw_alt.fwd(self, x, y)
+        if self.x3_fwd and self.e.pointwise == "bf16x3":
+            self._x3("x3 aB", x, self.cin, self.e._planes[self.wname][0], y, self.cout, self.cout, self.cin)
+            return
         _gemm(x, K_MAJOR, self.cin, self.w, OUT_MAJOR, self.cout, y, self.cout, self.M, self.cout, self.cin, self.e)
 
     def fwd_colstats(self, x, y, region=WS_BNP):
         """Forward + BatchNorm column sums of y left in `region`; returns the partial row count."""
-        if self.e.pw_alt is not None:
-            return self.e.pw_alt.fwd_colstats(self, x, y, region)
+        if self.x3_fwd and self.e.pointwise == "bf16x3":
+            return self._x3("x3 aB+stats", x, self.cin, self.e._planes[self.wname][0], y, self.cout, self.cout, self.cin,
+                            colstats_region=region)
         return _gemm_colstats(x, self.cin, self.w, self.cout, y, self.cout, self.M, self.cout, self.cin, self.e,
                               region=region)
 
@@ -1202,8 +1280,8 @@ class Pointwise:
             with torch.cuda.stream(side):
                 _gemm(x, OUT_MAJOR, self.cin, dy, OUT_MAJOR, self.cout, self.gw, self.cout, self.cin, self.cout,
                       self.M, e, region=WS_GEMM2)
-        if dx is not None and e.pw_alt is not None:
-            e.pw_alt.dgrad(self, dy, dx)
+        if dx is not None and self.x3_dgrad and e.pointwise == "bf16x3":
+            self._x3("x3 ab", dy, self.cout, e._planes[self.wname][1], dx, self.cin, self.cin, self.cout)
         elif dx is not None:    # dx[M,cin] = dy[M,cout] @ W^T: W read in place as a K-major B operand
             _gemm(dy, K_MAJOR, self.cout, self.w, K_MAJOR, self.cout, dx, self.cin, self.M, self.cin, self.cout, e)
 

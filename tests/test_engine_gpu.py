@@ -245,36 +245,36 @@ def test_stream_accessor_matches_the_public_handle():
     assert L.current_stream() == torch.cuda.current_stream().cuda_stream
 
 
-def test_bf16x3_hook_step_matches_oracle(setup):
-    """Engine.pw_alt (a measurement hook, None in the product): with tools/probes/bf16x3_hook.py the forward and
-    data-gradient GEMMs of the pointwise convolutions run on the bf16 matrix cores by operand splitting.  Not the exact
-    kernels' bits -- but the same results to fp32 accuracy: a training forward / backward through the hook meets the
-    suite's own gradient tolerance against the fp64 oracle on the device's decisions, and its output is within 1e-5 of
-    the exact engine's."""
+def test_exact_chain_mode_and_bf16x3_mode_agree(setup):
+    """Engine(pointwise=...): "bf16x3" (the default: pointwise forward / data-gradient GEMMs with >= 256 output columns on
+    csrc/gemm_bf16x3.hip) and "f32" (every GEMM the k-ordered fp32 MFMA chain, rounds 1-3).  Not the same bits -- the same
+    results to fp32 accuracy: a training forward / backward in either mode meets the suite's gradient tolerance against
+    the fp64 oracle on the device's decisions, the outputs are within 1e-5 of each other, and the default plan really
+    launches the bf16x3 kernel."""
     _need_gpu()
-    from tools.probes import probe_lib
-    if not probe_lib.available():
-        pytest.skip("tools/probes/lib/libspnet_probe.so not built (make -C tools/probes)")
-    from tools.probes.bf16x3_hook import Bf16x3Pointwise
     from tests.parity_util import assert_gradients_match, rel_err
-    eng, P, X, Y = setup
-    eng.load_state_dict(P)
+    from spnet_amd.engine import Engine, KernelTimer
+    _, P, X, Y = setup
     seed = 99
     h2, w2 = H // 2, W // 2
     mask = torch.tensor(dropout_mask(B * h2 * w2 * 3, seed).reshape(B, h2, w2, 3))
     outs = []
-    try:
-        for alt in (None, Bf16x3Pointwise(eng)):
-            eng.pw_alt = alt
-            eng.load_state_dict(P)                       # moving statistics back to P
-            eng.set_drop_seed(seed)
-            out = eng.forward(X.cuda(), training=True).clone()
-            eng.loss(Y.cuda())
-            eng.backward()
-            torch.cuda.synchronize()
-            outs.append(out.cpu())
-            assert_gradients_match(eng, P, X, Y, mask)
-        assert not torch.equal(outs[0], outs[1])          # another summation: not the same bits ...
-        assert rel_err(outs[1].numpy(), outs[0].numpy()) <= 1e-5      # ... the same numbers
-    finally:
-        eng.pw_alt = None
+    for mode in ("bf16x3", "f32"):
+        eng = Engine(H, W, B, device="cuda:0", seed=11, pointwise=mode)
+        eng.load_state_dict(P)
+        eng.set_drop_seed(seed)
+        eng.prof = KernelTimer()
+        out = eng.forward(X.cuda(), training=True).clone()
+        eng.loss(Y.cuda())
+        eng.backward()
+        torch.cuda.synchronize()
+        n_x3 = sum(1 for t in eng.prof.tags.values() if str(t[0]).startswith("x3"))
+        assert (n_x3 > 40) == (mode == "bf16x3"), n_x3
+        eng.prof = None
+        outs.append(out.cpu())
+        assert_gradients_match(eng, P, X, Y, mask)
+        del eng
+    assert not torch.equal(outs[0], outs[1])          # another summation: not the same bits ...
+    assert rel_err(outs[1].numpy(), outs[0].numpy()) <= 1e-5      # ... the same numbers
+    with pytest.raises(ValueError):
+        Engine(H, W, B, device="cuda:0", pointwise="bf16")

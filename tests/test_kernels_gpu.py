@@ -147,26 +147,23 @@ def test_gemm_accumulate_into_c(L, M, N, K, form, tile):
 
 
 @pytest.mark.parametrize("M,N,K", [(6144, 728, 728), (200, 96, 32), (97, 100, 260), (1536, 1024, 1536)])
-def test_gemm_bf16x3_probe_accuracy(L, M, N, K):
-    """The bf16x3 probe (fp32 operands as three bf16 pieces, six bf16 MFMAs, fp32 accumulation; NOT on the product path):
+def test_gemm_bf16x3_accuracy(L, M, N, K):
+    """The bf16x3 kernel (fp32 operands as three bf16 pieces, six bf16 MFMAs, fp32 accumulation; the pointwise forward /
+    data-gradient GEMMs of the product path since round 4):
     its error against float64 is of the size of the exact fp32 kernel's own -- within 3x of it, and below 2e-6 of the
     row / column norms product -- on random operands with a wide dynamic range; the weight planes reproduce W exactly."""
-    from tools.probes import probe_lib
-    if not probe_lib.available():
-        pytest.skip("tools/probes/lib/libspnet_probe.so not built (make -C tools/probes)")
-    PL = probe_lib.load()
     rs = np.random.RandomState(M + N)
     A = (rs.randn(M, K) * np.exp(rs.randn(M, K))).astype(np.float32)
     W = (rs.randn(K, N) * 0.1 * np.exp(rs.randn(K, N))).astype(np.float32)
     a, w = dev(A), dev(W)
-    Kp = int(PL.spnet_bf16x3_kp(K))
+    Kp = int(L.spnet_bf16x3_kp(K))
     planes = torch.zeros(3 * N * Kp, dtype=torch.int16, device="cuda")
-    assert 0 == PL.spnet_split_bf16x3(w.data_ptr(), planes.data_ptr(), K, N, st())
+    L.spnet_split_bf16x3(w.data_ptr(), planes.data_ptr(), K, N, st())
     pl = planes.view(torch.bfloat16).reshape(3, N, Kp).float().cpu().double()
     assert torch.equal((pl[0] + pl[1] + pl[2])[:, :K].T.contiguous(), torch.from_numpy(W).double())     # h + m + l == w exactly
     assert float(pl[:, :, K:].abs().max()) == 0.0 if Kp > K else True
     c3 = torch.full((M, N), float("nan"), device="cuda")
-    assert 0 == PL.spnet_gemm_bf16x3_fwd(a.data_ptr(), K, planes.data_ptr(), c3.data_ptr(), N, M, N, K, st())
+    L.spnet_gemm_bf16x3_fwd(a.data_ptr(), K, planes.data_ptr(), c3.data_ptr(), N, M, N, K, st())
     c1 = torch.empty(M, N, device="cuda")
     L.spnet_gemm_f32(a.data_ptr(), 0, K, w.data_ptr(), 1, N, c1.data_ptr(), N, M, N, K, 1, None, 0, None, 0, st())
     ref = A.astype(np.float64) @ W.astype(np.float64)
@@ -176,6 +173,51 @@ def test_gemm_bf16x3_probe_accuracy(L, M, N, K):
     assert np.isfinite(e3).all()
     assert e3.max() < 2e-6 and e3.max() < 3.0 * max(e1.max(), 1e-8), (e3.max(), e1.max())
     assert np.sqrt((e3 ** 2).mean()) < 3.0 * max(np.sqrt((e1 ** 2).mean()), 1e-9)
+
+
+@pytest.mark.parametrize("M,N,K", [(6144, 728, 728), (1000, 256, 128), (97, 260, 100)])
+def test_gemm_bf16x3_colstats_batched_split_and_dgrad_form(L, M, N, K):
+    """The pieces the engine uses: spnet_split_bf16x3_batched makes the planes of both operand forms in one launch
+    (identical to the single split for the forward form); the forward GEMM with BatchNorm column sums leaves exactly the
+    sums of the C it wrote, tile row by tile row; the data-gradient form dX = dY W^T on the planes of W as stored."""
+    import ctypes
+    rs = np.random.RandomState(K)
+    A = (rs.randn(M, K)).astype(np.float32)
+    W = (rs.randn(K, N) * 0.1).astype(np.float32)
+    G = (rs.randn(M, N)).astype(np.float32)
+    a, w, g = dev(A), dev(W), dev(G)
+    kf, kd = int(L.spnet_bf16x3_kp(K)), int(L.spnet_bf16x3_kp(N))
+    pf1 = torch.zeros(3 * N * kf, dtype=torch.int16, device="cuda")
+    L.spnet_split_bf16x3(w.data_ptr(), pf1.data_ptr(), K, N, st())
+    pf = torch.full((3 * N * kf,), -1, dtype=torch.int16, device="cuda")
+    pd = torch.full((3 * K * kd,), -1, dtype=torch.int16, device="cuda")
+    jobs = torch.tensor([w.data_ptr(), pf.data_ptr(), K, N, 1, N, w.data_ptr(), pd.data_ptr(), N, K, N, 1], dtype=torch.int64,
+                        device="cuda")
+    L.spnet_split_bf16x3_batched(jobs.data_ptr(), 2, max(N * kf, K * kd), st())
+    assert torch.equal(pf, pf1)
+    pl = pd.view(torch.bfloat16).reshape(3, K, kd).float().cpu().double()
+    assert torch.equal((pl[0] + pl[1] + pl[2])[:, :N], torch.from_numpy(W).double())          # element (n=k_in, k=n_out) = W[n][k]
+    # forward + column sums
+    c = torch.full((M, N), float("nan"), device="cuda")
+    rows = ctypes.c_int(0)
+    cs = torch.full(((M + 95) // 96 * 2 * N,), float("nan"), device="cuda")
+    L.spnet_gemm_bf16x3_fwd_colstats(a.data_ptr(), K, pf.data_ptr(), c.data_ptr(), N, M, N, K, cs.data_ptr(),
+                                     ctypes.addressof(rows), st())
+    assert rows.value == (M + 95) // 96
+    c0 = torch.empty(M, N, device="cuda")
+    L.spnet_gemm_bf16x3_fwd(a.data_ptr(), K, pf.data_ptr(), c0.data_ptr(), N, M, N, K, st())
+    assert torch.equal(c, c0)
+    close(c, A.astype(np.float64) @ W.astype(np.float64), rtol=2e-5, atol=2e-5 * np.sqrt(K))
+    part = cs.reshape(rows.value, 2, N).cpu().double().numpy()
+    cn = c.cpu().double().numpy()
+    for t in range(rows.value):
+        blk = cn[t * 96:(t + 1) * 96]
+        np.testing.assert_allclose(part[t, 0], blk.sum(0), rtol=1e-5, atol=1e-4)
+        np.testing.assert_allclose(part[t, 1], (blk ** 2).sum(0), rtol=1e-5, atol=1e-4)
+    # data gradient: dX[M][K] = G[M][N] W^T
+    dx = torch.full((M, K), float("nan"), device="cuda")
+    L.spnet_gemm_bf16x3_fwd(g.data_ptr(), N, pd.data_ptr(), dx.data_ptr(), K, M, K, N, st())
+    close(dx, G.astype(np.float64) @ W.astype(np.float64).T, rtol=2e-5, atol=2e-5 * np.sqrt(N))
 
 
 @pytest.mark.parametrize("tile", [0, 3, 5, 6])

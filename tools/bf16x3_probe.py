@@ -7,8 +7,6 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import torch
 from spnet_amd import _lib as L
-from tools.probes import probe_lib
-PL = probe_lib.load()
 
 st = lambda: torch.cuda.current_stream().cuda_stream
 
@@ -30,13 +28,13 @@ for M, N, K in ((6144, 728, 728), (24576, 728, 728), (6144, 1024, 728), (1536, 2
     rs = np.random.RandomState(M)
     A, W = rs.randn(M, K).astype(np.float32), (rs.randn(K, N) * 0.05).astype(np.float32)
     a, w = torch.from_numpy(A).cuda(), torch.from_numpy(W).cuda()
-    Kp = int(PL.spnet_bf16x3_kp(K))
+    Kp = int(L.spnet_bf16x3_kp(K))
     planes = torch.zeros(3 * N * Kp, dtype=torch.int16, device="cuda")
-    PL.spnet_split_bf16x3(w.data_ptr(), planes.data_ptr(), K, N, st())
+    L.spnet_split_bf16x3(w.data_ptr(), planes.data_ptr(), K, N, st())
     c3, c1 = torch.empty(M, N, device="cuda"), torch.empty(M, N, device="cuda")
-    f3 = lambda: PL.spnet_gemm_bf16x3_fwd(a.data_ptr(), K, planes.data_ptr(), c3.data_ptr(), N, M, N, K, st())
+    f3 = lambda: L.spnet_gemm_bf16x3_fwd(a.data_ptr(), K, planes.data_ptr(), c3.data_ptr(), N, M, N, K, st())
     f1 = lambda: L.spnet_gemm_f32(a.data_ptr(), 0, K, w.data_ptr(), 1, N, c1.data_ptr(), N, M, N, K, 1, None, 0, None, 0, st())
-    fs = lambda: PL.spnet_split_bf16x3(w.data_ptr(), planes.data_ptr(), K, N, st())
+    fs = lambda: L.spnet_split_bf16x3(w.data_ptr(), planes.data_ptr(), K, N, st())
     t3, t1, ts = t(f3), t(f1), t(fs)
     ref = A.astype(np.float64) @ W.astype(np.float64)
     scale = np.sqrt((A.astype(np.float64) ** 2).sum(1))[:, None] * np.sqrt((W.astype(np.float64) ** 2).sum(0))[None, :]

@@ -15,7 +15,7 @@ import collections, csv, json, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 FAMILIES = {
-    "gemm": ("gemm_f32_kernel", "reduce_slabs_kernel", "conv3x3_fwd_kernel", "conv3x3_dgrad_kernel", "conv3x3_wgrad_kernel"),
+    "gemm": ("gemm_f32_kernel", "gemm_bf16x3_fwd_kernel", "reduce_slabs_kernel", "conv3x3_fwd_kernel", "conv3x3_dgrad_kernel", "conv3x3_wgrad_kernel"),
     "dw_fwd": ("dw3x3_tile_fwd_kernel", "dw3x3_stream_fwd_kernel"),
     "dw_bwd": ("dw3x3_tile_bwd_kernel", "dw3x3_stream_bwd_kernel"),
 }

@@ -18,7 +18,7 @@ tot = sum(v[1] for v in agg.values())
 print("step span %.3f ms, kernel time %.3f ms, %d launches" % (span, tot / 1e6, len(seg)))
 fam = collections.defaultdict(float)
 for name, (n, ns) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
-    f = ("gemm" if ("gemm_f32" in name or "reduce_slabs" in name or "conv3x3_fwd_k" in name or "conv3x3_dgrad" in name or "conv3x3_wgrad" in name)
+    f = ("gemm" if ("gemm_f32" in name or "gemm_bf16x3" in name or "split_bf16x3" in name or "reduce_slabs" in name or "conv3x3_fwd_k" in name or "conv3x3_dgrad" in name or "conv3x3_wgrad" in name)
          else "dw" if "dw3x3" in name else "bn" if "bn_" in name else "stem" if ("conv3x3" in name or "conv1_" in name)
          else "pool" if "pool" in name else "other")
     fam[f] += ns
