@@ -1220,9 +1220,13 @@ class Pointwise:
         # bf16x3 kernel (csrc/gemm_bf16x3.hip) for the forward / data-gradient GEMM where its 96-wide tile pays: from 256
         # output columns on (in-step, us: 6144x728x728 67.7 -> 49.6, 94752x256x256 124 -> 103, 1536x1536x1024 52 -> 42;
         # 372000x128x128 147 -> 169: stays on the exact kernel)
+        # ... and while its 96 x 96 tiles still fill the chip: at least 192 of them (the reference's own 331 x 331 layout at
+        # batch 16 has 1,600-row middle-flow GEMMs, 136 tiles: 3,120 -> 2,950 training images/s with the bf16x3 kernel
+        # there, so those stay on the exact kernel's autotuned 32-row tiles; 1536x1024x728 (176 tiles): 31.6 -> 32.3 us)
         x3 = eng.pointwise == "bf16x3" and cin % 4 == 0 and cout % 4 == 0
-        self.x3_fwd = x3 and cout >= 256
-        self.x3_dgrad = x3 and cin >= 256 and eng.train_capable
+        tiles = lambda n: ((M + 95) // 96) * ((n + 95) // 96)
+        self.x3_fwd = x3 and cout >= 256 and tiles(cout) >= 192
+        self.x3_dgrad = x3 and cin >= 256 and tiles(cin) >= 192 and eng.train_capable
         eng._pw_layers.append(self)
         # BatchNorm backward blended into the data-gradient GEMM's A operand (bwd_blend) instead of an elementwise
         # pass of its own.  The blend reads BOTH g and yp once per COLUMN tile of dX, so it only pays while dX has

@@ -118,7 +118,8 @@ def test_bench_self_launched_two_ranks_on_one_gpu():
 
 def test_bench_default_line_carries_every_block():
     """The driver's N = 1 command with short step counts: one JSON line with the roofline of the dominant family, the
-    secondary family by sub-family, the predict / 331 x 331 legs, the bf16x3 probe as `roofline_alt` and the CPU baseline
+    secondary family by sub-family (and, inside `roofline`, by arithmetic), the predict / 331 x 331 / other-backbone legs,
+    `roofline_alt` (the bf16x3 kernel isolated, and the all-fp32-chain train step beside the product's) and the CPU baseline
     (one short oracle step here) -- every leg of the default run executes, none is skipped by a flag."""
     import json
     import torch
@@ -133,9 +134,14 @@ def test_bench_default_line_carries_every_block():
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]
     out = json.loads(lines[0])
-    for key in ("roofline", "roofline_secondary", "roofline_alt", "cpu_baseline", "predict", "layout_331", "kernel_families"):
+    for key in ("roofline", "roofline_secondary", "roofline_alt", "cpu_baseline", "predict", "layout_331", "kernel_families",
+                "irv2", "mobilenet"):
         assert key in out, key
-    assert out["n_gpus"] == 1 and out["dtype"] == "f32" and out["value"] > 0
+    assert out["n_gpus"] == 1 and out["dtype"].startswith("f32 (") and "bf16" in out["dtype"] and out["value"] > 0
+    bk = out["roofline"]["by_kernel"]
+    assert len(bk) == 2 and all(v["launches_per_step"] > 0 and v["ms_per_step"] > 0 for v in bk.values())
+    ts = out["roofline_alt"]["train_step"]
+    assert ts["exact_fp32"]["bf16x3_launches_per_step"] == 0 and ts["bf16x3"]["bf16x3_launches_per_step"] > 40
     assert set(out["roofline_secondary"].get("sub_families", out["roofline"].get("sub_families", {}))) >= {"entry", "middle", "exit"}
     alt = out["roofline_alt"]
     assert alt["max_rel_err_vs_f64"] < 5e-7 and alt["avg_launch_us"] > 0 and 0 < alt["frac"] < 1
