@@ -360,15 +360,17 @@ def _glorot_fans(name, shape):
 class Engine:
     def __init__(self, H, W, batch, n_out=576, device="cuda:0", loss_type="same", seed=0,
                  train=True, adam_eps=1e-7, share_from=None, rank=0, sigmoid_cols=None, backbone="Xception",
-                 pointwise="bf16x3"):
+                 pointwise="bf16x3", x3_min_tiles=192):
         """rank: data-parallel rank, mixed into the initial dropout seed so that replicas draw different masks.
         pointwise: which kernel runs the forward and data-gradient GEMMs of the pointwise (1x1) convolutions with >= 256
         output columns -- "bf16x3" (csrc/gemm_bf16x3.hip: fp32 operands as three bf16 pieces on the bf16 matrix cores, fp32
         accumulation, fp32-accurate; the default since round 4) or "f32" (the k-ordered fp32 MFMA chain of spnet_gemm_f32
-        for every GEMM, as in rounds 1-3)."""
+        for every GEMM, as in rounds 1-3).  x3_min_tiles: a layer goes to the bf16x3 kernel only if its GEMM has at least this
+        many 96 x 96 tiles (192: measured, see Pointwise; the parity tests pass 0 so that small test plans run it too)."""
         if pointwise not in ("bf16x3", "f32"):
             raise ValueError("pointwise must be 'bf16x3' or 'f32'")
         self.pointwise = pointwise
+        self.x3_min_tiles = int(x3_min_tiles)
         if not torch.cuda.is_available():
             raise RuntimeError("spnet_amd.Engine needs a HIP device (no CPU fallback)")
         self.H, self.W, self.B, self.n_out = int(H), int(W), int(batch), int(n_out)
@@ -1225,8 +1227,8 @@ class Pointwise:
         # there, so those stay on the exact kernel's autotuned 32-row tiles; 1536x1024x728 (176 tiles): 31.6 -> 32.3 us)
         x3 = eng.pointwise == "bf16x3" and cin % 4 == 0 and cout % 4 == 0
         tiles = lambda n: ((M + 95) // 96) * ((n + 95) // 96)
-        self.x3_fwd = x3 and cout >= 256 and tiles(cout) >= 192
-        self.x3_dgrad = x3 and cin >= 256 and tiles(cin) >= 192 and eng.train_capable
+        self.x3_fwd = x3 and cout >= 256 and tiles(cout) >= eng.x3_min_tiles
+        self.x3_dgrad = x3 and cin >= 256 and tiles(cin) >= eng.x3_min_tiles and eng.train_capable
         eng._pw_layers.append(self)
         # BatchNorm backward blended into the data-gradient GEMM's A operand (bwd_blend) instead of an elementwise
         # pass of its own.  The blend reads BOTH g and yp once per COLUMN tile of dX, so it only pays while dX has

@@ -47,7 +47,10 @@ def test_training_forward_and_every_gradient_at_benchmark_geometry(case):
     itself is 2e-1 away from its fp64 evaluation in single tensors); every decision that differs must be a tie."""
     from spnet_amd.engine import Engine
     P, X, Y, mask, dseed = case
-    eng = Engine(H, W, 2, device="cuda:0", seed=1)
+    # x3_min_tiles = 0: the pointwise forward / data-gradient GEMMs on the bf16x3 kernel as in the batch-32 benchmark plan
+    # (batch 2 has too few rows for the engine's own 192-tile rule)
+    eng = Engine(H, W, 2, device="cuda:0", seed=1, x3_min_tiles=0)
+    assert sum(p.x3_fwd for p in eng._pw_layers) >= 30 and sum(p.x3_dgrad for p in eng._pw_layers) >= 28
     eng.load_state_dict(P)
     eng.set_drop_seed(dseed)
     out = eng.forward(X.cuda(), training=True)

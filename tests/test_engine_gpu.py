@@ -260,7 +260,7 @@ def test_exact_chain_mode_and_bf16x3_mode_agree(setup):
     mask = torch.tensor(dropout_mask(B * h2 * w2 * 3, seed).reshape(B, h2, w2, 3))
     outs = []
     for mode in ("bf16x3", "f32"):
-        eng = Engine(H, W, B, device="cuda:0", seed=11, pointwise=mode)
+        eng = Engine(H, W, B, device="cuda:0", seed=11, pointwise=mode, x3_min_tiles=0)     # (0: also at this small M)
         eng.load_state_dict(P)
         eng.set_drop_seed(seed)
         eng.prof = KernelTimer()

@@ -27,13 +27,17 @@ CASES = [(64, 96, 3, 0), (64, 96, 3, 4), (64, 96, 3, 5), (100, 140, 1, 0), (100,
          (75, 131, 2, 2)]
 
 
+# x3_min_tiles = 0: the bf16x3 kernel on every pointwise layer with >= 256 output columns, as in the benchmark plans (at these
+# sizes the engine's own rule -- at least 192 tiles -- would leave every layer on the exact kernel); 192: the engine as built
+@pytest.mark.parametrize("x3_min_tiles", [0, 192])
 @pytest.mark.parametrize("H,W,B,seed", CASES)
-def test_forward_and_gradients_on_odd_geometries(H, W, B, seed):
+def test_forward_and_gradients_on_odd_geometries(H, W, B, seed, x3_min_tiles):
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
     from spnet_amd.engine import Engine
     P, X, Y, mask, dseed = make_case(H, W, B, seed)
-    eng = Engine(H, W, B, device="cuda:0", seed=H)
+    eng = Engine(H, W, B, device="cuda:0", seed=H, x3_min_tiles=x3_min_tiles)
+    assert any(p.x3_fwd for p in eng._pw_layers) == (x3_min_tiles == 0)
     eng.load_state_dict(P)
     # inference forward
     want = T.forward(P, X, training=False)
