@@ -264,6 +264,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16x3_fwd_kernel(const float* __
 // B operand element (n, k) is W[n * sn + k * sk] -- forward form of a Keras pointwise kernel [cin][cout]: K = cin, N = cout,
 // sn = 1, sk = cout; data-gradient form (dX = dY W^T): K = cout, N = cin, sn = cout, sk = 1.
 __global__ __launch_bounds__(256) void split_bf16x3_batched_kernel(const long long* __restrict__ jobs) {
+  __shared__ float tile[32][33];
   const long long* jb = jobs + 6 * blockIdx.y;
   const float* __restrict__ W = reinterpret_cast<const float*>(jb[0]);
   unsigned short* __restrict__ planes = reinterpret_cast<unsigned short*>(jb[1]);
@@ -271,13 +272,42 @@ __global__ __launch_bounds__(256) void split_bf16x3_batched_kernel(const long lo
   const long sn = jb[4], sk = jb[5];
   const int Kp = (K + 31) / 32 * 32;
   const long total = (long)N * Kp;
-  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-    const int k = (int)(i % Kp), n = (int)(i / Kp);
-    unsigned short h = 0, m = 0, l = 0;
-    if (k < K) split3(W[n * sn + k * sk], h, m, l);
-    planes[i] = h;
-    planes[total + i] = m;
-    planes[2 * total + i] = l;
+  if (sk == 1) {            // k is the contiguous axis of the source as well: straight through, coalesced both ways
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+      const int k = (int)(i % Kp), n = (int)(i / Kp);
+      unsigned short h = 0, m = 0, l = 0;
+      if (k < K) split3(W[n * sn + k], h, m, l);
+      planes[i] = h;
+      planes[total + i] = m;
+      planes[2 * total + i] = l;
+    }
+    return;
+  }
+  // n is the contiguous axis of the source (the forward form of a [cin][cout] kernel): 32 x 32 tiles through LDS, read
+  // along n, written along k
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;          // 32 x 8
+  const int tk = Kp / 32, tn = (N + 31) / 32;
+  for (int t = blockIdx.x; t < tk * tn; t += gridDim.x) {
+    const int k0 = (t % tk) * 32, n0 = (t / tk) * 32;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int k = k0 + ty + 8 * j, n = n0 + tx;
+      tile[ty + 8 * j][tx] = (k < K && n < N) ? W[n * sn + k * sk] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int n = n0 + ty + 8 * j, k = k0 + tx;
+      if (n < N) {
+        unsigned short h, m, l;
+        split3(tile[tx][ty + 8 * j], h, m, l);
+        const long i = (long)n * Kp + k;
+        planes[i] = h;
+        planes[total + i] = m;
+        planes[2 * total + i] = l;
+      }
+    }
+    __syncthreads();
   }
 }
 
