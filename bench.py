@@ -421,15 +421,19 @@ def backbone_leg(dev, backbone, batch, steps=20, warmup=5, predict=False):
 
     for _ in range(warmup):
         step()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        step()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
+    dts = []
+    for _ in range(3):       # (these small steps are close to host-bound: one slow repeat is the host's, not the plan's)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        torch.cuda.synchronize()
+        dts.append(time.perf_counter() - t0)
+    dt = min(dts)
     out = {"workload": "%s, 512x384 frames, batch %d, full train step, uniform-noise frames" % (backbone, batch),
            "train_images_per_sec": round(batch * steps / dt, 1), "ms_per_step": round(1e3 * dt / steps, 3), "steps": steps,
-           "batch": batch}
+           "batch": batch, "repeats_ms_per_step": [round(1e3 * t / steps, 3) for t in dts],
+           "timing": "best of 3 repeats of %d steps (a secondary leg; the headline `value` is one timed region)" % steps}
     tot = time_families(eng, step, max(5, steps // 2), torch.cuda.synchronize).totals()
     n_prof = max(5, steps // 2)
     if "gemm" in tot:
