@@ -39,3 +39,9 @@ veridis_yellow = _bgr((254, 228, 76))
 magma_light = _bgr((253, 252, 197))
 truecolor = yellow
 predcolor = veridis_purple
+
+# (additive, no counterpart in the reference: dtype above stays float32 either way)  Which kernel multiplies the forward /
+# data-gradient GEMMs of the wide pointwise convolutions: 'bf16x3' -- fp32 operands split exactly into three bf16 pieces
+# on the bf16 matrix cores, fp32 accumulation, fp32-accurate (csrc/gemm_bf16x3.hip; the default) -- or 'f32': the
+# k-ordered fp32 MFMA chain for every GEMM.
+pointwise_gemm = 'bf16x3'

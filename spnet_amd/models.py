@@ -257,7 +257,7 @@ class Model:
             eng = self._Engine(self.H, self.W, batch, n_out=self.Y0size, device=self.device, loss_type=cf.loss_type,
                                seed=self.seed, train=train, adam_eps=ADAM_EPS, share_from=root, rank=self.rank,
                                sigmoid_cols=(cf.ind_noobj, cf.vars_per_pred) if self.compound else None,
-                               backbone=self.basemodel)
+                               backbone=self.basemodel, pointwise=getattr(cf, "pointwise_gemm", "bf16x3"))
             if root is None:
                 self._root = eng
             self._engines[key] = eng

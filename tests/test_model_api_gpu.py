@@ -269,3 +269,27 @@ def test_uint8_frames_are_scaled_on_the_device_bit_for_bit():
     assert np.array_equal(y_r, y_u)
     with pytest.raises(TypeError):
         model.predict_u8(U.astype(np.float32))
+
+
+def test_config_selects_the_exact_gemm_chain():
+    """cf.pointwise_gemm (additive): 'bf16x3' (default) or 'f32' = every GEMM on the k-ordered fp32 MFMA chain; the model's
+    plans are built accordingly and both predict the same frames to fp32 accuracy."""
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from spnet_amd import config as cf
+    from spnet_amd import models as M
+    rs = np.random.RandomState(2)
+    X = (rs.rand(4, 96, 128, 1).astype(np.float32) * 2 - 1)
+    old = cf.pointwise_gemm
+    try:
+        preds = {}
+        for mode in ("bf16x3", "f32"):
+            cf.pointwise_gemm = mode
+            m = M.Model((96, 128, 1), Y0size=576, seed=7)
+            assert m._root.pointwise == mode
+            preds[mode] = m.predict(X, batch_size=4)
+    finally:
+        cf.pointwise_gemm = old
+    scale = float(np.abs(preds["f32"]).max())
+    np.testing.assert_allclose(preds["bf16x3"], preds["f32"], rtol=1e-4, atol=1e-5 * scale)
