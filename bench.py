@@ -37,7 +37,12 @@ DW_FWD_BYTES_PER_IMAGE = 63.1e6
 # cores with every fp32 operand split exactly into three bf16 pieces (six bf16 MFMAs per product block, fp32 accumulate:
 # error against float64 no larger than the fp32 fmaf chain's, tests/test_kernels_gpu.py); all other GEMMs, the weight
 # gradients included, are fp32 MFMA chains.  `roofline_alt.train_step` carries the all-fp32-chain step beside it.
-DTYPE = "f32 (pointwise fwd/dgrad GEMMs: f32 operands as 3 bf16 pieces on bf16 MFMA, f32 accumulate; all else f32 MFMA/FMA)"
+DTYPE = "f32 (bf16x3 MFMA for pointwise fwd/dgrad GEMMs)"
+ARITHMETIC = ("fp32 tensors, accumulators and results; forward / data-gradient GEMMs of the pointwise convolutions with >= 256 "
+              "output columns: fp32 operands split exactly into three bf16 pieces, six bf16 MFMAs per product block, fp32 "
+              "accumulation (error vs float64 no larger than the fp32 fmaf chain's); weight gradients and every other GEMM: "
+              "fp32 MFMA chains; Engine(pointwise='f32') / cf.pointwise_gemm = 'f32' restores the chain everywhere "
+              "(roofline_alt.train_step times it in the same run)")
 
 # BASELINE.json's metric string, verbatim
 METRIC = "training images/sec on 512\u00d7384 fake-ESPI, Xception backbone, 1/2/4/8 GPU"
@@ -844,7 +849,7 @@ def run(args):
                        "parallelism": "dp%d" % world, "n_ranks_seen": n_ranks_seen,
                        "collective_backend": backend, "rccl_version": rccl_version() if backend == "nccl" else None,
                        "devices_visible": torch.cuda.device_count(), "final_loss": round(loss, 6),
-                       "wgrad_overlap": not args.no_overlap,
+                       "wgrad_overlap": not args.no_overlap, "arithmetic": ARITHMETIC,
                        "host_enqueue_ms_per_step_backpressured": round(1e3 * t_host / args.steps, 3),
                        "host_enqueue_ms_per_step_gpu_idle": round(1e3 * t_host_idle, 3),
                        "pool_source": args.pool_source, "pool_generation_s": round(t_gen, 1)},

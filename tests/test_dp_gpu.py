@@ -137,7 +137,8 @@ def test_bench_default_line_carries_every_block():
     for key in ("roofline", "roofline_secondary", "roofline_alt", "cpu_baseline", "predict", "layout_331", "kernel_families",
                 "irv2", "mobilenet"):
         assert key in out, key
-    assert out["n_gpus"] == 1 and out["dtype"].startswith("f32 (") and "bf16" in out["dtype"] and out["value"] > 0
+    assert out["n_gpus"] == 1 and out["dtype"].startswith("f32 (") and "bf16x3" in out["dtype"] and out["value"] > 0
+    assert "fp32 MFMA" in out["config"]["arithmetic"]
     bk = out["roofline"]["by_kernel"]
     assert len(bk) == 2 and all(v["launches_per_step"] > 0 and v["ms_per_step"] > 0 for v in bk.values())
     ts = out["roofline_alt"]["train_step"]
