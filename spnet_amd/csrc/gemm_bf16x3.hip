@@ -145,10 +145,10 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16x3_fwd_kernel(const float* __
     *reinterpret_cast<uint2*>(base_ + 1 * X3_PLANE + o_) = make_uint2(m0_, m1_);                               \
     *reinterpret_cast<uint2*>(base_ + 2 * X3_PLANE + o_) = make_uint2(l0_, l1_);                               \
   } while (0)
-#define X3_STAGE(KS_, S_)                                                                                      \
+#define X3_STAGE(KS_, S_, ALLK_)                                                                                     \
   do {                                                                                                         \
     unsigned short* base_ = smem + ((KS_) & 1) * 6 * X3_PLANE;                                                 \
-    const bool kok_ = (KS_) * 32 + akq < K;                                                                    \
+    const bool kok_ = (ALLK_) || (KS_) * 32 + akq < K; /* (the zeroing is for the last K step alone) */        \
     X3_SPLIT_STORE(a##S_##0, tid);                                                                             \
     X3_SPLIT_STORE(a##S_##1, tid + 256);                                                                       \
     X3_SPLIT_STORE(a##S_##2, tid + 512);                                                                       \
@@ -168,13 +168,10 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16x3_fwd_kernel(const float* __
       for (int r = 0; r < 4; ++r) acc[i][j][r] = 0.f;
 
   // Pipeline: K step ks + 1 sits in one register set and ks + 2 is in flight into the other while step ks is multiplied;
-  // the split and the LDS stores of ks + 1 are issued between the MFMAs of the last three terms, then ks + 3 is fetched
-  // into the set just emptied.
+  // the split and the LDS stores of ks + 1 are issued between the MFMAs of step ks, then ks + 3 is fetched into the set
+  // just emptied.
   X3_FETCH(0, x);
-  X3_STAGE(0, x);
-  if (nk > 1) X3_FETCH(1, x);
-  if (nk > 2) X3_FETCH(2, y);
-  __syncthreads();
+  X3_STAGE(0, x, false);
   const int p16 = lane & 15, kg = lane >> 4;
   // smallest terms first: (l,h) (m,m) (h,l), then (m,h) (h,m), then (h,h); the nine tiles of a term back to back, so
   // that consecutive MFMAs never wait for each other's accumulator
@@ -184,7 +181,24 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16x3_fwd_kernel(const float* __
   _Pragma("unroll") for (int i = 0; i < 3; ++i)                                                                \
   _Pragma("unroll") for (int j = 0; j < 3; ++j)                                                                \
       acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i][TA[t]], bfr[j][TB[t]], acc[i][j], 0, 0, 0)
-#define X3_ITER(KS_, S_)                                                                                       \
+// The split and the stage stores of K step ks + 1 are spread over all 54 MFMAs of step ks, two vector instructions per
+// MFMA: 8 cycles of MFMA issue + 2 x 4 fill the 16 cycles an MFMA executes (MI355X_MICROARCH.md, issue costs), where four
+// per MFMA behind the last 27 alone stretched those gaps to 24 (round 4: 47.4 -> 46.0 us on 6144 x 728 x 728).  The K tail
+// is zeroed in the last K step only, which the steady loop never stages (12 v_cndmask per K step less).
+#define X3_BODY(KS_, S_, STEADY_)                                                                              \
+    if ((STEADY_) || (KS_) + 1 < nk) {                                                                         \
+      X3_STAGE((KS_) + 1, S_, STEADY_);                                                        \
+      X3_TERMS(0, 6);                                                                          \
+      _Pragma("unroll") for (int g = 0; g < 54; ++g) {                                                         \
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                                     \
+        __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);                                                     \
+        if (g % 3 == 0) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);                                     \
+      }                                                                                                        \
+      if ((STEADY_) || (KS_) + 3 < nk) X3_FETCH((KS_) + 3, S_);                                \
+    } else {                                                                                                   \
+      X3_TERMS(0, 6);                                                                          \
+    }
+#define X3_ITER(KS_, S_, STEADY_)                                                                              \
   do {                                                                                                         \
     const unsigned short* base = smem + ((KS_) & 1) * 6 * X3_PLANE;                                            \
     bf16x8 af[3][3], bfr[3][3]; /* [tile][plane] */                                                            \
@@ -193,24 +207,30 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16x3_fwd_kernel(const float* __
       af[t][p] = *reinterpret_cast<const bf16x8*>(base + p * X3_PLANE + (wm * 48 + t * 16 + p16) * X3_LDR + X3_SWZ(p16, kg));        \
       bfr[t][p] = *reinterpret_cast<const bf16x8*>(base + (3 + p) * X3_PLANE + (wn * 48 + t * 16 + p16) * X3_LDR + X3_SWZ(p16, kg)); \
     }                                                                                                          \
-    X3_TERMS(0, 3);                                                                            \
-    if ((KS_) + 1 < nk) {                                                                                      \
-      X3_STAGE((KS_) + 1, S_);                                                                 \
-      X3_TERMS(3, 6);                                                                          \
-      _Pragma("unroll") for (int g = 0; g < 27; ++g) { /* one MFMA, then what the vector pipe issues in its shadow */ \
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                                     \
-        __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);                                                     \
-        __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);                                                     \
-      }                                                                                                        \
-      if ((KS_) + 3 < nk) X3_FETCH((KS_) + 3, S_);                                             \
-    } else {                                                                                                   \
-      X3_TERMS(3, 6);                                                                          \
-    }                                                                                                          \
+    X3_BODY(KS_, S_, STEADY_);                                                                 \
     __syncthreads();                                                                                           \
   } while (0)
-  for (int ks = 0; ks < nk; ks += 2) {
-    X3_ITER(ks, x);
-    if (ks + 1 < nk) X3_ITER(ks + 1, y);
+  // The steady state is a loop of its own with nothing conditional in it: the wait for a register set's loads is then
+  // counted against the eight younger loads of the other set (s_waitcnt vmcnt(15) ... (8)).  With the fetch behind
+  // "if (ks + 3 < nk)" the compiler has to assume the younger loads were never issued and waits for them as well
+  // (vmcnt(7) ... (0)): a prefetch distance of one K step instead of two (-2 % on the 6144 x 728 x 728 launches).
+  int ks = 0;
+  if (nk > 4) {
+    X3_FETCH(1, x);
+    X3_FETCH(2, y);
+    __syncthreads();
+    for (; ks + 4 < nk; ks += 2) {
+      X3_ITER(ks, x, true);
+      X3_ITER(ks + 1, y, true);
+    }
+  } else {
+    if (nk > 1) X3_FETCH(1, x);
+    if (nk > 2) X3_FETCH(2, y);
+    __syncthreads();
+  }
+  for (; ks < nk; ks += 2) {
+    X3_ITER(ks, x, false);
+    if (ks + 1 < nk) X3_ITER(ks + 1, y, false);
   }
 
   // C/D map of the 16x16 MFMA: column = lane & 15, row = 4 * (lane >> 4) + register

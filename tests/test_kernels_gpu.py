@@ -146,7 +146,8 @@ def test_gemm_accumulate_into_c(L, M, N, K, form, tile):
     assert torch.equal(C, want)
 
 
-@pytest.mark.parametrize("M,N,K", [(6144, 728, 728), (200, 96, 32), (97, 100, 260), (1536, 1024, 1536)])
+@pytest.mark.parametrize("M,N,K", [(6144, 728, 728), (200, 96, 32), (97, 100, 260), (1536, 1024, 1536), (5000, 800, 100),
+                                   (300, 128, 160), (300, 128, 192)])
 def test_gemm_bf16x3_accuracy(L, M, N, K):
     """The bf16x3 kernel (fp32 operands as three bf16 pieces, six bf16 MFMAs, fp32 accumulation; the pointwise forward /
     data-gradient GEMMs of the product path since round 4):
@@ -175,7 +176,7 @@ def test_gemm_bf16x3_accuracy(L, M, N, K):
     assert np.sqrt((e3 ** 2).mean()) < 3.0 * max(np.sqrt((e1 ** 2).mean()), 1e-9)
 
 
-@pytest.mark.parametrize("M,N,K", [(6144, 728, 728), (1000, 256, 128), (97, 260, 100)])
+@pytest.mark.parametrize("M,N,K", [(6144, 728, 728), (5483, 732, 260), (1000, 256, 128), (97, 260, 100)])
 def test_gemm_bf16x3_colstats_batched_split_and_dgrad_form(L, M, N, K):
     """The pieces the engine uses: spnet_split_bf16x3_batched makes the planes of both operand forms in one launch
     (identical to the single split for the forward form); the forward GEMM with BatchNorm column sums leaves exactly the
