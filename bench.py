@@ -884,8 +884,10 @@ def run(args):
                     "achieved_fp32_equivalent_tflops": round(x3_fl / max(x3_ms, 1e-9) / 1e9, 1),
                     "peak_fp32_equivalent_tflops": round(BF16_MFMA_PEAK_TFLOPS / 6.0, 1),
                     "frac_of_own_peak": round(x3_fl / max(x3_ms, 1e-9) / 1e9 / (BF16_MFMA_PEAK_TFLOPS / 6.0), 4),
-                    "note": "six bf16 MFMAs per fp32 product block: dense bf16 MFMA peak / 6; the kernel is bound by its "
-                            "operand traffic through L2 (10 B per operand element), DESIGN.md section 3"},
+                    "note": "six bf16 MFMAs per fp32 product block: dense bf16 MFMA peak / 6; no unit of the CU is "
+                            "saturated (SQ counters, profiles/r04_k_bf16x3_pmc_table.txt: matrix pipe busy 53 % of a "
+                            "wave's life at two waves per SIMD, 49 % of it issue stalls, 20 % at barriers / waitcnt, LDS "
+                            "29 % busy without bank conflicts), DESIGN.md section 3"},
                 "fp32 MFMA kernels (weight gradients, blended data gradients, block1_conv2, Dense, narrow layers)": {
                     "launches_per_step": (g_n - x3_n) / args.steps, "ms_per_step": round((g_ms - x3_ms) / args.steps, 3),
                     "achieved_tflops": round((g_flop - x3_fl) / max(g_ms - x3_ms, 1e-9) / 1e9, 1),
