@@ -887,7 +887,9 @@ def run(args):
                     "note": "six bf16 MFMAs per fp32 product block: dense bf16 MFMA peak / 6; no unit of the CU is "
                             "saturated (SQ counters, profiles/r04_k_bf16x3_pmc_table.txt: matrix pipe busy 53 % of a "
                             "wave's life at two waves per SIMD, 49 % of it issue stalls, 20 % at barriers / waitcnt, LDS "
-                            "29 % busy without bank conflicts), DESIGN.md section 3"},
+                            "29 % busy without bank conflicts); on all-zero operands the same launch takes 36 instead of "
+                            "46-48 us: a quarter of its time is clock given up to the power limit "
+                            "(profiles/r04_k_diag_bf16x3_power_probe.txt), DESIGN.md section 3"},
                 "fp32 MFMA kernels (weight gradients, blended data gradients, block1_conv2, Dense, narrow layers)": {
                     "launches_per_step": (g_n - x3_n) / args.steps, "ms_per_step": round((g_ms - x3_ms) / args.steps, 3),
                     "achieved_tflops": round((g_flop - x3_fl) / max(g_ms - x3_ms, 1e-9) / 1e9, 1),
