@@ -481,7 +481,7 @@ def bf16x3_alt_measure(dev, iters=200):
     a = torch.randn(M, K, device=dev, generator=g)
     w = torch.randn(K, N, device=dev, generator=g) * 0.05
     Kp = int(L.spnet_bf16x3_kp(K))
-    planes = torch.zeros(3 * N * Kp, dtype=torch.int16, device=dev)
+    planes = torch.zeros(3 * int(L.spnet_bf16x3_plane_elems(N, K)), dtype=torch.int16, device=dev)
     c3, c1 = torch.empty(M, N, device=dev), torch.empty(M, N, device=dev)
     st = torch.cuda.current_stream().cuda_stream
     split = lambda: L.spnet_split_bf16x3(w.data_ptr(), planes.data_ptr(), K, N, st)

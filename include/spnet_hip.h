@@ -35,28 +35,48 @@ extern "C" {
 int spnet_gemm_f32(const float* A, int a_major, int lda, const float* B, int b_major, int ldb, float* C,
                    int ldc, int M, int N, int K, int split_k, float* workspace, long ws_floats,
                    const float* bias, int tile, void* stream);
-/* ---- fp32 GEMM on the bf16 matrix cores by operand splitting (csrc/gemm_bf16x3.hip): the forward and data-gradient GEMMs
- * of the pointwise convolutions (keras SeparableConv2D pointwise step / 1x1 Conv2D; spnet/models.py:346-359).  Every fp32
- * operand is the exact sum of three bf16 pieces; six bf16 MFMAs with fp32 accumulation per product block; error against
- * float64 no larger than spnet_gemm_f32's, not the same bits.  A [M][K] fp32 (lda % 4 == 0, K % 4 == 0, 16-byte aligned),
- * planes = 3 * N * spnet_bf16x3_kp(K) bf16 in K-major order, B element (n, k):  C[M][N] = A * B^T-of-planes.
- * spnet_split_bf16x3: planes of a Keras pointwise kernel W[K][N] in the forward form.  spnet_split_bf16x3_batched: all
- * splits of a step in one launch, job = {W, planes, K, N, sn, sk} as six 64-bit words in device memory, element (n, k) =
- * W[n*sn + k*sk] (forward: sn 1, sk cout; data gradient dX = dY W^T: K = cout, N = cin, sn cout, sk 1); max_elems = the
- * largest N * kp(K).  _colstats: BatchNorm column sums of C as [*stat_rows][2][N] partial rows, *stat_rows = ceil(M/96). */
+/* ---- fp32 GEMM on the bf16 matrix cores by operand splitting (csrc/gemm_bf16x3.hip): the forward, data-gradient and
+ * weight-gradient GEMMs of the pointwise convolutions (keras SeparableConv2D pointwise step / 1x1 Conv2D;
+ * spnet/models.py:346-359).  Every fp32 operand is the exact sum of three bf16 pieces; six bf16 MFMAs with fp32 accumulation
+ * per product block; error against float64 no larger than spnet_gemm_f32's, not the same bits.
+ * "planes" of a matrix X[R][K]: 3 * spnet_bf16x3_plane_elems(R, K) bf16 (high, middle, low piece) in 1-KiB pieces of 16 rows
+ * x 32 columns (layout: csrc/x3t.h), 16-byte aligned, allocated ZEROED (pad rows / columns are never written), at most 2 GiB.
+ *   spnet_split_bf16x3           planes of a Keras pointwise kernel W[K][N] in the forward form (rows = output channels)
+ *   spnet_split_rows_bf16x3      planes of an fp32 matrix A[R][K] (row stride lda)
+ *   spnet_split_bf16x3_batched   all splits of a step in one launch, job = {src, planes, K, N, sn, sk} as six 64-bit words in
+ *                                device memory, element (row n, column k) = src[n*sn + k*sk] (forward form of W[cin][cout]:
+ *                                K = cin, N = cout, sn 1, sk cout; data gradient dX = dY W^T: K = cout, N = cin, sn cout,
+ *                                sk 1); max_elems = the largest plane_elems(N, K) of the batch
+ *   spnet_gemm_bf16x3_fwd        C[M][N] = A B^T, A [M][K] fp32 split inside the kernel (lda % 4 == 0, K % 4 == 0, 16-byte
+ *                                aligned), B = planes of [N][K]
+ *   spnet_gemm_bf16x3_pp         the same with A given as planes of [M][K] (written by the producing kernel:
+ *                                spnet_dwconv3x3_*_x3, spnet_bn_bwd_*_x3): no split, no stage registers, LDS-DMA only
+ *   _colstats / colstats != NULL BatchNorm column sums of C as [*stat_rows][2][N] partial rows, *stat_rows = ceil(M/96)
+ *                                (stat_rows: HOST int)
+ *   spnet_gemm_bf16x3_wgrad_batched  nbatch weight gradients dW[cin][cout] = z^T dy of ONE shape in one launch, from the
+ *                                planes of z [M][cin] and dy [M][cout]; jobs = DEVICE array of {z planes, dy planes, dst}
+ *                                (three 64-bit words each); ksplit == 1: dst = dW; ksplit > 1: dst = ksplit slabs of
+ *                                cin*cout floats in slice order (add them with spnet_reduce_slabs); deterministic.
+ *                                spnet_gemm_bf16x3_wgrad_ksplit: the slice count this library would choose. */
 long spnet_bf16x3_kp(int K);
+long spnet_bf16x3_plane_elems(long R, int K);
 int spnet_split_bf16x3(const float* W, void* planes, int K, int N, void* stream);
+int spnet_split_rows_bf16x3(const float* A, long lda, void* planes, long R, int K, void* stream);
 int spnet_split_bf16x3_batched(const void* jobs, int njobs, long max_elems, void* stream);
 int spnet_gemm_bf16x3_fwd(const float* A, int lda, const void* planes, float* C, int ldc, int M, int N, int K, void* stream);
 int spnet_gemm_bf16x3_fwd_colstats(const float* A, int lda, const void* planes, float* C, int ldc, int M, int N, int K,
                                    float* colstats, int* stat_rows, void* stream);
+int spnet_gemm_bf16x3_pp(const void* a_planes, const void* b_planes, float* C, int ldc, int M, int N, int K, float* colstats,
+                         int* stat_rows, void* stream);
+long spnet_gemm_bf16x3_wgrad_ksplit(int cin, int cout, int M, int nbatch);
+int spnet_gemm_bf16x3_wgrad_batched(const void* jobs, int nbatch, int cin, int cout, int M, int ksplit, void* stream);
 /* C += A B, formed in the epilogue (no K split): a data gradient added onto what another consumer of the same tensor
  * has already left in C (the branch convolutions of an inception block; call site spnet/models.py:357-359). */
 int spnet_gemm_f32_accumulate(const float* A, int a_major, int lda, const float* B, int b_major, int ldb, float* C,
                               int ldc, int M, int N, int K, int tile, void* stream);
 
-/* ---- probe, not on the product path: fp32 GEMM on the bf16 matrix cores by operand splitting ------------------------- */
-/* Same contraction (no split-K, no bias) that also emits BatchNorm column statistics of C from the
+/* ---- fp32 MFMA contractions with fused epilogues / operand forms (product path) ------------------------------------ */
+/* spnet_gemm_f32's contraction (no split-K, no bias) that also emits BatchNorm column statistics of C from the
  * accumulators: colstats[rows][2][N] per row-tile (sum, sum of squares), *stat_rows (HOST int) = rows.
  * colstats must hold ceil(M/32)*2*N floats. */
 int spnet_gemm_f32_colstats(const float* A, int a_major, int lda, const float* B, int b_major, int ldb,

@@ -27,7 +27,12 @@ P = c_void_p  # device pointers travel as integers
 _SIGS = {
     "spnet_gemm_f32": (c_int, [P, c_int, c_int, P, c_int, c_int, P, c_int, c_int, c_int, c_int, c_int, P, c_long, P, c_int, P]),
     "spnet_bf16x3_kp": (c_long, [c_int]),
+    "spnet_bf16x3_plane_elems": (c_long, [c_long, c_int]),
     "spnet_split_bf16x3": (c_int, [P, P, c_int, c_int, P]),
+    "spnet_split_rows_bf16x3": (c_int, [P, c_long, P, c_long, c_int, P]),
+    "spnet_gemm_bf16x3_pp": (c_int, [P, P, P, c_int, c_int, c_int, c_int, P, P, P]),
+    "spnet_gemm_bf16x3_wgrad_ksplit": (c_long, [c_int, c_int, c_int, c_int]),
+    "spnet_gemm_bf16x3_wgrad_batched": (c_int, [P, c_int, c_int, c_int, c_int, c_int, P]),
     "spnet_split_bf16x3_batched": (c_int, [P, c_int, c_long, P]),
     "spnet_gemm_bf16x3_fwd": (c_int, [P, c_int, P, P, c_int, c_int, c_int, c_int, P]),
     "spnet_gemm_bf16x3_fwd_colstats": (c_int, [P, c_int, P, P, c_int, c_int, c_int, c_int, P, P, P]),

@@ -737,10 +737,10 @@ class Engine:
                 continue
             ent = self._planes.setdefault(pw.wname, [None, None])
             if pw.x3_fwd and ent[0] is None:
-                ent[0] = torch.zeros(3 * pw.cout * int(L.spnet_bf16x3_kp(pw.cin)), dtype=torch.int16, device=self.dev)
+                ent[0] = torch.zeros(3 * int(L.spnet_bf16x3_plane_elems(pw.cout, pw.cin)), dtype=torch.int16, device=self.dev)
                 self._planes_gen[0] += 1
             if pw.x3_dgrad and ent[1] is None:
-                ent[1] = torch.zeros(3 * pw.cin * int(L.spnet_bf16x3_kp(pw.cout)), dtype=torch.int16, device=self.dev)
+                ent[1] = torch.zeros(3 * int(L.spnet_bf16x3_plane_elems(pw.cin, pw.cout)), dtype=torch.int16, device=self.dev)
                 self._planes_gen[0] += 1
         if self._planes_jobs is None or self._planes_jobs[1] != self._planes_gen[0]:
             self._planes_ver[0] = -1

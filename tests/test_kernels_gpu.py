@@ -146,25 +146,49 @@ def test_gemm_accumulate_into_c(L, M, N, K, form, tile):
     assert torch.equal(C, want)
 
 
+def x3_planes(L, R, K, fill=0):
+    """a zeroed (or poisoned) plane set for an [R][K] matrix"""
+    n = 3 * int(L.spnet_bf16x3_plane_elems(R, K))
+    return torch.full((n,), fill, dtype=torch.int16, device="cuda")
+
+
+def x3_untile(planes, R, K):
+    """planes in the pieces layout of csrc/x3t.h -> float64 [3][R16][Kp] (R16, Kp: R, K rounded up to 16 / 32): element
+    (r, k) of a plane sits at ((r/16)*nk + k/32)*512 + (r%16)*32 + (((k%32)/8 ^ -((r%16)/4)) & 3)*8 + k%8."""
+    nk, rg = (K + 31) // 32, (R + 15) // 16
+    p = planes.view(torch.bfloat16).reshape(3, rg, nk, 16, 4, 8).float().cpu().double()
+    r16 = torch.arange(16)
+    cpos = torch.arange(4)[None, :] ^ ((-(r16 // 4)) & 3)[:, None]            # [r16][chunk] -> stored position
+    q = p[:, :, :, r16[:, None], cpos, :]                                     # [3][rg][nk][16][chunk][8]
+    return q.permute(0, 1, 3, 2, 4, 5).reshape(3, rg * 16, nk * 32)
+
+
 @pytest.mark.parametrize("M,N,K", [(6144, 728, 728), (200, 96, 32), (97, 100, 260), (1536, 1024, 1536), (5000, 800, 100),
                                    (300, 128, 160), (300, 128, 192)])
 def test_gemm_bf16x3_accuracy(L, M, N, K):
-    """The bf16x3 kernel (fp32 operands as three bf16 pieces, six bf16 MFMAs, fp32 accumulation; the pointwise forward /
-    data-gradient GEMMs of the product path since round 4):
-    its error against float64 is of the size of the exact fp32 kernel's own -- within 3x of it, and below 2e-6 of the
-    row / column norms product -- on random operands with a wide dynamic range; the weight planes reproduce W exactly."""
+    """The bf16x3 kernels (fp32 operands as three bf16 pieces, six bf16 MFMAs, fp32 accumulation; the pointwise GEMMs of the
+    product path): the error against float64 is of the size of the exact fp32 kernel's own -- within 3x of it, and below 2e-6
+    of the row / column norms product -- on random operands with a wide dynamic range; the planes reproduce their matrix
+    exactly and their pad rows / columns are zero; the planes x planes kernel (A split by its producer) and the kernel that
+    splits an fp32 A while staging it give the same bits."""
     rs = np.random.RandomState(M + N)
     A = (rs.randn(M, K) * np.exp(rs.randn(M, K))).astype(np.float32)
     W = (rs.randn(K, N) * 0.1 * np.exp(rs.randn(K, N))).astype(np.float32)
     a, w = dev(A), dev(W)
-    Kp = int(L.spnet_bf16x3_kp(K))
-    planes = torch.zeros(3 * N * Kp, dtype=torch.int16, device="cuda")
+    planes = x3_planes(L, N, K)
     L.spnet_split_bf16x3(w.data_ptr(), planes.data_ptr(), K, N, st())
-    pl = planes.view(torch.bfloat16).reshape(3, N, Kp).float().cpu().double()
-    assert torch.equal((pl[0] + pl[1] + pl[2])[:, :K].T.contiguous(), torch.from_numpy(W).double())     # h + m + l == w exactly
-    assert float(pl[:, :, K:].abs().max()) == 0.0 if Kp > K else True
+    pl = x3_untile(planes, N, K)
+    assert torch.equal((pl[0] + pl[1] + pl[2])[:N, :K].T.contiguous(), torch.from_numpy(W).double())     # h + m + l == w exactly
+    assert float(pl[:, N:].abs().max() if pl.shape[1] > N else 0) == 0.0 and float(pl[:, :, K:].abs().max() if pl.shape[2] > K else 0) == 0.0
+    apl = x3_planes(L, M, K)
+    L.spnet_split_rows_bf16x3(a.data_ptr(), K, apl.data_ptr(), M, K, st())
+    al = x3_untile(apl, M, K)
+    assert torch.equal((al[0] + al[1] + al[2])[:M, :K], torch.from_numpy(A).double())
     c3 = torch.full((M, N), float("nan"), device="cuda")
     L.spnet_gemm_bf16x3_fwd(a.data_ptr(), K, planes.data_ptr(), c3.data_ptr(), N, M, N, K, st())
+    cp = torch.full((M + 1, N), 7.0, device="cuda")                     # (a guard row behind C)
+    L.spnet_gemm_bf16x3_pp(apl.data_ptr(), planes.data_ptr(), cp.data_ptr(), N, M, N, K, None, None, st())
+    assert torch.equal(cp[:M], c3) and bool((cp[M] == 7.0).all())
     c1 = torch.empty(M, N, device="cuda")
     L.spnet_gemm_f32(a.data_ptr(), 0, K, w.data_ptr(), 1, N, c1.data_ptr(), N, M, N, K, 1, None, 0, None, 0, st())
     ref = A.astype(np.float64) @ W.astype(np.float64)
@@ -176,28 +200,59 @@ def test_gemm_bf16x3_accuracy(L, M, N, K):
     assert np.sqrt((e3 ** 2).mean()) < 3.0 * max(np.sqrt((e1 ** 2).mean()), 1e-9)
 
 
+def test_gemm_bf16x3_nan_and_inf_propagate(L):
+    """A NaN or an infinity in an operand must come out as non-finite results, as on the exact chain (a split by integer
+    rounding turns some NaNs into zeros: MI355X_MICROARCH.md, correctness boundaries): every split goes through
+    v_cvt_pk_bf16_f32."""
+    M, N, K = 96, 96, 64
+    rs = np.random.RandomState(0)
+    A, W = rs.randn(M, K).astype(np.float32), rs.randn(K, N).astype(np.float32)
+    A[3, 5] = np.float32(np.nan)
+    A[7, 9] = np.frombuffer(np.uint32(0x7FFFFFFF).tobytes(), np.float32)[0]          # NaN with every payload bit set
+    W[11, 13] = np.float32(np.inf)
+    W[20, 21] = np.frombuffer(np.uint32(0xFFFFFFFF).tobytes(), np.float32)[0]
+    a, w = dev(A), dev(W)
+    planes, apl = x3_planes(L, N, K), x3_planes(L, M, K)
+    L.spnet_split_bf16x3(w.data_ptr(), planes.data_ptr(), K, N, st())
+    L.spnet_split_rows_bf16x3(a.data_ptr(), K, apl.data_ptr(), M, K, st())
+    for kind in ("fwd", "pp"):
+        c = torch.zeros(M, N, device="cuda")
+        if kind == "fwd":
+            L.spnet_gemm_bf16x3_fwd(a.data_ptr(), K, planes.data_ptr(), c.data_ptr(), N, M, N, K, st())
+        else:
+            L.spnet_gemm_bf16x3_pp(apl.data_ptr(), planes.data_ptr(), c.data_ptr(), N, M, N, K, None, None, st())
+        c = c.cpu().numpy()
+        assert np.isnan(c[3]).all() and np.isnan(c[7]).all(), kind          # NaN rows of A
+        assert not np.isfinite(c[:, 13]).any() and np.isnan(c[:, 21]).all(), kind     # inf / NaN columns of W
+        ok = np.ones((M, N), bool)
+        ok[[3, 7]] = False
+        ok[:, [13, 21]] = False
+        assert np.isfinite(c[ok]).all(), kind
+
+
 @pytest.mark.parametrize("M,N,K", [(6144, 728, 728), (5483, 732, 260), (1000, 256, 128), (97, 260, 100)])
 def test_gemm_bf16x3_colstats_batched_split_and_dgrad_form(L, M, N, K):
     """The pieces the engine uses: spnet_split_bf16x3_batched makes the planes of both operand forms in one launch
     (identical to the single split for the forward form); the forward GEMM with BatchNorm column sums leaves exactly the
-    sums of the C it wrote, tile row by tile row; the data-gradient form dX = dY W^T on the planes of W as stored."""
+    sums of the C it wrote, tile row by tile row (both operand forms of A); the data-gradient form dX = dY W^T on the planes
+    of W as stored."""
     import ctypes
     rs = np.random.RandomState(K)
     A = (rs.randn(M, K)).astype(np.float32)
     W = (rs.randn(K, N) * 0.1).astype(np.float32)
     G = (rs.randn(M, N)).astype(np.float32)
     a, w, g = dev(A), dev(W), dev(G)
-    kf, kd = int(L.spnet_bf16x3_kp(K)), int(L.spnet_bf16x3_kp(N))
-    pf1 = torch.zeros(3 * N * kf, dtype=torch.int16, device="cuda")
+    pe = lambda r, k: int(L.spnet_bf16x3_plane_elems(r, k))
+    pf1 = x3_planes(L, N, K)
     L.spnet_split_bf16x3(w.data_ptr(), pf1.data_ptr(), K, N, st())
-    pf = torch.full((3 * N * kf,), -1, dtype=torch.int16, device="cuda")
-    pd = torch.full((3 * K * kd,), -1, dtype=torch.int16, device="cuda")
+    pf, pd = x3_planes(L, N, K, -1), x3_planes(L, K, N, -1)       # (poisoned: the split writes every element, pads included)
     jobs = torch.tensor([w.data_ptr(), pf.data_ptr(), K, N, 1, N, w.data_ptr(), pd.data_ptr(), N, K, N, 1], dtype=torch.int64,
                         device="cuda")
-    L.spnet_split_bf16x3_batched(jobs.data_ptr(), 2, max(N * kf, K * kd), st())
+    L.spnet_split_bf16x3_batched(jobs.data_ptr(), 2, max(pe(N, K), pe(K, N)), st())
     assert torch.equal(pf, pf1)
-    pl = pd.view(torch.bfloat16).reshape(3, K, kd).float().cpu().double()
-    assert torch.equal((pl[0] + pl[1] + pl[2])[:, :N], torch.from_numpy(W).double())          # element (n=k_in, k=n_out) = W[n][k]
+    pl = x3_untile(pd, K, N)
+    assert torch.equal((pl[0] + pl[1] + pl[2])[:K, :N], torch.from_numpy(W).double())          # element (n=k_in, k=n_out) = W[n][k]
+    assert float(pl[:, K:].abs().max() if pl.shape[1] > K else 0) == 0.0 and float(pl[:, :, N:].abs().max() if pl.shape[2] > N else 0) == 0.0
     # forward + column sums
     c = torch.full((M, N), float("nan"), device="cuda")
     rows = ctypes.c_int(0)
@@ -215,10 +270,75 @@ def test_gemm_bf16x3_colstats_batched_split_and_dgrad_form(L, M, N, K):
         blk = cn[t * 96:(t + 1) * 96]
         np.testing.assert_allclose(part[t, 0], blk.sum(0), rtol=1e-5, atol=1e-4)
         np.testing.assert_allclose(part[t, 1], (blk ** 2).sum(0), rtol=1e-5, atol=1e-4)
+    # the same from A's planes: C and the partial sums bit for bit
+    apl = x3_planes(L, M, K)
+    L.spnet_split_rows_bf16x3(a.data_ptr(), K, apl.data_ptr(), M, K, st())
+    c2 = torch.full((M, N), float("nan"), device="cuda")
+    cs2 = torch.full_like(cs, float("nan"))
+    rows2 = ctypes.c_int(0)
+    L.spnet_gemm_bf16x3_pp(apl.data_ptr(), pf.data_ptr(), c2.data_ptr(), N, M, N, K, cs2.data_ptr(), ctypes.addressof(rows2), st())
+    assert rows2.value == rows.value and torch.equal(c2, c) and torch.equal(cs2, cs)
     # data gradient: dX[M][K] = G[M][N] W^T
     dx = torch.full((M, K), float("nan"), device="cuda")
     L.spnet_gemm_bf16x3_fwd(g.data_ptr(), N, pd.data_ptr(), dx.data_ptr(), K, M, K, N, st())
     close(dx, G.astype(np.float64) @ W.astype(np.float64).T, rtol=2e-5, atol=2e-5 * np.sqrt(N))
+    gpl = x3_planes(L, M, N)
+    L.spnet_split_rows_bf16x3(g.data_ptr(), N, gpl.data_ptr(), M, N, st())
+    dx2 = torch.full((M, K), float("nan"), device="cuda")
+    L.spnet_gemm_bf16x3_pp(gpl.data_ptr(), pd.data_ptr(), dx2.data_ptr(), K, M, K, N, None, None, st())
+    assert torch.equal(dx2, dx)
+
+
+@pytest.mark.parametrize("M,cin,cout,nb", [(6144, 728, 728, 2), (1000, 100, 260, 3), (96, 96, 96, 1), (1552, 256, 728, 1),
+                                           (5000, 260, 36, 2)])
+def test_gemm_bf16x3_wgrad_from_planes(L, M, cin, cout, nb):
+    """spnet_gemm_bf16x3_wgrad_batched: dW = z^T dy from the planes the forward / data-gradient launches read (fragments by
+    transposing LDS reads), several problems per launch; error against float64 of the size of the exact fp32 kernel's own;
+    with a K split + spnet_reduce_slabs the same to rounding, and bit-identical from run to run; pixel counts that are not a
+    multiple of 32 (a row group missing from the last contraction step) and channel counts that are not a multiple of 96."""
+    rs = np.random.RandomState(M + cin)
+    Z = [(rs.randn(M, cin) * np.exp(0.5 * rs.randn(M, cin))).astype(np.float32) for _ in range(nb)]
+    G = [(rs.randn(M, cout) * 0.1).astype(np.float32) for _ in range(nb)]
+    zp, gp = [x3_planes(L, M, cin) for _ in range(nb)], [x3_planes(L, M, cout) for _ in range(nb)]
+    zd, gd = [dev(z) for z in Z], [dev(g) for g in G]
+    for b in range(nb):
+        L.spnet_split_rows_bf16x3(zd[b].data_ptr(), cin, zp[b].data_ptr(), M, cin, st())
+        L.spnet_split_rows_bf16x3(gd[b].data_ptr(), cout, gp[b].data_ptr(), M, cout, st())
+    dw = [torch.full((cin + 1, cout), 7.0, device="cuda") for _ in range(nb)]
+    jobs = torch.tensor([v for b in range(nb) for v in (zp[b].data_ptr(), gp[b].data_ptr(), dw[b].data_ptr())], dtype=torch.int64,
+                        device="cuda")
+    L.spnet_gemm_bf16x3_wgrad_batched(jobs.data_ptr(), nb, cin, cout, M, 1, st())
+    for b in range(nb):
+        ref = Z[b].astype(np.float64).T @ G[b].astype(np.float64)
+        scale = np.sqrt((Z[b].astype(np.float64) ** 2).sum(0))[:, None] * np.sqrt((G[b].astype(np.float64) ** 2).sum(0))[None, :]
+        c1 = torch.empty(cin, cout, device="cuda")
+        L.spnet_gemm_f32(zd[b].data_ptr(), 1, cin, gd[b].data_ptr(), 1, cout, c1.data_ptr(), cout, cin, cout, M, 1, None, 0, None, 0, st())
+        e3 = np.abs(dw[b][:cin].cpu().double().numpy() - ref) / scale
+        e1 = np.abs(c1.cpu().double().numpy() - ref) / scale
+        assert bool((dw[b][cin] == 7.0).all())
+        assert np.isfinite(e3).all() and e3.max() < 2e-6 and e3.max() < 3.0 * max(e1.max(), 1e-8), (b, e3.max(), e1.max())
+    # K split: slabs + ordered sum
+    ks = max(2, min(7, ((M + 31) // 32) // 3))
+    per = ((M + 31) // 32 + ks - 1) // ks
+    ks = ((M + 31) // 32 + per - 1) // per
+    if ks > 1:
+        slabs = [torch.full((ks, cin, cout), float("nan"), device="cuda") for _ in range(nb)]
+        jobs2 = torch.tensor([v for b in range(nb) for v in (zp[b].data_ptr(), gp[b].data_ptr(), slabs[b].data_ptr())],
+                             dtype=torch.int64, device="cuda")
+        outs = []
+        for rep in range(2):
+            for sl in slabs:
+                sl.fill_(float("nan"))
+            L.spnet_gemm_bf16x3_wgrad_batched(jobs2.data_ptr(), nb, cin, cout, M, ks, st())
+            o = [torch.empty(cin, cout, device="cuda") for _ in range(nb)]
+            for b in range(nb):
+                L.spnet_reduce_slabs(slabs[b].data_ptr(), ks, cin, cout, o[b].data_ptr(), cout, st())
+            outs.append(o)
+        for b in range(nb):
+            assert torch.equal(outs[0][b], outs[1][b])
+            ref = Z[b].astype(np.float64).T @ G[b].astype(np.float64)
+            close(outs[0][b], ref, rtol=2e-5, atol=2e-5 * np.sqrt(M) * 0.3)
+    assert int(L.spnet_gemm_bf16x3_wgrad_ksplit(256, 256, 94752, 1)) > 8 and int(L.spnet_gemm_bf16x3_wgrad_ksplit(728, 728, 6144, 24)) == 1
 
 
 @pytest.mark.parametrize("tile", [0, 3, 5, 6])

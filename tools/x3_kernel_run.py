@@ -11,7 +11,7 @@ M, N, K = 6144, 728, 728
 a = [torch.randn(M, K, device="cuda") for _ in range(4)]
 w = torch.randn(K, N, device="cuda") * 0.05
 Kp = int(L.spnet_bf16x3_kp(K))
-planes = torch.zeros(3 * N * Kp, dtype=torch.int16, device="cuda")
+planes = torch.zeros(3 * int(L.spnet_bf16x3_plane_elems(N, K)), dtype=torch.int16, device="cuda")
 L.spnet_split_bf16x3(w.data_ptr(), planes.data_ptr(), K, N, st())
 c = torch.empty(M, N, device="cuda")
 for i in range(20):

@@ -30,7 +30,7 @@ def timeit(fn, iters=300):
 for label, a, w in (("random normal", torch.randn(M, K, device="cuda"), torch.randn(K, N, device="cuda") * 0.05),
                     ("all zeros", torch.zeros(M, K, device="cuda"), torch.zeros(K, N, device="cuda")),
                     ("random normal again", torch.randn(M, K, device="cuda"), torch.randn(K, N, device="cuda") * 0.05)):
-    planes = torch.zeros(3 * N * Kp, dtype=torch.int16, device="cuda")
+    planes = torch.zeros(3 * int(L.spnet_bf16x3_plane_elems(N, K)), dtype=torch.int16, device="cuda")
     L.spnet_split_bf16x3(w.data_ptr(), planes.data_ptr(), K, N, st())
     t3 = timeit(lambda: L.spnet_gemm_bf16x3_fwd(a.data_ptr(), K, planes.data_ptr(), c.data_ptr(), N, M, N, K, st()))
     t1 = timeit(lambda: L.spnet_gemm_f32(a.data_ptr(), 0, K, w.data_ptr(), 1, N, c.data_ptr(), N, M, N, K, 1, None, 0, None, 0, st()))
