@@ -157,6 +157,18 @@ int spnet_dwconv3x3_tiled_fwd_bnfin(const float* x, const float* w, float* y, in
                                     const float* partial, int rows, long M, const float* gamma, const float* beta,
                                     float* moving_mean, float* moving_var, float* save_mean, float* save_invstd,
                                     float* scale_shift, float eps, float momentum, void* stream);
+/* The three forward forms with the output written as the bf16x3 planes of the [B*H*W][C] matrix (see the bf16x3 GEMM
+ * block above; y_planes: zeroed allocation of 3 * spnet_bf16x3_plane_elems(B*H*W, C) bf16): the depthwise step of a
+ * SeparableConv2D hands its result to the pointwise GEMMs (spnet_gemm_bf16x3_pp forward, spnet_gemm_bf16x3_wgrad_batched)
+ * in the form they read, 6 bytes per element, no fp32 copy.  Same arithmetic as the fp32 forms. */
+int spnet_dwconv3x3_tiled_fwd_x3(const float* x, const float* w, void* y_planes, int B, int H, int W, int C,
+                                 int relu_in, const float* in_scale, const float* in_shift, void* stream);
+int spnet_dwconv3x3_tiled_fwd_bnfin_x3(const float* x, const float* w, void* y_planes, int B, int H, int W, int C, int relu_in,
+                                       const float* partial, int rows, long M, const float* gamma, const float* beta,
+                                       float* moving_mean, float* moving_var, float* save_mean, float* save_invstd,
+                                       float* scale_shift, float eps, float momentum, void* stream);
+int spnet_dwconv3x3_stream_fwd_x3(const float* x, const float* w, void* y_planes, int B, int H, int W, int C, int relu_in,
+                                  const float* in_scale, const float* in_shift, int rows_per_seg, void* stream);
 long spnet_dwconv3x3_tiled_bwd_ws(int B, int H, int W, int C);
 long spnet_dwconv3x3_tiled_rows(int B, int H, int W, int C);
 /* in_scale/in_shift (or NULL): the producer BatchNorm's affine applied on load (x_fwd is then the PRE-BN
@@ -234,6 +246,17 @@ int spnet_bn_bwd_from_partials(const float* x, const float* dy, long M, int C, c
                                const float* beta, const float* save_mean, const float* save_invstd, int P,
                                const float* partial, float* dx, float* dgamma, float* dbeta, float* coeffs,
                                void* stream);
+/* spnet_bn_bwd / spnet_bn_bwd_from_partials with dx written as the bf16x3 planes of the [M][C] matrix (dx_planes: zeroed
+ * allocation of 3 * spnet_bf16x3_plane_elems(M, C) bf16; C % 4 == 0): the gradient a BatchNormalization hands to the
+ * pointwise convolution in front of it is read by that layer's data-gradient and weight-gradient GEMMs only
+ * (spnet_gemm_bf16x3_pp, spnet_gemm_bf16x3_wgrad_batched), in this form.  Same arithmetic as the fp32 forms. */
+int spnet_bn_bwd_x3(const float* x, const float* dy, long M, int C, const float* gamma, const float* beta,
+                    const float* save_mean, const float* save_invstd, int act, void* dx_planes, float* dgamma,
+                    float* dbeta, float* coeffs, float* workspace, void* stream);
+int spnet_bn_bwd_from_partials_x3(const float* x, const float* dy, long M, int C, const float* gamma,
+                                  const float* beta, const float* save_mean, const float* save_invstd, int P,
+                                  const float* partial, void* dx_planes, float* dgamma, float* dbeta, float* coeffs,
+                                  void* stream);
 
 /* Reduction half of the backward only (dgamma, dbeta, blend coefficients for spnet_gemm_f32_bnblend). */
 int spnet_bn_bwd_coeffs_from_partials(int P, const float* partial, long M, int C, const float* gamma,

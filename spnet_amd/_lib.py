@@ -53,6 +53,10 @@ _SIGS = {
     "spnet_dwconv3x3_tiled_fwd": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, P, P, P]),
     "spnet_dwconv3x3_tiled_fwd_bnfin": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, P, c_int, c_long, P, P, P, P, P, P, P,
                                                 c_float, c_float, P]),
+    "spnet_dwconv3x3_tiled_fwd_x3": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, P, P, P]),
+    "spnet_dwconv3x3_tiled_fwd_bnfin_x3": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, P, c_int, c_long, P, P, P, P, P, P, P,
+                                                   c_float, c_float, P]),
+    "spnet_dwconv3x3_stream_fwd_x3": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, P, P, c_int, P]),
     "spnet_dwconv3x3_tiled_bwd_ws": (c_long, [c_int, c_int, c_int, c_int]),
     "spnet_dwconv3x3_tiled_rows": (c_long, [c_int, c_int, c_int, c_int]),
     "spnet_dwconv3x3_tiled_bwd": (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, P, P, P, P, P, P, P, P, P]),
@@ -67,6 +71,8 @@ _SIGS = {
     "spnet_bn_finalize_apply": (c_int, [P, c_int, P, c_long, c_int, P, P, P, P, P, P, P, c_int, P, P, c_float, c_float, P]),
     "spnet_bn_finalize_apply_ld": (c_int, [P, c_int, P, c_long, c_int, P, P, P, P, P, P, P, c_int, P, P, c_long, c_float, c_float, P]),
     "spnet_bn_bwd_from_partials": (c_int, [P, P, c_long, c_int, P, P, P, P, c_int, P, P, P, P, P, P]),
+    "spnet_bn_bwd_from_partials_x3": (c_int, [P, P, c_long, c_int, P, P, P, P, c_int, P, P, P, P, P, P]),
+    "spnet_bn_bwd_x3": (c_int, [P, P, c_long, c_int, P, P, P, P, c_int, P, P, P, P, P, P]),
     "spnet_gemm_f32_colstats": (c_int, [P, c_int, c_int, P, c_int, c_int, P, c_int, c_int, c_int, c_int, c_int, P, P, P]),
     "spnet_gemm_f32_bnblend": (c_int, [P, P, P, c_int, c_int, P, c_int, P, c_int, c_int, c_int, c_int, c_int, P, P]),
     "spnet_bn_bwd_coeffs_from_partials": (c_int, [c_int, P, c_long, c_int, P, P, P, P, P, P, c_int, P]),

@@ -7,7 +7,7 @@
 // that combines them in a fixed order in double precision.
 //
 // Activation fused behind the affine: 0 none, 1 ReLU, 2 LeakyReLU(0.1), 3 ReLU6 (keras.applications.mobilenet.relu6).
-#include "common.h"
+#include "x3t.h"
 
 #define BN_MAX_PARTS 256
 
@@ -386,7 +386,9 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_vec_kernel(
     const float* __restrict__ mean, const float* __restrict__ invstd,
     const float* __restrict__ gamma, const float* __restrict__ beta, int act,
     const float* __restrict__ k1, const float* __restrict__ k2, const float* __restrict__ k3,
-    float* __restrict__ dx) {
+    float* __restrict__ dx, unsigned short* __restrict__ planes, long plane_stride) {
+  // planes != NULL: dx goes out as the bf16x3 planes of the [M][C] matrix (x3t.h) -- the operand of the pointwise layer's
+  // data-gradient and weight-gradient GEMMs -- instead of fp32
   const int c4n = C >> 2;
   const long total = M * c4n;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
@@ -415,7 +417,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_vec_kernel(
     o.y = fmaf(a.y, g.y, fmaf(b.y, xh.y, d.y));
     o.z = fmaf(a.z, g.z, fmaf(b.z, xh.z, d.z));
     o.w = fmaf(a.w, g.w, fmaf(b.w, xh.w, d.w));
-    *reinterpret_cast<float4*>(dx + i * 4) = o;
+    if (planes) x3t_store4(planes, plane_stride, x3t_off(i / c4n, c, (C + 31) >> 5), o.x, o.y, o.z, o.w);
+    else *reinterpret_cast<float4*>(dx + i * 4) = o;
   }
 }
 
@@ -547,7 +550,7 @@ __global__ __launch_bounds__(256) void bn_bwd_fused_vec_kernel(
     const float* __restrict__ x, const float* __restrict__ dy, long M, int C, const float* __restrict__ partial, int P,
     const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ mean,
     const float* __restrict__ invstd, int act, float* __restrict__ dgamma, float* __restrict__ dbeta,
-    float* __restrict__ dx, int rows_per_slab, int chunks) {
+    float* __restrict__ dx, int rows_per_slab, int chunks, unsigned short* __restrict__ planes, long plane_stride) {
   __shared__ double dred[2 * 16 * BN_FUSE_CH];
   __shared__ __attribute__((aligned(16))) float cf[7][BN_FUSE_CH];   // k1, k2, k3, mean, invstd, gamma, beta
   const int wid = xcd_remap(blockIdx.x, gridDim.x);                  // XCD-aware order (see the forward kernel)
@@ -607,7 +610,8 @@ __global__ __launch_bounds__(256) void bn_bwd_fused_vec_kernel(
     o.y = fmaf(k1.y, g.y, fmaf(k2.y, xh.y, k3.y));
     o.z = fmaf(k1.z, g.z, fmaf(k2.z, xh.z, k3.z));
     o.w = fmaf(k1.w, g.w, fmaf(k2.w, xh.w, k3.w));
-    *reinterpret_cast<float4*>(dx + r * C + c) = o;
+    if (planes) x3t_store4(planes, plane_stride, x3t_off(r, c, (C + 31) >> 5), o.x, o.y, o.z, o.w);   // (see bn_bwd_apply_vec_kernel)
+    else *reinterpret_cast<float4*>(dx + r * C + c) = o;
   };
 #pragma unroll
   for (int u = 0; u < BN_FUSE_AHEAD; ++u) {
@@ -757,12 +761,18 @@ extern "C" int spnet_bn_fwd_infer(const float* x, long M, int C, const float* ga
 
 // Backward of y = act(BN(x)): dx, dgamma[C], dbeta[C].  x is the BN *input* saved by the forward.
 // coeffs: 3*C floats of scratch.  workspace: spnet_bn_ws(M,C) floats.  dx may alias dy.
-extern "C" int spnet_bn_bwd(const float* x, const float* dy, long M, int C, const float* gamma,
-                            const float* beta, const float* save_mean, const float* save_invstd,
-                            int act, float* dx, float* dgamma, float* dbeta, float* coeffs,
-                            float* workspace, void* stream) {
+static bool bn_planes_ok(const void* p, long M, int C) {
+  return p && !(((uintptr_t)p) & 15) && !(C & 3) && 3 * x3t_plane_elems(M, C) * 2 < (1L << 31);
+}
+
+static int bn_bwd_impl(const float* x, const float* dy, long M, int C, const float* gamma,
+                       const float* beta, const float* save_mean, const float* save_invstd,
+                       int act, float* dx, unsigned short* planes, float* dgamma, float* dbeta, float* coeffs,
+                       float* workspace, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   if ((C & 3) && C > 4) return (int)hipErrorInvalidValue;
+  if (planes && !bn_planes_ok(planes, M, C)) return (int)hipErrorInvalidValue;
+  const long ps = x3t_plane_elems(M, C);
   const int parts = bn_parts(M, C);
   launch_partial<1>(x, dy, M, C, save_mean, save_invstd, gamma, beta, act, workspace, parts, st);
   if (!(C & 3) && bn_fuse_ok(parts, M, C)) {      // few partial rows: finalize folded into the apply pass (same results)
@@ -770,7 +780,7 @@ extern "C" int spnet_bn_bwd(const float* x, const float* dy, long M, int C, cons
     const int chunks = (C + BN_FUSE_CH - 1) / BN_FUSE_CH;
     dim3 grid((unsigned)(chunks * ((M + rps - 1) / rps)));
     hipLaunchKernelGGL(bn_bwd_fused_vec_kernel, grid, dim3(256), 0, st, x, dy, M, C, workspace, parts, gamma, beta,
-                       save_mean, save_invstd, act, dgamma, dbeta, dx, rps, chunks);
+                       save_mean, save_invstd, act, dgamma, dbeta, dx, rps, chunks, planes, ps);
     SPNET_RETURN_LAUNCH_STATUS();
   }
   hipLaunchKernelGGL(bn_bwd_finalize_kernel<0>, dim3((C + BN_FIN_CH - 1) / BN_FIN_CH), dim3(256), 0, st, workspace, parts,
@@ -784,9 +794,25 @@ extern "C" int spnet_bn_bwd(const float* x, const float* dy, long M, int C, cons
     const long n4 = M * (C / 4);
     hipLaunchKernelGGL(bn_bwd_apply_vec_kernel, dim3(spnet_ew_grid(n4, 256)), dim3(256), 0, st, x, dy,
                        M, C, save_mean, save_invstd, gamma, beta, act, coeffs, coeffs + C,
-                       coeffs + 2 * C, dx);
+                       coeffs + 2 * C, dx, planes, ps);
   }
   SPNET_RETURN_LAUNCH_STATUS();
+}
+extern "C" int spnet_bn_bwd(const float* x, const float* dy, long M, int C, const float* gamma,
+                            const float* beta, const float* save_mean, const float* save_invstd,
+                            int act, float* dx, float* dgamma, float* dbeta, float* coeffs,
+                            float* workspace, void* stream) {
+  return bn_bwd_impl(x, dy, M, C, gamma, beta, save_mean, save_invstd, act, dx, nullptr, dgamma, dbeta, coeffs, workspace, stream);
+}
+// ... with dx written as the bf16x3 planes of the [M][C] matrix (csrc/x3t.h; zeroed allocation of
+// 3 * spnet_bf16x3_plane_elems(M, C) bf16; C % 4 == 0): the operand of spnet_gemm_bf16x3_pp / _wgrad_batched
+extern "C" int spnet_bn_bwd_x3(const float* x, const float* dy, long M, int C, const float* gamma,
+                               const float* beta, const float* save_mean, const float* save_invstd,
+                               int act, void* dx_planes, float* dgamma, float* dbeta, float* coeffs,
+                               float* workspace, void* stream) {
+  if (!dx_planes) return (int)hipErrorInvalidValue;
+  return bn_bwd_impl(x, dy, M, C, gamma, beta, save_mean, save_invstd, act, nullptr, reinterpret_cast<unsigned short*>(dx_planes),
+                     dgamma, dbeta, coeffs, workspace, stream);
 }
 
 // ---------------------------------------------------------------- split entry points (fused pipelines)
@@ -866,26 +892,44 @@ extern "C" int spnet_bn_finalize_apply(float* partial, int P, const float* x, lo
 
 // Backward given the two per-channel sums as partial[P][2][C] (sum g, sum g*xhat; g already includes
 // any activation mask): dgamma, dbeta, dx = k1*g + k2*xhat + k3.
-extern "C" int spnet_bn_bwd_from_partials(const float* x, const float* dy, long M, int C, const float* gamma,
-                                          const float* beta, const float* save_mean,
-                                          const float* save_invstd, int P, const float* partial, float* dx,
-                                          float* dgamma, float* dbeta, float* coeffs, void* stream) {
+static int bn_bwd_from_partials_impl(const float* x, const float* dy, long M, int C, const float* gamma,
+                                     const float* beta, const float* save_mean,
+                                     const float* save_invstd, int P, const float* partial, float* dx, unsigned short* planes,
+                                     float* dgamma, float* dbeta, float* coeffs, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   if (C & 3) return (int)hipErrorInvalidValue;
+  if (planes && !bn_planes_ok(planes, M, C)) return (int)hipErrorInvalidValue;
+  const long ps = x3t_plane_elems(M, C);
   if (bn_fuse_ok(P, M, C)) {                                  // few partial rows: one launch (bit-identical results)
     const int rps = bn_fuse_rows_per_slab(M, C);
     const int chunks = (C + BN_FUSE_CH - 1) / BN_FUSE_CH;
     dim3 grid((unsigned)(chunks * ((M + rps - 1) / rps)));
     hipLaunchKernelGGL(bn_bwd_fused_vec_kernel, grid, dim3(256), 0, st, x, dy, M, C, partial, P, gamma, beta, save_mean,
-                       save_invstd, 0, dgamma, dbeta, dx, rps, chunks);
+                       save_invstd, 0, dgamma, dbeta, dx, rps, chunks, planes, ps);
     SPNET_RETURN_LAUNCH_STATUS();
   }
   hipLaunchKernelGGL(bn_bwd_finalize_kernel<0>, dim3((C + BN_FIN_CH - 1) / BN_FIN_CH), dim3(256), 0, st, partial, P,
                      C, M, gamma, save_invstd, save_mean, dgamma, dbeta, coeffs, coeffs + C, coeffs + 2 * C);
   const long n4 = M * (C / 4);
   hipLaunchKernelGGL(bn_bwd_apply_vec_kernel, dim3(spnet_ew_grid(n4, 256)), dim3(256), 0, st, x, dy, M, C,
-                     save_mean, save_invstd, gamma, beta, 0, coeffs, coeffs + C, coeffs + 2 * C, dx);
+                     save_mean, save_invstd, gamma, beta, 0, coeffs, coeffs + C, coeffs + 2 * C, dx, planes, ps);
   SPNET_RETURN_LAUNCH_STATUS();
+}
+extern "C" int spnet_bn_bwd_from_partials(const float* x, const float* dy, long M, int C, const float* gamma,
+                                          const float* beta, const float* save_mean,
+                                          const float* save_invstd, int P, const float* partial, float* dx,
+                                          float* dgamma, float* dbeta, float* coeffs, void* stream) {
+  return bn_bwd_from_partials_impl(x, dy, M, C, gamma, beta, save_mean, save_invstd, P, partial, dx, nullptr, dgamma, dbeta,
+                                   coeffs, stream);
+}
+// ... with dx as bf16x3 planes (see spnet_bn_bwd_x3)
+extern "C" int spnet_bn_bwd_from_partials_x3(const float* x, const float* dy, long M, int C, const float* gamma,
+                                             const float* beta, const float* save_mean,
+                                             const float* save_invstd, int P, const float* partial, void* dx_planes,
+                                             float* dgamma, float* dbeta, float* coeffs, void* stream) {
+  if (!dx_planes) return (int)hipErrorInvalidValue;
+  return bn_bwd_from_partials_impl(x, dy, M, C, gamma, beta, save_mean, save_invstd, P, partial, nullptr,
+                                   reinterpret_cast<unsigned short*>(dx_planes), dgamma, dbeta, coeffs, stream);
 }
 
 // The reduction half of the backward only: dgamma, dbeta and the blend coefficients [k1 | k2' | k3'] (cld floats

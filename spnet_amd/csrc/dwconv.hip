@@ -6,7 +6,7 @@
 //   LDS-tiled stride-1 kernels (forward; fused backward = data + weight gradient + producer BatchNorm sums)
 //   strided gather kernels (stride 1 | 2: forward, data gradient, weight gradient)
 //   row reductions shared by the two-stage (deterministic) weight-gradient sums
-#include "common.h"
+#include "x3t.h"
 
 __device__ __forceinline__ float4 f4_relu(float4 v) {
   return make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));
@@ -86,7 +86,10 @@ __global__ __launch_bounds__(256) void dw3x3_tile_fwd_kernel(const float* __rest
                                                              float* __restrict__ out, int H, int W, int C,
                                                              int relu_in, int tiles_h, int tiles_w,
                                                              int cchunks, const float* __restrict__ in_scale,
-                                                             const float* __restrict__ in_shift, DwBnFinalize fin) {
+                                                             const float* __restrict__ in_shift, DwBnFinalize fin,
+                                                             unsigned short* __restrict__ planes, long plane_stride) {
+  // planes != NULL: the output goes out as the bf16x3 planes of the [B*H*W][C] matrix (x3t.h) -- the A operand of the
+  // pointwise GEMMs that follow (forward, weight gradient) -- instead of fp32: 6 bytes per element written, no fp32 copy.
   constexpr int PW = TW + 2;
   constexpr int CC2 = 2 * CC4;
   static_assert(CC2 * TW == 256, "thread layout");
@@ -208,8 +211,10 @@ __global__ __launch_bounds__(256) void dw3x3_tile_fwd_kernel(const float* __rest
     f2_fma(a_next, v1, k[1]); f2_fma(a_next, v2, k[2]);
     const int t = rr - 1;                            // completed output tile-row
     const int ho = h0 + t - 1;
-    if (t >= 1 && t <= TH && ho < H && w < W)
-      *reinterpret_cast<float2*>(out + ibase + ((long)ho * W + w) * C + c2 * 2) = a_prev;
+    if (t >= 1 && t <= TH && ho < H && w < W) {
+      if (planes) x3t_store2(planes, plane_stride, x3t_off(((long)b * H + ho) * W + w, c2 * 2, (C + 31) >> 5), a_prev.x, a_prev.y);
+      else *reinterpret_cast<float2*>(out + ibase + ((long)ho * W + w) * C + c2 * 2) = a_prev;
+    }
     a_prev = a_cur;
     a_cur = a_next;
   }
@@ -415,11 +420,15 @@ __device__ __forceinline__ void dw_bs(__amdgpu_buffer_rsrc_t r, const v4f v, int
 // read 4 x CL x 16 contiguous bytes per pixel where the plane has that many channels
 struct DwStreamGeom { int strips, cchunks, segs, rows_per_seg; long waves; };
 
-template <int CL, int PD>
+template <int CL, int PD, bool X3>
 __global__ __launch_bounds__(256) void dw3x3_stream_fwd_kernel(const float* __restrict__ in, const float* __restrict__ wt,
                                                                float* __restrict__ out, int H, int W, int C, int relu_in,
                                                                const float* __restrict__ in_scale,
-                                                               const float* __restrict__ in_shift, DwStreamGeom g) {
+                                                               const float* __restrict__ in_shift, DwStreamGeom g,
+                                                               unsigned short* __restrict__ planes, long plane_stride) {
+  // X3: the output as bf16x3 planes (see dw3x3_tile_fwd_kernel; a template parameter, so that a row of the march stays ONE
+  // basic block with counted waits); a wave's store then covers 8 consecutive
+  // pixels x 32 channels = 512 contiguous bytes of a piece, three times.
   constexpr int SW = 64 / CL;
   const int lane = threadIdx.x & 63;
   // (the wave index is uniform: readfirstlane tells the compiler, so that descriptors and row offsets live in SGPRs)
@@ -442,7 +451,10 @@ __global__ __launch_bounds__(256) void dw3x3_stream_fwd_kernel(const float* __re
   const long rstride = (long)W * C;
   const int rbytes = (int)rstride * 4;                // bytes per image row
   const __amdgpu_buffer_rsrc_t rs_in = dw_rsrc(in + (long)b * H * rstride, H * rbytes);
-  const __amdgpu_buffer_rsrc_t rs_out = dw_rsrc(out + (long)b * H * rstride, H * rbytes);
+  const __amdgpu_buffer_rsrc_t rs_out = X3 ? __builtin_amdgcn_make_buffer_rsrc(planes, 0, (int)(3 * plane_stride * 2), 0x00020000)
+                                               : dw_rsrc(out + (long)b * H * rstride, H * rbytes);
+  const int nk = (C + 31) >> 5;
+  const int pbytes = (int)(plane_stride * 2);
   const int vo = own_ok ? (w * C + c4 * 4) * 4 : DW_OOB;          // byte offsets inside an image row
   const int ve = edge_ok ? (we * C + c4 * 4) * 4 : DW_OOB;
   const int c4c = min(c4, c4n - 1) * 4;               // (clamped: per-channel vectors are fetched by every lane)
@@ -494,7 +506,19 @@ __global__ __launch_bounds__(256) void dw3x3_stream_fwd_kernel(const float* __re
       v4f a_next = v0 * k[0];
       a_next = v4_fma(v1, k[1], a_next); a_next = v4_fma(v2, k[2], a_next);
       const int t = r - 1;                            // completed output row
-      dw_bs(rs_out, a_prev, (t >= h_lo && t < h_hi) ? vo : DW_OOB, min(max(t, 0), H - 1) * rbytes);
+      if (X3) {
+        unsigned h0, m0, l0, h1, m1, l1;
+        x3_split_pk(a_prev.x, a_prev.y, h0, m0, l0);
+        x3_split_pk(a_prev.z, a_prev.w, h1, m1, l1);
+        const int m = (b * H + min(max(t, 0), H - 1)) * W + w;
+        const int po = (t >= h_lo && t < h_hi && own_ok) ? x3t_off32_bytes(m, c4 * 4, nk) : DW_OOB;
+        typedef unsigned int v2u __attribute__((ext_vector_type(2)));
+        __builtin_amdgcn_raw_buffer_store_b64(v2u{h0, h1}, rs_out, po, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b64(v2u{m0, m1}, rs_out, po, pbytes, 0);
+        __builtin_amdgcn_raw_buffer_store_b64(v2u{l0, l1}, rs_out, po, 2 * pbytes, 0);
+      } else {
+        dw_bs(rs_out, a_prev, (t >= h_lo && t < h_hi) ? vo : DW_OOB, min(max(t, 0), H - 1) * rbytes);
+      }
       a_prev = a_cur;
       a_cur = a_next;
     }
@@ -953,14 +977,21 @@ static DwGeom dw_geom(int B, int H, int W, int C, bool fwd) {
   return g;
 }
 
+static bool dw_planes_ok(const void* p, int B, int H, int W, int C) {
+  return p && !(((uintptr_t)p) & 15) && 3 * x3t_plane_elems((long)B * H * W, C) * 2 < (1L << 31);
+}
+
 static int dw_tiled_fwd(const float* x, const float* w, float* y, int B, int H, int W, int C, int relu_in,
-                        const float* in_scale, const float* in_shift, const DwBnFinalize& fin, void* stream) {
+                        const float* in_scale, const float* in_shift, const DwBnFinalize& fin, void* stream,
+                        unsigned short* planes = nullptr) {
   if (C & 3) return (int)hipErrorInvalidValue;
+  if (planes && !dw_planes_ok(planes, B, H, W, C)) return (int)hipErrorInvalidValue;
+  const long plane_stride = x3t_plane_elems((long)B * H * W, C);
   const DwGeom g = dw_geom(B, H, W, C, true);
 #define DW_FWD(CC4, TW, TH)                                                                                     \
   hipLaunchKernelGGL((dw3x3_tile_fwd_kernel<CC4, TW, TH>), dim3((unsigned)g.nblk), dim3(256), g.lds_fwd,        \
                      (hipStream_t)stream, x, w, y, H, W, C, relu_in, g.tiles_h, g.tiles_w, g.cchunks, in_scale, \
-                     in_shift, fin)
+                     in_shift, fin, planes, plane_stride)
   if (g.cfg == 1) DW_FWD(16, 8, 6);
   else if (g.cfg == 2) DW_FWD(8, 16, 24);
   else DW_FWD(8, 16, 12);
@@ -974,23 +1005,49 @@ extern "C" int spnet_dwconv3x3_tiled_fwd(const float* x, const float* w, float* 
   DwBnFinalize fin = {};
   return dw_tiled_fwd(x, w, y, B, H, W, C, relu_in, in_scale, in_shift, fin, stream);
 }
+// ... with the output written as the bf16x3 planes of the [B*H*W][C] matrix (csrc/x3t.h; zeroed allocation of
+// 3 * spnet_bf16x3_plane_elems(B*H*W, C) bf16): the A operand of spnet_gemm_bf16x3_pp / _wgrad_batched; same arithmetic.
+extern "C" int spnet_dwconv3x3_tiled_fwd_x3(const float* x, const float* w, void* y_planes, int B, int H, int W,
+                                            int C, int relu_in, const float* in_scale,
+                                            const float* in_shift, void* stream) {
+  DwBnFinalize fin = {};
+  if (!y_planes) return (int)hipErrorInvalidValue;
+  return dw_tiled_fwd(x, w, nullptr, B, H, W, C, relu_in, in_scale, in_shift, fin, stream, reinterpret_cast<unsigned short*>(y_planes));
+}
 
 // The same with the producer BatchNorm's forward finalize folded into the prologue (training): partial[rows][2][C]
 // are the column sums of the producer's pre-normalisation output (spnet_gemm_f32_colstats), M its row count; the kernel
 // applies relu?(x*scale + shift) with the scale / shift it derives, writes save_mean / save_invstd / scale_shift[2C] and
 // updates the moving statistics exactly like spnet_bn_finalize_fwd.  rows <= 128.
-extern "C" int spnet_dwconv3x3_tiled_fwd_bnfin(const float* x, const float* w, float* y, int B, int H, int W, int C,
-                                               int relu_in, const float* partial, int rows, long M,
-                                               const float* gamma, const float* beta, float* moving_mean,
-                                               float* moving_var, float* save_mean, float* save_invstd,
-                                               float* scale_shift, float eps, float momentum, void* stream) {
+static int dw_tiled_fwd_bnfin(const float* x, const float* w, float* y, unsigned short* planes, int B, int H, int W, int C,
+                              int relu_in, const float* partial, int rows, long M,
+                              const float* gamma, const float* beta, float* moving_mean,
+                              float* moving_var, float* save_mean, float* save_invstd,
+                              float* scale_shift, float eps, float momentum, void* stream) {
   if (!partial || rows < 1 || rows > 128 || M < 1) return (int)hipErrorInvalidValue;
   DwBnFinalize fin;
   fin.partial = partial; fin.gamma = gamma; fin.beta = beta; fin.moving_mean = moving_mean; fin.moving_var = moving_var;
   fin.save_mean = save_mean; fin.save_invstd = save_invstd; fin.scale = scale_shift; fin.shift = scale_shift + C;
   fin.rows = rows; fin.M = M;
   fin.eps = eps; fin.momentum = momentum;
-  return dw_tiled_fwd(x, w, y, B, H, W, C, relu_in, nullptr, nullptr, fin, stream);
+  return dw_tiled_fwd(x, w, y, B, H, W, C, relu_in, nullptr, nullptr, fin, stream, planes);
+}
+extern "C" int spnet_dwconv3x3_tiled_fwd_bnfin(const float* x, const float* w, float* y, int B, int H, int W, int C,
+                                               int relu_in, const float* partial, int rows, long M,
+                                               const float* gamma, const float* beta, float* moving_mean,
+                                               float* moving_var, float* save_mean, float* save_invstd,
+                                               float* scale_shift, float eps, float momentum, void* stream) {
+  return dw_tiled_fwd_bnfin(x, w, y, nullptr, B, H, W, C, relu_in, partial, rows, M, gamma, beta, moving_mean, moving_var,
+                            save_mean, save_invstd, scale_shift, eps, momentum, stream);
+}
+extern "C" int spnet_dwconv3x3_tiled_fwd_bnfin_x3(const float* x, const float* w, void* y_planes, int B, int H, int W, int C,
+                                                  int relu_in, const float* partial, int rows, long M,
+                                                  const float* gamma, const float* beta, float* moving_mean,
+                                                  float* moving_var, float* save_mean, float* save_invstd,
+                                                  float* scale_shift, float eps, float momentum, void* stream) {
+  if (!y_planes) return (int)hipErrorInvalidValue;
+  return dw_tiled_fwd_bnfin(x, w, nullptr, reinterpret_cast<unsigned short*>(y_planes), B, H, W, C, relu_in, partial, rows, M,
+                            gamma, beta, moving_mean, moving_var, save_mean, save_invstd, scale_shift, eps, momentum, stream);
 }
 
 // ---------------------------------------------------------------- streaming entry points
@@ -1044,16 +1101,34 @@ extern "C" long spnet_dwconv3x3_stream_bwd_ws(int B, int H, int W, int C, int ro
 }
 
 // y = dw3x3(relu?(x * in_scale + in_shift)), the arithmetic (and bits) of spnet_dwconv3x3_tiled_fwd
-extern "C" int spnet_dwconv3x3_stream_fwd(const float* x, const float* w, float* y, int B, int H, int W, int C,
-                                          int relu_in, const float* in_scale, const float* in_shift, int rows_per_seg,
-                                          void* stream) {
+static int dw_stream_fwd(const float* x, const float* w, float* y, unsigned short* planes, int B, int H, int W, int C,
+                         int relu_in, const float* in_scale, const float* in_shift, int rows_per_seg, void* stream) {
   if ((C & 3) || B < 1 || H < 1 || W < 1) return (int)hipErrorInvalidValue;
+  if (planes && !dw_planes_ok(planes, B, H, W, C)) return (int)hipErrorInvalidValue;
   if ((long)H * W * C * 4 >= (1L << 31)) return (int)hipErrorInvalidValue;       // 32-bit byte offsets inside an image
   const DwStreamGeom g = dw_stream_geom(B, H, W, C, rows_per_seg, false);
   if ((g.waves + 3) / 4 > 0x7fffffffL) return (int)hipErrorInvalidValue;
-  hipLaunchKernelGGL((dw3x3_stream_fwd_kernel<DWS_CL, DWS_PD_FWD>), dim3((unsigned)((g.waves + 3) / 4)), dim3(256), 0,
-                     (hipStream_t)stream, x, w, y, H, W, C, relu_in, in_scale, in_shift, g);
+  if (planes)
+    hipLaunchKernelGGL((dw3x3_stream_fwd_kernel<DWS_CL, DWS_PD_FWD, true>), dim3((unsigned)((g.waves + 3) / 4)), dim3(256), 0,
+                       (hipStream_t)stream, x, w, y, H, W, C, relu_in, in_scale, in_shift, g, planes,
+                       x3t_plane_elems((long)B * H * W, C));
+  else
+    hipLaunchKernelGGL((dw3x3_stream_fwd_kernel<DWS_CL, DWS_PD_FWD, false>), dim3((unsigned)((g.waves + 3) / 4)), dim3(256), 0,
+                       (hipStream_t)stream, x, w, y, H, W, C, relu_in, in_scale, in_shift, g, planes, 0L);
   SPNET_RETURN_LAUNCH_STATUS();
+}
+extern "C" int spnet_dwconv3x3_stream_fwd(const float* x, const float* w, float* y, int B, int H, int W, int C,
+                                          int relu_in, const float* in_scale, const float* in_shift, int rows_per_seg,
+                                          void* stream) {
+  return dw_stream_fwd(x, w, y, nullptr, B, H, W, C, relu_in, in_scale, in_shift, rows_per_seg, stream);
+}
+// ... with the bf16x3 planes output (see spnet_dwconv3x3_tiled_fwd_x3)
+extern "C" int spnet_dwconv3x3_stream_fwd_x3(const float* x, const float* w, void* y_planes, int B, int H, int W, int C,
+                                             int relu_in, const float* in_scale, const float* in_shift, int rows_per_seg,
+                                             void* stream) {
+  if (!y_planes) return (int)hipErrorInvalidValue;
+  return dw_stream_fwd(x, w, nullptr, reinterpret_cast<unsigned short*>(y_planes), B, H, W, C, relu_in, in_scale, in_shift,
+                       rows_per_seg, stream);
 }
 
 // The fused backward of spnet_dwconv3x3_tiled_bwd in streaming form: same arguments and outputs; the partial buffers

@@ -43,6 +43,11 @@ __device__ __forceinline__ long x3t_off(long row, int col, int nk) {
   const int r16 = (int)(row & 15);
   return ((row >> 4) * nk + (col >> 5)) * 512 + r16 * 32 + ((((col & 31) >> 3) ^ (0 - (r16 >> 2))) & 3) * 8 + (col & 7);
 }
+// the same in 32-bit arithmetic, as a BYTE offset (plane sets are at most 2 GiB)
+__device__ __forceinline__ int x3t_off32_bytes(int row, int col, int nk) {
+  const int r16 = row & 15;
+  return (((row >> 4) * nk + (col >> 5)) << 10) + (r16 << 6) + (((((col & 31) >> 3) ^ (0 - (r16 >> 2))) & 3) << 4) + ((col & 7) << 1);
+}
 // four consecutive columns (col % 4 == 0) of one row: 8 bytes per plane
 __device__ __forceinline__ void x3t_store4(unsigned short* __restrict__ planes, long plane_stride, long off, float a, float b,
                                            float c, float d) {

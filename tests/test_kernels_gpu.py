@@ -341,6 +341,88 @@ def test_gemm_bf16x3_wgrad_from_planes(L, M, cin, cout, nb):
     assert int(L.spnet_gemm_bf16x3_wgrad_ksplit(256, 256, 94752, 1)) > 8 and int(L.spnet_gemm_bf16x3_wgrad_ksplit(728, 728, 6144, 24)) == 1
 
 
+def _planes_equal_split_of(L, planes, y, M, C):
+    """`planes` (written by a producer kernel) == the split of the fp32 tensor y [M][C] the fp32 form of that kernel
+    writes: bit for bit, pads included (they must still be zero), and h + m + l == y exactly."""
+    ref = x3_planes(L, M, C)
+    L.spnet_split_rows_bf16x3(y.data_ptr(), C, ref.data_ptr(), M, C, st())
+    assert torch.equal(planes, ref)
+    pl = x3_untile(planes, M, C)
+    assert torch.equal((pl[0] + pl[1] + pl[2])[:M, :C], y.reshape(M, C).cpu().double())
+
+
+@pytest.mark.parametrize("B,H,W,C", [(2, 12, 16, 728), (3, 7, 5, 64), (2, 6, 8, 1536), (1, 1, 1, 8), (2, 24, 32, 256),
+                                     (1, 47, 63, 128), (2, 13, 17, 40)])
+@pytest.mark.parametrize("form", ["tiled", "stream", "stream5", "bnfin"])
+def test_dwconv_forward_writes_bf16x3_planes(L, B, H, W, C, form):
+    """spnet_dwconv3x3_{tiled,stream}_fwd_x3 / _tiled_fwd_bnfin_x3: the depthwise output as the bf16x3 planes the pointwise
+    GEMMs read == the split of the fp32 form's output, bit for bit (same arithmetic, another store)."""
+    rs = np.random.RandomState(B * H + C)
+    x = dev(rs.randn(B, H, W, C) * np.exp(rs.randn(B, H, W, C)))
+    w = dev(rs.randn(3, 3, C))
+    sc, sh = dev(rs.rand(C) + 0.5), dev(rs.randn(C) * 0.1)
+    M = B * H * W
+    y = torch.full((B, H, W, C), float("nan"), device="cuda")
+    planes = x3_planes(L, M, C)
+    if form == "bnfin":
+        rows = 5
+        part = dev(rs.rand(rows, 2, C) * M)
+        part[:, 1] += part[:, 0] ** 2 / M          # sum of squares >= (sum)^2 / M
+        gam, bet = dev(rs.rand(C) + 0.5), dev(rs.randn(C) * 0.1)
+        outs = []
+        for k in range(2):
+            mm, mv, sm, si, ss = [torch.zeros(C, device="cuda") for _ in range(4)] + [torch.zeros(2 * C, device="cuda")]
+            args = (B, H, W, C, 1, part.data_ptr(), rows, M, gam.data_ptr(), bet.data_ptr(), mm.data_ptr(), mv.data_ptr(),
+                    sm.data_ptr(), si.data_ptr(), ss.data_ptr(), 1e-3, 0.99, st())
+            if k == 0:
+                L.spnet_dwconv3x3_tiled_fwd_bnfin(x.data_ptr(), w.data_ptr(), y.data_ptr(), *args)
+            else:
+                L.spnet_dwconv3x3_tiled_fwd_bnfin_x3(x.data_ptr(), w.data_ptr(), planes.data_ptr(), *args)
+            outs.append((mm, mv, sm, si, ss))
+        for a, b in zip(*outs):
+            assert torch.equal(a, b)
+    elif form == "tiled":
+        L.spnet_dwconv3x3_tiled_fwd(x.data_ptr(), w.data_ptr(), y.data_ptr(), B, H, W, C, 1, sc.data_ptr(), sh.data_ptr(), st())
+        L.spnet_dwconv3x3_tiled_fwd_x3(x.data_ptr(), w.data_ptr(), planes.data_ptr(), B, H, W, C, 1, sc.data_ptr(), sh.data_ptr(), st())
+    else:
+        rps = 5 if form == "stream5" else 0
+        L.spnet_dwconv3x3_stream_fwd(x.data_ptr(), w.data_ptr(), y.data_ptr(), B, H, W, C, 1, sc.data_ptr(), sh.data_ptr(), rps, st())
+        L.spnet_dwconv3x3_stream_fwd_x3(x.data_ptr(), w.data_ptr(), planes.data_ptr(), B, H, W, C, 1, sc.data_ptr(), sh.data_ptr(), rps, st())
+    assert bool(torch.isfinite(y).all())
+    _planes_equal_split_of(L, planes, y, M, C)
+
+
+@pytest.mark.parametrize("M,C,P", [(6144, 728, 32), (6144, 728, 160), (1536, 1536, 16), (500, 36, 8), (94752, 256, 128)])
+@pytest.mark.parametrize("act", [0, 1])
+def test_batchnorm_backward_writes_bf16x3_planes(L, M, C, P, act):
+    """spnet_bn_bwd_from_partials_x3 (both of its paths: one launch up to 128 partial rows, finalize + apply beyond) and
+    spnet_bn_bwd_x3: dx as bf16x3 planes == the split of the fp32 form's dx, bit for bit; dgamma / dbeta identical."""
+    rs = np.random.RandomState(M + C)
+    x, g = dev(rs.randn(M, C)), dev(rs.randn(M, C) * np.exp(rs.randn(M, C)))
+    gamma, beta = dev(rs.rand(C) + 0.5), dev(rs.randn(C) * 0.1)
+    mu, isd = dev(rs.randn(C) * 0.1), dev(rs.rand(C) + 0.5)
+    part = dev(rs.randn(P, 2, C))
+    co = torch.empty(3 * C, device="cuda")
+    if act == 0:
+        dx = torch.full((M, C), float("nan"), device="cuda")
+        d0, d1 = [torch.empty(C, device="cuda") for _ in range(2)], [torch.empty(C, device="cuda") for _ in range(2)]
+        planes = x3_planes(L, M, C)
+        a = (x.data_ptr(), g.data_ptr(), M, C, gamma.data_ptr(), beta.data_ptr(), mu.data_ptr(), isd.data_ptr(), P, part.data_ptr())
+        L.spnet_bn_bwd_from_partials(*a, dx.data_ptr(), d0[0].data_ptr(), d0[1].data_ptr(), co.data_ptr(), st())
+        L.spnet_bn_bwd_from_partials_x3(*a, planes.data_ptr(), d1[0].data_ptr(), d1[1].data_ptr(), co.data_ptr(), st())
+        assert torch.equal(d0[0], d1[0]) and torch.equal(d0[1], d1[1])
+        _planes_equal_split_of(L, planes, dx, M, C)
+    ws = torch.empty(L.spnet_bn_ws(M, C), device="cuda")
+    dx = torch.full((M, C), float("nan"), device="cuda")
+    d0, d1 = [torch.empty(C, device="cuda") for _ in range(2)], [torch.empty(C, device="cuda") for _ in range(2)]
+    planes = x3_planes(L, M, C)
+    a = (x.data_ptr(), g.data_ptr(), M, C, gamma.data_ptr(), beta.data_ptr(), mu.data_ptr(), isd.data_ptr(), act)
+    L.spnet_bn_bwd(*a, dx.data_ptr(), d0[0].data_ptr(), d0[1].data_ptr(), co.data_ptr(), ws.data_ptr(), st())
+    L.spnet_bn_bwd_x3(*a, planes.data_ptr(), d1[0].data_ptr(), d1[1].data_ptr(), co.data_ptr(), ws.data_ptr(), st())
+    assert torch.equal(d0[0], d1[0]) and torch.equal(d0[1], d1[1])
+    _planes_equal_split_of(L, planes, dx, M, C)
+
+
 @pytest.mark.parametrize("tile", [0, 3, 5, 6])
 def test_gemm_batched_wgrad_form(L, tile):
     """Several weight-gradient problems of one shape in one launch == the same problems one by one."""
