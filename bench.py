@@ -521,23 +521,23 @@ def bf16x3_alt_measure(dev, iters=200):
 
 def exact_chain_step_measure(dev, X_pool, steps=20, warmup=5):
     """`roofline_alt.train_step`: the benchmark train step (Xception, batch 32, 512x384, without the augmentation kernels)
-    on the SAME engine in its two arithmetic modes, alternating: `pointwise="bf16x3"` (the product path since round 4: forward
-    and data-gradient GEMMs of the pointwise convolutions with >= 256 output columns on csrc/gemm_bf16x3.hip) and
-    `pointwise="f32"` (every GEMM the k-ordered fp32 MFMA chain, the product path of rounds 1-3): images/s and the GEMM
-    family's time from HIP events.  Weight gradients, the blended data-gradient GEMMs of blocks 2-3, block1_conv2 and the
+    on two engines over the same frames, alternating: `pointwise="bf16x3"` (the product path: the three GEMMs of every
+    pointwise convolution with >= 256 channels on csrc/gemm_bf16x3.hip, their operands written as bf16 planes by the
+    producing kernels) and `pointwise="f32"` (every GEMM the k-ordered fp32 MFMA chain, the product path of rounds 1-3):
+    images/s and the GEMM family's time from HIP events.  The blended data-gradient GEMMs of blocks 2-3, block1_conv2 and the
     Dense head are the exact fp32 kernels in both columns."""
     import torch
     from spnet_amd.engine import Engine
-    eng = Engine(H, W, BATCH, device=str(dev), seed=0)
+    engs = {"bf16x3": Engine(H, W, BATCH, device=str(dev), seed=0), "f32": Engine(H, W, BATCH, device=str(dev), seed=0, pointwise="f32")}
     X = X_pool[:BATCH].contiguous()
     Y = torch.rand(BATCH, 576, device=dev)
-
-    def step():
-        eng.train_step(X, Y, 1e-6)
-
     out = {}
     for name, mode in (("bf16x3", "bf16x3"), ("exact_fp32", "f32"), ("bf16x3_again", "bf16x3")):
-        eng.pointwise = mode
+        eng = engs[mode]
+
+        def step():
+            eng.train_step(X, Y, 1e-6)
+
         for _ in range(warmup):
             step()
         torch.cuda.synchronize()
@@ -560,11 +560,10 @@ def exact_chain_step_measure(dev, X_pool, steps=20, warmup=5):
                      "gemm_launches_per_step": g_n / n_prof,
                      "bf16x3_launches_per_step": sum(v[0] for v in x3) / n_prof,
                      "bf16x3_ms_per_step": round(sum(v[1] for v in x3) / n_prof, 3)}
-    eng.pointwise = "bf16x3"
     out["step_speedup_over_exact"] = round(out["exact_fp32"]["ms_per_step"] / out["bf16x3"]["ms_per_step"], 4)
     out["gemm_family_speedup_over_exact"] = round(out["exact_fp32"]["gemm_family_ms_per_step"] /
                                                   out["bf16x3"]["gemm_family_ms_per_step"], 4)
-    del eng
+    del eng, engs
     torch.cuda.empty_cache()
     return out
 

@@ -369,7 +369,7 @@ class Engine:
         many 96 x 96 tiles (192: measured, see Pointwise; the parity tests pass 0 so that small test plans run it too)."""
         if pointwise not in ("bf16x3", "f32"):
             raise ValueError("pointwise must be 'bf16x3' or 'f32'")
-        self.pointwise = pointwise
+        self._pointwise = pointwise     # fixed for the life of the plan: the operand buffers depend on it (`pointwise` property)
         self.x3_min_tiles = int(x3_min_tiles)
         if not torch.cuda.is_available():
             raise RuntimeError("spnet_amd.Engine needs a HIP device (no CPU fallback)")
@@ -437,6 +437,17 @@ class Engine:
         self.update_mask = None         # optional flat 0/1 tensor: frozen parameters are skipped by Adam
         self._build_graph()
         self._build_planes()
+
+    @property
+    def pointwise(self):
+        """"bf16x3" | "f32": which kernels run the pointwise GEMMs.  Read-only -- a bf16x3 plan keeps the operands of those
+        GEMMs as bf16 planes written by their producers (SepConvBN.x3p), there is no fp32 copy to fall back on; build
+        another Engine (share_from=...) for the other arithmetic."""
+        return self._pointwise
+
+    def new_planes(self, R, K):
+        """zeroed bf16x3 plane set of an [R][K] matrix (csrc/x3t.h): the pad rows / columns are never written"""
+        return torch.zeros(3 * int(L.spnet_bf16x3_plane_elems(R, K)), dtype=torch.int16, device=self.dev)
 
     @property
     def t(self):
@@ -764,6 +775,9 @@ class Engine:
                 if pd is not None:      # data gradient dX = dY W^T: (n = cin, k = cout) = W[n][k]
                     flat += [w, pd.data_ptr(), cout, cin, cout, 1]
                     mx = max(mx, pd.numel() // 3)
+            if self._planes_jobs is not None:     # a captured graph may still hold the old table's address: keep it alive,
+                self._planes_tables_kept = getattr(self, "_planes_tables_kept", []) + [self._planes_jobs[0]]
+                self._graph = self._igraph = None     # ... and re-capture with the new one
             self._planes_jobs = (torch.tensor(flat, dtype=torch.int64, device=self.dev), self._planes_gen[0], len(flat) // 6, mx)
         table, _, nj, mx = self._planes_jobs
         L.spnet_split_bf16x3_batched(table.data_ptr(), nj, mx, _stream())
@@ -824,6 +838,12 @@ class Engine:
         if not todo:
             return
         self.deferred_wgrads = []
+        x3 = [t for t in todo if t[0] == "x3"]
+        if x3:
+            self._flush_x3_wgrads(x3)
+            todo = [t for t in todo if t[0] != "x3"]
+            if not todo:
+                return
         x0, dy0, gw0, cin, cout, M = todo[0]
         if any((t[3], t[4], t[5]) != (cin, cout, M) for t in todo):
             raise RuntimeError("deferred weight gradients must share one shape")
@@ -849,6 +869,47 @@ class Engine:
                 prof.stop("gemm", t0, 2.0 * nb * cin * cout * M, ("AB x%d batched" % nb, cin, cout, M))
 
         side = self.wgrad_stream
+        if side is None:
+            launch()
+        else:
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                launch()
+
+    def _flush_x3_wgrads(self, todo):
+        """dW of the deferred layers whose operands are bf16x3 planes: ONE launch of spnet_gemm_bf16x3_wgrad_batched
+        (weight-gradient stream); a K split (slabs in the weight-gradient stream's workspace + one ordered sum per layer)
+        only if the batch alone does not fill the chip."""
+        _, _, _, _, cin, cout, M = todo[0]
+        if any((t[4], t[5], t[6]) != (cin, cout, M) for t in todo):
+            raise RuntimeError("deferred weight gradients must share one shape")
+        nb = len(todo)
+        side = self.wgrad_stream
+        region = WS_GEMM2 if side is not None else WS_GEMM
+        ks = int(L.spnet_gemm_bf16x3_wgrad_ksplit(cin, cout, M, nb))
+        if ks > 1 and nb * ks * cin * cout > region[1]:
+            ks = max(1, region[1] // (nb * cin * cout))
+        key = ("x3", ks) + tuple(v for t in todo for v in (t[1].data_ptr(), t[2].data_ptr(), t[3].data_ptr()))
+        if self._wgrad_table is None:
+            self._wgrad_table = {}
+        if key not in self._wgrad_table:
+            ws = self.ws_ptr(region)
+            flat = [v for b, t in enumerate(todo)
+                    for v in (t[1].data_ptr(), t[2].data_ptr(), t[3].data_ptr() if ks == 1 else ws + 4 * b * ks * cin * cout)]
+            self._wgrad_table[key] = torch.tensor(flat, dtype=torch.int64, device=self.dev)
+        table = self._wgrad_table[key]
+
+        def launch():
+            prof = self.prof
+            t0 = prof.start() if prof is not None else None
+            L.spnet_gemm_bf16x3_wgrad_batched(table.data_ptr(), nb, cin, cout, M, ks, _stream())
+            if ks > 1:
+                ws = self.ws_ptr(region)
+                for b, t in enumerate(todo):
+                    L.spnet_reduce_slabs(ws + 4 * b * ks * cin * cout, ks, cin, cout, t[3].data_ptr(), cout, _stream())
+            if prof is not None:
+                prof.stop("gemm", t0, 2.0 * nb * cin * cout * M, ("x3 AB x%d batched" % nb, cin, cout, M))
+
         if side is None:
             launch()
         else:
@@ -899,6 +960,10 @@ class Engine:
                           L.ptr(self.sq_scratch), self.loss_out[6:].data_ptr(), self.lr_ptr, _stream())
         self._tver[0] += 1
         self.refresh_transposes()
+        # ... and the bf16x3 planes of the new weights, here and not lazily at the next forward: a captured train step
+        # (SPNET_TRAIN_GRAPH=1) then always contains the split, whatever ran between the warm step and the capture
+        # (round-4 ADVICE: a predict / validation pass in between left the planes "fresh" and the graph without a split)
+        self.refresh_planes()
 
     def train_step(self, X, Y, lr, reducer=None):
         """augmented batch X -> forward -> custom_loss -> backward -> (all-reduce) -> Adam(+l2).
@@ -924,6 +989,7 @@ class Engine:
                 self._coeff_ver = -1
                 self._tver[0] += 1
                 self._wT_ver[0] = self._tver[0]
+                self._planes_ver[0] = self._tver[0]
                 return self.loss_out
             self._graph_warm += 1
         self._step_body(reducer, None)
@@ -1256,6 +1322,42 @@ class Pointwise:
             prof.stop("gemm", t0, 2.0 * self.M * N * K, (tag, self.M, N, K))
         return rows
 
+    def _x3p(self, tag, a_planes, b_planes, C, N, K, colstats_region=None):
+        """One planes x planes launch: C[M][N] = A planes x B planes^T (+ BatchNorm column sums); returns the partial row
+        count."""
+        e = self.e
+        prof = e.prof
+        t0 = prof.start() if prof is not None else None
+        rows = 0
+        if colstats_region is None:
+            L.spnet_gemm_bf16x3_pp(L.ptr(a_planes), L.ptr(b_planes), L.ptr(C), N, self.M, N, K, None, None, _stream())
+        else:
+            if (self.M + 95) // 96 * 2 * N > colstats_region[1]:
+                raise RuntimeError("BatchNorm partial region too small for M=%d N=%d" % (self.M, N))
+            L.spnet_gemm_bf16x3_pp(L.ptr(a_planes), L.ptr(b_planes), L.ptr(C), N, self.M, N, K, e.ws_ptr(colstats_region),
+                                   __import__("ctypes").addressof(_stat_rows), _stream())
+            rows = _stat_rows.value
+        if prof is not None:
+            prof.stop("gemm", t0, 2.0 * self.M * N * K, (tag, self.M, N, K))
+        return rows
+
+    def fwd_p(self, zp, y, colstats_region=None):
+        """Forward from the planes of x (written by the producing depthwise kernel); with colstats_region the BatchNorm
+        column sums of y are left there and the partial row count is returned."""
+        tag = "x3 aB" if colstats_region is None else "x3 aB+stats"
+        return self._x3p(tag, zp, self.e._planes[self.wname][0], y, self.cout, self.cin, colstats_region)
+
+    def bwd_p(self, zp, dyp, dx):
+        """Backward from planes: dW = z^T dy by spnet_gemm_bf16x3_wgrad_batched (deferred into the engine's batched launch,
+        or alone on the weight-gradient stream with a deterministic K split), dx = dy W^T by the planes x planes kernel."""
+        e = self.e
+        if self.defer_wgrad:
+            e.deferred_wgrads.append(("x3", zp, dyp, self.gw, self.cin, self.cout, self.M))
+        else:
+            e._flush_x3_wgrads([("x3", zp, dyp, self.gw, self.cin, self.cout, self.M)])
+        if dx is not None:
+            self._x3p("x3 ab", dyp, e._planes[self.wname][1], dx, self.cin, self.cout)
+
     def fwd(self, x, y):
         if self.x3_fwd and self.e.pointwise == "bf16x3":
             self._x3("x3 aB", x, self.cin, self.e._planes[self.wname][0], y, self.cout, self.cout, self.cin)
@@ -1453,6 +1555,23 @@ class BN:
         return out
 
 
+    def bwd_full_x3(self, x, g, out_planes, act):
+        """bwd_full with the result written as bf16x3 planes (the operand of the pointwise layer's two backward GEMMs)"""
+        e, C = self.e, self.C
+        L.spnet_bn_bwd_x3(L.ptr(x), L.ptr(g), self.M, C, L.ptr(self.gamma), L.ptr(self.beta), self.mean_ptr,
+                          self.invstd_ptr, act, L.ptr(out_planes), L.ptr(self.ggamma), L.ptr(self.gbeta),
+                          L.ptr(e.small[:3 * C]), e.ws_ptr(WS_MISC), _stream())
+        return out_planes
+
+    def bwd_from_partials_x3(self, x, g, out_planes, rows):
+        """bwd_from_partials with the result written as bf16x3 planes"""
+        e, C = self.e, self.C
+        L.spnet_bn_bwd_from_partials_x3(L.ptr(x), L.ptr(g), self.M, C, L.ptr(self.gamma), L.ptr(self.beta),
+                                        self.mean_ptr, self.invstd_ptr, rows, e.ws_ptr(WS_BNP), L.ptr(out_planes),
+                                        L.ptr(self.ggamma), L.ptr(self.gbeta), L.ptr(e.small[:3 * C]), _stream())
+        return out_planes
+
+
 class Ref:
     """A tensor as consumers see it: `t` in HBM, plus (optionally) the BatchNorm whose affine still has to
     be applied on load because the normalised tensor was never materialised."""
@@ -1471,6 +1590,14 @@ def _dw_fwd(x, w, y, B, H, W, C, relu_in, scale_ptr, shift_ptr):
         L.spnet_dwconv3x3_stream_fwd(L.ptr(x), L.ptr(w), L.ptr(y), B, H, W, C, relu_in, scale_ptr, shift_ptr, 0, _stream())
     else:
         L.spnet_dwconv3x3_tiled_fwd(L.ptr(x), L.ptr(w), L.ptr(y), B, H, W, C, relu_in, scale_ptr, shift_ptr, _stream())
+
+
+def _dw_fwd_x3(x, w, zp, B, H, W, C, relu_in, scale_ptr, shift_ptr):
+    """_dw_fwd with the output written as bf16x3 planes"""
+    if L.spnet_dwconv3x3_prefers_stream(B, H, W, C, 0):
+        L.spnet_dwconv3x3_stream_fwd_x3(L.ptr(x), L.ptr(w), L.ptr(zp), B, H, W, C, relu_in, scale_ptr, shift_ptr, 0, _stream())
+    else:
+        L.spnet_dwconv3x3_tiled_fwd_x3(L.ptr(x), L.ptr(w), L.ptr(zp), B, H, W, C, relu_in, scale_ptr, shift_ptr, _stream())
 
 
 class _DwBwdPlan:
@@ -1516,9 +1643,15 @@ class SepConvBN:
         self.H, self.W = H, W
         self.M = B * H * W
         self.wd = eng.P(name + "/depthwise_kernel")
-        self.z = eng.new(B, H, W, cin)
         self.yp = eng.new(B, H, W, cout)
         self.pw = Pointwise(eng, self.M, cin, cout, name + "/pointwise_kernel", defer_wgrad=defer_wgrad)
+        # Planes mode (round 5): the depthwise kernel writes z, and the BatchNorm backward writes dy, as the bf16x3 planes the
+        # pointwise GEMMs read (csrc/x3t.h) -- all three of them then run on the bf16 matrix cores from LDS-DMA'd pieces
+        # and no fp32 z / dy exists.  Needs the forward AND (in a training plan) the data-gradient GEMM on the bf16x3 path;
+        # a layer with only one of them (cin < 256: blocks 2-3) keeps fp32 operands and the kernel that splits A itself.
+        self.x3p = eng.pointwise == "bf16x3" and self.pw.x3_fwd and (self.pw.x3_dgrad or not eng.train_capable)
+        self.z = None if self.x3p else eng.new(B, H, W, cin)
+        self.zp = eng.new_planes(self.M, cin) if self.x3p else None
         self.bn = BN(eng, cout, self.M, name + "_bn")
         self.y = eng.new(B, H, W, cout) if mode == "apply" else None
         self.dwb = _DwBwdPlan(B, H, W, cin)
@@ -1540,7 +1673,8 @@ class SepConvBN:
             # (units with an activation behind their BN take the unfused path and use dbn / the incoming buffer)
             self.blend = (act == ACT_NONE or mode != "apply") and self.pw.blend
             self.dyb = eng.new(B, H, W, cout) if self.blend else None
-            self.dbn = None if (bwd_inplace or self.blend) else eng.new(B, H, W, cout)
+            self.dbn = None if (bwd_inplace or self.blend or self.x3p) else eng.new(B, H, W, cout)
+            self.dyp = eng.new_planes(self.M, cout) if self.x3p else None
         if src.bn is not None and hasattr(src, "owner"):
             src.owner.consumer_rows = self.rows_src
             # the producer's training-forward BatchNorm finalize runs inside this unit's depthwise prologue
@@ -1561,18 +1695,20 @@ class SepConvBN:
             t0 = prof.start()
         owner = getattr(self.src, "owner", None)
         if training and owner is not None and owner.pending_rows:
-            L.spnet_dwconv3x3_tiled_fwd_bnfin(L.ptr(self.src.t), L.ptr(self.wd), L.ptr(self.z), e.B, self.H, self.W,
-                                              self.cin, self.relu_in, e.ws_ptr(WS_BNP), owner.pending_rows, sb.M,
-                                              L.ptr(sb.gamma), L.ptr(sb.beta), L.ptr(sb.mm), L.ptr(sb.mv), sb.mean_ptr,
-                                              sb.invstd_ptr, L.ptr(sb.ss), BN_EPS, BN_MOMENTUM, _stream())
+            bnfin = L.spnet_dwconv3x3_tiled_fwd_bnfin_x3 if self.x3p else L.spnet_dwconv3x3_tiled_fwd_bnfin
+            bnfin(L.ptr(self.src.t), L.ptr(self.wd), L.ptr(self.zp if self.x3p else self.z), e.B, self.H, self.W,
+                  self.cin, self.relu_in, e.ws_ptr(WS_BNP), owner.pending_rows, sb.M,
+                  L.ptr(sb.gamma), L.ptr(sb.beta), L.ptr(sb.mm), L.ptr(sb.mv), sb.mean_ptr,
+                  sb.invstd_ptr, L.ptr(sb.ss), BN_EPS, BN_MOMENTUM, _stream())
             owner.pending_rows = 0
         else:
-            _dw_fwd(self.src.t, self.wd, self.z, e.B, self.H, self.W, self.cin, self.relu_in,
-                    sb.scale_ptr if sb else None, sb.shift_ptr if sb else None)
+            (_dw_fwd_x3 if self.x3p else _dw_fwd)(self.src.t, self.wd, self.zp if self.x3p else self.z, e.B, self.H, self.W,
+                                                  self.cin, self.relu_in, sb.scale_ptr if sb else None,
+                                                  sb.shift_ptr if sb else None)
         if prof is not None:
             prof.stop("dw", t0, 2.0 * 4 * self.M * self.cin, ("dw fwd", self.H, self.W, self.cin))   # read x + write z
         if training:
-            rows = self.pw.fwd_colstats(self.z, self.yp)
+            rows = self.pw.fwd_p(self.zp, self.yp, WS_BNP) if self.x3p else self.pw.fwd_colstats(self.z, self.yp)
             if self.fin_by_consumer and rows <= 128:
                 self.pending_rows = rows            # the consumer's depthwise is the next launch on this stream
             elif self.mode == "apply":
@@ -1585,7 +1721,10 @@ class SepConvBN:
             else:
                 self.bn.finalize(rows)
         else:
-            self.pw.fwd(self.z, self.yp)
+            if self.x3p:
+                self.pw.fwd_p(self.zp, self.yp)
+            else:
+                self.pw.fwd(self.z, self.yp)
             self.bn.infer()
         if self.mode == "apply":
             self.bn.apply(self.yp, self.y, self.act, self.residual)
@@ -1601,6 +1740,12 @@ class SepConvBN:
             else:
                 self.bn.coeffs_full(self.yp, g)
             self.pw.bwd_blend(self.z, g, self.yp, self.bn, self.dyb, self.dz)
+        elif self.x3p:
+            if from_partials:
+                self.bn.bwd_from_partials_x3(self.yp, g, self.dyp, self.consumer_rows)
+            else:
+                self.bn.bwd_full_x3(self.yp, g, self.dyp, self.act if self.mode == "apply" else ACT_NONE)
+            self.pw.bwd_p(self.zp, self.dyp, self.dz)
         else:
             out = g if self.bwd_inplace else self.dbn
             if from_partials:

@@ -10,25 +10,23 @@ from spnet_amd.engine import Engine
 
 mode = sys.argv[1] if len(sys.argv) > 1 else "train"
 B = 32 if mode == "train" else 128
-eng = Engine(384, 512, B, device="cuda:0", seed=0, train=(mode == "train"))
+# (one engine per arithmetic: a bf16x3 plan keeps its GEMM operands as planes, the mode is fixed at construction;
+# x3_min_tiles=0: every eligible shape on the bf16x3 kernels, also those the product plan keeps exact)
+engs = {"f32": Engine(384, 512, B, device="cuda:0", seed=0, train=(mode == "train"), pointwise="f32"),
+        "bf16x3": Engine(384, 512, B, device="cuda:0", seed=0, train=(mode == "train"), x3_min_tiles=0)}
 X = torch.rand(B, 384, 512, 1, device="cuda") * 2 - 1
 Y = torch.rand(B, 576, device="cuda")
-eng.wgrad_stream = None
-
-
-def step():
-    if mode == "train":
-        eng.train_step(X, Y, 1e-6)
-    else:
-        eng.forward(X, training=False)
-
-
 res = {}
-for p_ in eng._pw_layers:            # (measure every shape on both kernels, also those the plan keeps exact)
-    p_.x3_fwd, p_.x3_dgrad = True, eng.train_capable
-eng._build_planes()
 for name, alt in (("exact", "f32"), ("x3", "bf16x3")):
-    eng.pointwise = alt
+    eng = engs[alt]
+    eng.wgrad_stream = None
+
+    def step():
+        if mode == "train":
+            eng.train_step(X, Y, 1e-6)
+        else:
+            eng.forward(X, training=False)
+
     for _ in range(3):
         step()
     torch.cuda.synchronize()
@@ -37,7 +35,7 @@ for name, alt in (("exact", "f32"), ("x3", "bf16x3")):
         if not (isinstance(tag, tuple) and len(tag) == 4):
             continue
         form = str(tag[0]).replace("x3 ", "")
-        if form not in ("aB", "aB+stats", "ab"):
+        if form not in ("aB", "aB+stats", "ab") and not form.startswith("AB"):
             continue
         res.setdefault((form,) + tuple(tag[1:]), {})[name] = (n / 8, 1e3 * ms / n)
 print("%-10s %8s %6s %6s | %5s | %9s %9s | %s" % ("form", "M", "N", "K", "n", "exact us", "x3 us", "x3/exact"))
