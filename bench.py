@@ -37,12 +37,14 @@ DW_FWD_BYTES_PER_IMAGE = 63.1e6
 # cores with every fp32 operand split exactly into three bf16 pieces (six bf16 MFMAs per product block, fp32 accumulate:
 # error against float64 no larger than the fp32 fmaf chain's, tests/test_kernels_gpu.py); all other GEMMs, the weight
 # gradients included, are fp32 MFMA chains.  `roofline_alt.train_step` carries the all-fp32-chain step beside it.
-DTYPE = "f32 (bf16x3 MFMA for pointwise fwd/dgrad GEMMs)"
-ARITHMETIC = ("fp32 tensors, accumulators and results; forward / data-gradient GEMMs of the pointwise convolutions with >= 256 "
-              "output columns: fp32 operands split exactly into three bf16 pieces, six bf16 MFMAs per product block, fp32 "
-              "accumulation (error vs float64 no larger than the fp32 fmaf chain's); weight gradients and every other GEMM: "
-              "fp32 MFMA chains; Engine(pointwise='f32') / cf.pointwise_gemm = 'f32' restores the chain everywhere "
-              "(roofline_alt.train_step times it in the same run)")
+DTYPE = "f32 (bf16x3 MFMA for pointwise fwd/dgrad/wgrad GEMMs)"
+ARITHMETIC = ("fp32 tensors, accumulators and results; the forward, data-gradient and weight-gradient GEMMs of the pointwise "
+              "convolutions with >= 256 input and output channels: fp32 operands split exactly into three bf16 pieces (by the "
+              "kernels that produce them), six bf16 MFMAs per product block, fp32 accumulation (error vs float64 no larger "
+              "than the fp32 fmaf chain's); every other GEMM: fp32 MFMA chains; Engine(pointwise='f32') / "
+              "cf.pointwise_gemm = 'f32' builds the all-chain plan (roofline_alt.train_step times it in the same run)")
+X3_PEAK_TFLOPS = BF16_MFMA_PEAK_TFLOPS / 6.0      # fp32-equivalent: six bf16 MFMAs per fp32 product block
+X3_REAL_OPERAND_TFLOPS = 1247.0 / 6.0             # MI355X_MICROARCH.md, DVFS give-back: its tuned bf16 GEMM on random operands
 
 # BASELINE.json's metric string, verbatim
 METRIC = "training images/sec on 512\u00d7384 fake-ESPI, Xception backbone, 1/2/4/8 GPU"
@@ -126,6 +128,199 @@ def time_families(eng, step, steps, sync, cushions=2):
         sync()
         agg.add(tp)
     return agg
+
+
+GEMM_KERNELS = (        # (kernel, tag prefix of Engine's KernelTimer, peak TFLOP/s, what it runs)
+    ("gemm_bf16x3_pp_kernel", "x3p ", X3_PEAK_TFLOPS, "pointwise forward (+ BatchNorm sums) and data gradient from bf16 planes"),
+    ("gemm_bf16x3_wgrad_kernel", "x3w ", X3_PEAK_TFLOPS, "pointwise weight gradients from the same planes (transposing LDS reads)"),
+    ("gemm_bf16x3_fwd_kernel", "x3 ", X3_PEAK_TFLOPS, "pointwise forward on an fp32 A operand split in the kernel (strided residual convolutions)"),
+    ("fp32 MFMA kernels (gemm_f32_kernel, conv3x3_*_kernel)", None, FP32_MFMA_PEAK_TFLOPS,
+     "entry-flow layers below 256 channels incl. the blended data gradients, block1_conv2, Dense head, their weight gradients"),
+)
+
+
+def gemm_family_by_kernel(tim, steps):
+    """The GEMM family of a KernelTimer / FamilyTimes reading split by kernel (tag prefix), each against ITS OWN peak:
+    {kernel: {launches_per_step, ms_per_step, achieved, peak, frac, ...}}, the dominant kernel's name, and the family's
+    time-weighted fraction sum_k(flops_k / peak_k) / sum_k(time_k)."""
+    tot_n, tot_ms, tot_fl = tim.totals()["gemm"]
+    rows, seen = {}, [0, 0.0, 0.0]
+    for kern, prefix, peak, what in GEMM_KERNELS:
+        if prefix is None:
+            n, ms, fl = tot_n - seen[0], tot_ms - seen[1], tot_fl - seen[2]
+        else:
+            sel = [v for t, v in tim.tagged().items() if isinstance(t, tuple) and str(t[0]).startswith(prefix)]
+            n, ms, fl = (sum(v[i] for v in sel) for i in range(3))
+            seen = [seen[0] + n, seen[1] + ms, seen[2] + fl]
+        if n <= 0:
+            continue
+        tf = fl / max(ms, 1e-9) / 1e9
+        rows[kern] = {"runs": what, "launches_per_step": n / steps, "ms_per_step": round(ms / steps, 3),
+                      "avg_launch_us": round(1e3 * ms / n, 2), "algorithmic_flops_per_launch": round(fl / n),
+                      "achieved": round(tf, 1), "peak": round(peak, 1), "unit": "TFLOP/s" + (" (fp32-equivalent)" if prefix else ""),
+                      "frac": round(tf / peak, 4)}
+    ideal_ms = sum(r["algorithmic_flops_per_launch"] * r["launches_per_step"] / (r["peak"] * 1e9) for r in rows.values())
+    fam_ms = sum(r["ms_per_step"] for r in rows.values())
+    dominant = max(rows, key=lambda k: rows[k]["ms_per_step"])
+    return rows, dominant, round(ideal_ms / max(fam_ms, 1e-9), 4), (tot_n, tot_ms, tot_fl)
+
+
+def gemm_roofline_block(tim, steps, traffic=None):
+    """`roofline` for a GEMM-dominated plan: the dominant KERNEL against its own peak (recomputable from the committed
+    rocprofv3 kernel stats: that kernel's calls x average duration), the family beside it."""
+    rows, dom, fam_frac, (g_n, g_ms, g_fl) = gemm_family_by_kernel(tim, steps)
+    d = rows[dom]
+    fam_tf = g_fl / max(g_ms, 1e-9) / 1e9
+    blk = {"kernel": "%s: %s" % (dom, d["runs"]), "bound": "mfma", "achieved": d["achieved"], "peak": d["peak"],
+           "unit": d["unit"], "frac": d["frac"], "traffic": traffic,
+           "algorithmic_flops_per_launch": d["algorithmic_flops_per_launch"], "avg_launch_us": d["avg_launch_us"],
+           "launches_per_step": d["launches_per_step"], "ms_per_step": d["ms_per_step"],
+           "peak_note": "dense bf16 MFMA peak 2500 TFLOP/s / 6 MFMAs per fp32 product block" if dom.startswith("gemm_bf16x3") else
+                        "fp32 MFMA peak (v_mfma_f32_*_f32 at the vector rate)",
+           "by_kernel": rows,
+           "family": {"kernels": list(rows), "launches_per_step": g_n / steps, "ms_per_step": round(g_ms / steps, 3),
+                      "frac_time_weighted": fam_frac,
+                      "frac_time_weighted_note": "sum over kernels of (algorithmic FLOPs / that kernel's own peak) / family time",
+                      "achieved_fp32_equivalent_tflops": round(fam_tf, 2),
+                      "frac_vs_fp32_peak_legacy": round(fam_tf / FP32_MFMA_PEAK_TFLOPS, 4),
+                      "legacy_note": "family FLOPs / family time / 157.3: the yardstick of rounds 1-4, kept only so that the "
+                                     "rounds compare -- most of these FLOPs run on the bf16 pipe, whose peak is 2.65x higher"}}
+    if dom.startswith("gemm_bf16x3"):
+        blk["frac_vs_real_operand_bf16_rate"] = round(d["achieved"] / X3_REAL_OPERAND_TFLOPS, 4)
+        blk["real_operand_note"] = ("MI355X_MICROARCH.md (DVFS give-back) quotes its own tuned bf16 GEMM at 1247 TFLOP/s on random "
+                                    "operands (1483 on zeros): / 6 = 207.8 fp32-equivalent is what the power limit leaves")
+    return blk
+
+
+FAMILY_OF = (("spnet_bn_", "bn"), ("spnet_maxpool", "pool"), ("spnet_avgpool", "pool"), ("spnet_gather_s2", "pool"),
+             ("spnet_scatter_add_s2", "pool"), ("spnet_stem_head", "stem"), ("spnet_conv3x3_small", "stem"),
+             ("spnet_dropout", "stem"), ("spnet_adam_step", "optimizer"), ("spnet_dwconv", "dw"), ("spnet_gemm", "gemm"),
+             ("spnet_conv3x3_", "gemm"), ("spnet_reduce_slabs", "gemm"), ("spnet_split_bf16x3", "gemm"),
+             ("spnet_transpose_batched", "gemm"), ("spnet_cutout", "augment"), ("spnet_saltpepper", "augment"),
+             ("spnet_minmax", "augment"), ("spnet_gather_rows", "augment"), ("spnet_ellipse_loss", "loss"))
+
+
+def algorithmic_bytes(name, a):
+    """HBM bytes an entry point has to move at the least -- every operand tensor read once, every result written once, in
+    the element sizes the plan really uses (fp32; 6 bytes per element for a bf16x3 planes output) -- or None where no
+    model is written down (those launches count in `unmodelled_ms_per_step`).  SURVEY.md section 8(d): BatchNorm, pooling,
+    the stem and the optimizer are HBM-bound; argument positions: include/spnet_hip.h."""
+    f4 = 4
+    if name in ("spnet_bn_bwd_from_partials", "spnet_bn_bwd", "spnet_bn_bwd_from_partials_x3", "spnet_bn_bwd_x3"):
+        return a[2] * a[3] * (2 * f4 + (6 if name.endswith("_x3") else f4))          # read x, dy; write dx
+    if name in ("spnet_bn_finalize_apply", "spnet_bn_finalize_apply_ld"):
+        return a[3] * a[4] * f4 * (2 + (1 if a[13] else 0))                            # read x (+ residual); write y
+    if name == "spnet_bn_apply":
+        return a[1] * a[2] * f4 * (2 + (1 if (a[5] and not a[6]) else 0))
+    if name in ("spnet_bn_fwd_train", "spnet_bn_fwd_train_ld"):
+        return a[1] * a[2] * f4 * (2 + (1 if (a[11] and not a[12]) else 0))
+    if name in ("spnet_bn_fwd_infer", "spnet_bn_fwd_infer_ld"):
+        return a[1] * a[2] * f4 * (2 + (1 if (a[9] and not a[10]) else 0))
+    if name == "spnet_bn_finalize_fwd":
+        return a[1] * 2 * a[3] * f4
+    if name == "spnet_bn_bwd_coeffs_from_partials":
+        return a[0] * 2 * a[3] * f4
+    if name == "spnet_bn_bwd_coeffs":
+        return a[2] * a[3] * 2 * f4
+    if name == "spnet_bn_infer_coeffs":
+        return a[0] * 6 * f4
+    if name == "spnet_maxpool3x3s2_add_fwd":
+        B, Hh, Ww, C = a[4:8]
+        o = B * ((Hh + 1) // 2) * ((Ww + 1) // 2) * C
+        return f4 * (B * Hh * Ww * C + 2 * o) + (o if a[3] else 0)                    # x; residual + y; byte argmax per 4 channels x 4
+    if name in ("spnet_maxpool3x3s2_bwd", "spnet_maxpool3x3s2_bwd_bnsums"):
+        B, Hh, Ww, C = a[3:7]
+        o = B * ((Hh + 1) // 2) * ((Ww + 1) // 2) * C
+        return f4 * (o + B * Hh * Ww * C * (2 if name.endswith("bnsums") else 1)) + o  # g, idx; write dx (+ read yp)
+    if name in ("spnet_gather_s2", "spnet_scatter_add_s2"):
+        B, Hh, Ww, C = a[2:6]
+        o = B * ((Hh + 1) // 2) * ((Ww + 1) // 2) * C
+        return f4 * o * (2 if name == "spnet_gather_s2" else 3)
+    if name == "spnet_adam_step":
+        return 28 * a[4]                                                                # w, g, m, v read; w, m, v written
+    if name == "spnet_dropout":
+        return 2 * f4 * a[2]
+    if name == "spnet_conv3x3_small":
+        op, cin, cout, stride, same = a[0:5]
+        B, Hh, Ww = a[8:11]
+        oh = (Hh + stride - 1) // stride if same else (Hh - 3) // stride + 1
+        ow = (Ww + stride - 1) // stride if same else (Ww - 3) // stride + 1
+        return f4 * (B * Hh * Ww * cin + B * oh * ow * cout)
+    if name == "spnet_stem_head":
+        B, Hh, Ww = a[5:8]
+        return f4 * (B * Hh * Ww + B * (Hh // 2) * (Ww // 2) * (4 if a[0] == 0 else 3))
+    return None
+
+
+def time_entry_points(eng, step, steps, sync, cushions=2):
+    """HIP events around EVERY launching entry point of the C ABI during `steps` steps (spnet_amd._lib.set_tracer), one
+    stream: {entry: [calls, ms, algorithmic bytes | None]}.  Same discipline as time_families: every timed step is
+    enqueued behind untimed ones, its events are read and dropped before the next."""
+    import torch
+    from spnet_amd import _lib as L
+    acc = {}
+    for _ in range(steps):
+        for _ in range(cushions):
+            step()
+        rec = []
+
+        def tracer(name, args, tok):
+            if tok is None:
+                e0 = torch.cuda.Event(enable_timing=True)
+                e0.record()
+                return e0
+            e1 = torch.cuda.Event(enable_timing=True)
+            e1.record()
+            rec.append((name, args, tok, e1))
+
+        L.set_tracer(tracer)
+        try:
+            step()
+        finally:
+            L.set_tracer(None)
+        sync()
+        for name, args, e0, e1 in rec:
+            b = algorithmic_bytes(name, args)
+            a = acc.setdefault(name, [0, 0.0, 0.0, 0])
+            a[0] += 1
+            a[1] += e0.elapsed_time(e1)
+            if b is None:
+                a[3] += 1
+            else:
+                a[2] += b
+    return acc
+
+
+def other_family_rooflines(acc, steps, skip=("gemm", "dw")):
+    """`roofline_other`: the HBM-bound families that are neither GEMMs nor depthwise layers (BatchNorm passes, pooling, the
+    stem, the optimizer, augmentation, loss), algorithmic bytes / HIP-event time against the 8 TB/s peak."""
+    fams = {}
+    for name, (n, ms, by, unm) in acc.items():
+        fam = next((f for pre, f in FAMILY_OF if name.startswith(pre)), "other")
+        if fam in skip:
+            continue
+        d = fams.setdefault(fam, {"n": 0, "ms": 0.0, "bytes": 0.0, "unmodelled_ms": 0.0, "entries": {}})
+        d["n"] += n
+        d["ms"] += ms
+        if unm:
+            d["unmodelled_ms"] += ms
+        else:
+            d["bytes"] += by
+        d["entries"][name] = [n, ms, by, unm]
+    out = {}
+    for fam, d in sorted(fams.items(), key=lambda kv: -kv[1]["ms"]):
+        mod_ms = d["ms"] - d["unmodelled_ms"]
+        gbs = d["bytes"] / max(mod_ms, 1e-9) / 1e6 if mod_ms > 0 else None
+        top = sorted(d["entries"].items(), key=lambda kv: -kv[1][1])[:4]
+        out[fam] = {"bound": "hbm", "launching_calls_per_step": d["n"] / steps, "ms_per_step": round(d["ms"] / steps, 3),
+                    "algorithmic_bytes_per_step": round(d["bytes"] / steps),
+                    "achieved": None if gbs is None else round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": None if gbs is None else round(gbs / HBM_PEAK_GBS, 4),
+                    "unmodelled_ms_per_step": round(d["unmodelled_ms"] / steps, 3),
+                    "largest_entries": {k: {"calls_per_step": v[0] / steps, "ms_per_step": round(v[1] / steps, 3),
+                                            "achieved_gbs": None if v[3] or v[1] <= 0 else round(v[2] / v[1] / 1e6, 1)}
+                                        for k, v in top}}
+    return out
 
 
 def labels_to_Y(label_rows):
@@ -257,17 +452,11 @@ def secondary(args):
            "data": "synthetic (uniform noise)",
            "config": {"workload": "%s, %s, %dx%d frames, batch %d" % (args.mode, args.backbone, w, h, b)}}
     if not args.no_kernel_timers:       # the GEMM family of this configuration against the fp32 MFMA peak (HIP events)
-        tot = time_families(eng, step, args.steps, torch.cuda.synchronize).totals()
-        if "gemm" in tot:
-            g_n, g_ms, g_flop = tot["gemm"]
-            tf = g_flop / (g_ms * 1e-3) / 1e12
-            out["roofline"] = {"kernel": "fp32 MFMA GEMM family (every convolution / dense layer of this configuration)",
-                               "bound": "mfma", "achieved": round(tf, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                               "frac": round(tf / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
-                               "launches_per_step": g_n / args.steps, "ms_per_step": round(g_ms / args.steps, 3),
-                               "algorithmic_flops_per_step": round(g_flop / args.steps),
-                               "measured": "HIP events around every GEMM launch during %d extra steps, each enqueued behind two untimed "
-                                           "steps (no host gap inside an event pair)" % args.steps}
+        tim = time_families(eng, step, args.steps, torch.cuda.synchronize)
+        if "gemm" in tim.totals():
+            out["roofline"] = dict(gemm_roofline_block(tim, args.steps),
+                                   measured="HIP events around every GEMM launch during %d extra steps, each enqueued behind two "
+                                            "untimed steps (no host gap inside an event pair)" % args.steps)
     print(json.dumps(out))
 
 
@@ -301,11 +490,11 @@ def predict_measure(X_pool, dev, steps, warmup, host_frames=1024):
 
     dt = timed(steps, True)
     dt_eager = timed(steps, False)
-    tot = time_families(eng, lambda: step(False), steps, torch.cuda.synchronize).totals()
-    g_n, g_ms, g_flop = tot["gemm"]
+    tim = time_families(eng, lambda: step(False), steps, torch.cuda.synchronize)
+    tot = tim.totals()
     d_n, d_ms, _ = tot["dw"]
     n_prof = steps
-    gemm_tflops = g_flop / (g_ms * 1e-3) / 1e12
+    roof = gemm_roofline_block(tim, n_prof)
     dw_gbs = DW_FWD_BYTES_PER_IMAGE * PB * n_prof / (d_ms * 1e-3) / 1e9
     del eng
     # PCIe-inclusive: model.predict over host frames, as predict_spnet.py calls it
@@ -334,10 +523,7 @@ def predict_measure(X_pool, dev, steps, warmup, host_frames=1024):
         "host_streamed_u8_frames_per_sec": host_u8,
         "host_frames_note": "Model.predict over %d host frames: pageable -> pinned ring -> HBM on a copy stream, "
                             "overlapped with the forward passes (PCIe-inclusive; not `value`)" % nh,
-        "roofline": {"kernel": "fp32 MFMA GEMM family, forward form (pointwise / residual / Dense + conv3x3_fwd_kernel)",
-                     "bound": "mfma", "achieved": round(gemm_tflops, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                     "frac": round(gemm_tflops / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
-                     "launches_per_step": g_n / n_prof, "ms_per_step": round(g_ms / n_prof, 3), "measured": note},
+        "roofline": dict(roof, measured=note),
         "roofline_secondary": {"kernel": "dw3x3_stream_fwd_kernel (34 depthwise layers, forward)", "bound": "hbm",
                                "achieved": round(dw_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                "frac": round(dw_gbs / HBM_PEAK_GBS, 4), "traffic": None,
@@ -439,17 +625,11 @@ def backbone_leg(dev, backbone, batch, steps=20, warmup=5, predict=False):
            "train_images_per_sec": round(batch * steps / dt, 1), "ms_per_step": round(1e3 * dt / steps, 3), "steps": steps,
            "batch": batch, "repeats_ms_per_step": [round(1e3 * t / steps, 3) for t in dts],
            "timing": "best of 3 repeats of %d steps (a secondary leg; the headline `value` is one timed region)" % steps}
-    tot = time_families(eng, step, max(5, steps // 2), torch.cuda.synchronize).totals()
     n_prof = max(5, steps // 2)
-    if "gemm" in tot:
-        g_n, g_ms, g_flop = tot["gemm"]
-        tf = g_flop / (g_ms * 1e-3) / 1e12
-        out["roofline"] = {"kernel": "fp32 MFMA GEMM family (every convolution / dense layer of this backbone)",
-                           "bound": "mfma", "achieved": round(tf, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                           "frac": round(tf / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
-                           "launches_per_step": g_n / n_prof, "ms_per_step": round(g_ms / n_prof, 3),
-                           "algorithmic_flops_per_step": round(g_flop / n_prof),
-                           "measured": "HIP events around every GEMM launch during %d extra steps, each behind two untimed ones" % n_prof}
+    tim = time_families(eng, step, n_prof, torch.cuda.synchronize)
+    if "gemm" in tim.totals():
+        out["roofline"] = dict(gemm_roofline_block(tim, n_prof),
+                               measured="HIP events around every GEMM launch during %d extra steps, each behind two untimed ones" % n_prof)
     del eng
     torch.cuda.empty_cache()
     if predict:
@@ -469,51 +649,70 @@ def backbone_leg(dev, backbone, batch, steps=20, warmup=5, predict=False):
 
 
 def bf16x3_alt_measure(dev, iters=200):
-    """`roofline_alt`: the bf16x3 kernel (csrc/gemm_bf16x3.hip: six bf16 MFMAs with fp32 accumulation per product block;
-    the product path of the pointwise forward / data-gradient GEMMs since round 4) beside the exact fp32 MFMA kernel on the
-    network's dominant forward shape, the Xception middle-flow pointwise GEMM at batch 32 (6144 x 728 x 728), isolated.  Error of both kernels against float64 (torch.float64 on the device), relative
-    to |a_row| * |w_col|."""
+    """`roofline_alt`: the bf16x3 kernels (csrc/gemm_bf16x3.hip: six bf16 MFMAs with fp32 accumulation per product block,
+    operands as bf16 planes in 1-KiB pieces) beside the exact fp32 MFMA kernel on the network's dominant shape, the Xception
+    middle-flow pointwise layer at batch 32 (6144 pixels x 728 x 728), isolated, operands rotating over four buffers: the
+    planes x planes kernel (forward / data gradient), round 4's kernel (fp32 A split while staged), the weight gradient from
+    planes.  Error of the forward kernels against float64 (torch.float64 on the device), relative to |a_row| * |w_col|."""
     import torch
     from spnet_amd import _lib as L
     M, N, K = 6144, 728, 728
     g = torch.Generator(device=dev)
     g.manual_seed(3)
-    a = torch.randn(M, K, device=dev, generator=g)
+    nb = 4
+    a = [torch.randn(M, K, device=dev, generator=g) for _ in range(nb)]
+    gy = torch.randn(M, N, device=dev, generator=g) * 0.1
     w = torch.randn(K, N, device=dev, generator=g) * 0.05
-    Kp = int(L.spnet_bf16x3_kp(K))
-    planes = torch.zeros(3 * int(L.spnet_bf16x3_plane_elems(N, K)), dtype=torch.int16, device=dev)
-    c3, c1 = torch.empty(M, N, device=dev), torch.empty(M, N, device=dev)
+    pe = lambda r, k: 3 * int(L.spnet_bf16x3_plane_elems(r, k))
+    planes = torch.zeros(pe(N, K), dtype=torch.int16, device=dev)
+    apl = [torch.zeros(pe(M, K), dtype=torch.int16, device=dev) for _ in range(nb)]
+    gpl = torch.zeros(pe(M, N), dtype=torch.int16, device=dev)
+    c3, c1, cp = (torch.empty(M, N, device=dev) for _ in range(3))
+    NW = 8                    # weight gradients per launch here (the step batches the middle flow's 24)
+    dw = torch.empty(NW, K, N, device=dev)
     st = torch.cuda.current_stream().cuda_stream
-    split = lambda: L.spnet_split_bf16x3(w.data_ptr(), planes.data_ptr(), K, N, st)
-    f3 = lambda: L.spnet_gemm_bf16x3_fwd(a.data_ptr(), K, planes.data_ptr(), c3.data_ptr(), N, M, N, K, st)
-    f1 = lambda: L.spnet_gemm_f32(a.data_ptr(), 0, K, w.data_ptr(), 1, N, c1.data_ptr(), N, M, N, K, 1, None, 0, None, 0, st)
+    split = lambda i=0: L.spnet_split_bf16x3(w.data_ptr(), planes.data_ptr(), K, N, st)
+    for i in range(nb):
+        L.spnet_split_rows_bf16x3(a[i].data_ptr(), K, apl[i].data_ptr(), M, K, st)
+    L.spnet_split_rows_bf16x3(gy.data_ptr(), N, gpl.data_ptr(), M, N, st)
+    jobs = torch.tensor([v for b in range(NW) for v in (apl[b % nb].data_ptr(), gpl.data_ptr(), dw[b].data_ptr())],
+                        dtype=torch.int64, device=dev)
+    fp = lambda i: L.spnet_gemm_bf16x3_pp(apl[i % nb].data_ptr(), planes.data_ptr(), cp.data_ptr(), N, M, N, K, None, None, st)
+    f3 = lambda i: L.spnet_gemm_bf16x3_fwd(a[i % nb].data_ptr(), K, planes.data_ptr(), c3.data_ptr(), N, M, N, K, st)
+    f1 = lambda i: L.spnet_gemm_f32(a[i % nb].data_ptr(), 0, K, w.data_ptr(), 1, N, c1.data_ptr(), N, M, N, K, 1, None, 0, None, 0, st)
+    fw = lambda i: L.spnet_gemm_bf16x3_wgrad_batched(jobs.data_ptr(), NW, K, N, M, 1, st)
 
     def t(fn):
-        for _ in range(10):
-            fn()
+        for i in range(10):
+            fn(i)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        for _ in range(iters):
-            fn()
+        for i in range(iters):
+            fn(i)
         e1.record()
         torch.cuda.synchronize()
         return e0.elapsed_time(e1) * 1e3 / iters
 
     split()
-    t3, t1, ts = t(f3), t(f1), t(split)
-    ref = a.double() @ w.double()
-    scale = a.double().norm(dim=1)[:, None] * w.double().norm(dim=0)[None, :]
-    e3, e1 = (c3.double() - ref).abs() / scale, (c1.double() - ref).abs() / scale
+    tp, t3, t1, ts, tw = t(fp), t(f3), t(f1), t(split), t(fw)
+    fp(0); f3(0); f1(0)
+    ref = a[0].double() @ w.double()
+    scale = a[0].double().norm(dim=1)[:, None] * w.double().norm(dim=0)[None, :]
+    ep, e1 = (cp.double() - ref).abs() / scale, (c1.double() - ref).abs() / scale
+    same = bool(torch.equal(cp, c3))
     fl = 2.0 * M * N * K
-    peak = BF16_MFMA_PEAK_TFLOPS / 6.0
-    return {"kernel": "gemm_bf16x3_fwd_kernel, isolated on the dominant shape: fp32 operands as 3 bf16 pieces, 6 bf16 MFMAs "
-                      "per product block, fp32 accumulate", "shape": {"M": M, "N": N, "K": K}, "bound": "mfma",
-            "achieved": round(fl / t3 / 1e6, 1), "peak": round(peak, 1), "unit": "TFLOP/s (fp32-equivalent)",
-            "frac": round(fl / t3 / 1e6 / peak, 4),
+    return {"kernel": "gemm_bf16x3_pp_kernel, isolated on the dominant shape: both operands as bf16x3 planes (1-KiB pieces, "
+                      "LDS-DMA), 6 bf16 MFMAs per product block, fp32 accumulate", "shape": {"M": M, "N": N, "K": K}, "bound": "mfma",
+            "achieved": round(fl / tp / 1e6, 1), "peak": round(X3_PEAK_TFLOPS, 1), "unit": "TFLOP/s (fp32-equivalent)",
+            "frac": round(fl / tp / 1e6 / X3_PEAK_TFLOPS, 4),
+            "frac_vs_real_operand_bf16_rate": round(fl / tp / 1e6 / X3_REAL_OPERAND_TFLOPS, 4),
             "peak_note": "dense bf16 MFMA peak %.0f TFLOP/s / 6 MFMAs per product block" % BF16_MFMA_PEAK_TFLOPS,
-            "avg_launch_us": round(t3, 1), "exact_fp32_kernel_us": round(t1, 1), "speedup_vs_exact": round(t1 / t3, 3),
+            "avg_launch_us": round(tp, 1), "fp32_a_split_in_kernel_us": round(t3, 1), "exact_fp32_kernel_us": round(t1, 1),
+            "speedup_vs_exact": round(t1 / tp, 3), "bit_identical_to_fp32_a_kernel": same,
+            "wgrad_from_planes_us": round(tw / NW, 1), "wgrad_tflops_fp32_equivalent": round(NW * fl / tw / 1e6, 1),
+            "wgrad_note": "per layer, %d layers of this shape per launch (gemm_bf16x3_wgrad_kernel)" % NW,
             "weight_split_us": round(ts, 1),
-            "max_rel_err_vs_f64": float("%.3g" % e3.max().item()), "rms_rel_err_vs_f64": float("%.3g" % e3.pow(2).mean().sqrt().item()),
+            "max_rel_err_vs_f64": float("%.3g" % ep.max().item()), "rms_rel_err_vs_f64": float("%.3g" % ep.pow(2).mean().sqrt().item()),
             "exact_max_rel_err_vs_f64": float("%.3g" % e1.max().item()),
             "exact_rms_rel_err_vs_f64": float("%.3g" % e1.pow(2).mean().sqrt().item()),
             "iters": iters}
@@ -826,12 +1025,13 @@ def run(args):
 
     # Roofline leg: the same K steps replayed with every kernel on ONE stream (no weight-gradient overlap),
     # so that a kernel's HIP-event duration is its own and not that of two kernels sharing the chip.
-    timer = None
+    timer = entry_times = None
     if not args.no_kernel_timers:
         eng.wgrad_stream = None
         step()
         fence()
         timer = time_families(eng, step, args.steps, fence)
+        entry_times = time_entry_points(eng, step, args.steps, fence)      # (every rank: a step contains the collectives)
         eng.wgrad_stream = None if args.no_overlap else side_stream
 
     result = None
@@ -872,40 +1072,15 @@ def run(args):
                             (tr["dw_fwd"]["launches"] + tr["dw_bwd"]["launches"])
             g_n, g_ms, g_flop = tot["gemm"]
             d_n, d_ms, d_bytes = tot["dw"]
-            gemm_tflops = g_flop / (g_ms * 1e-3) / 1e12
             dw_gbs = DW_TRAIN_BYTES_PER_IMAGE * BATCH * args.steps / (d_ms * 1e-3) / 1e9
-            # the family by arithmetic: launches of gemm_bf16x3_fwd_kernel (tags "x3 ...") and the fp32 MFMA kernels
-            x3 = [v for t, v in timer.tagged().items() if isinstance(t, tuple) and str(t[0]).startswith("x3")]
-            x3_n, x3_ms, x3_fl = (sum(v[i] for v in x3) for i in range(3))
-            by_kernel = {
-                "gemm_bf16x3_fwd_kernel (pointwise forward + data gradient, >= 256 output columns)": {
-                    "launches_per_step": x3_n / args.steps, "ms_per_step": round(x3_ms / args.steps, 3),
-                    "achieved_fp32_equivalent_tflops": round(x3_fl / max(x3_ms, 1e-9) / 1e9, 1),
-                    "peak_fp32_equivalent_tflops": round(BF16_MFMA_PEAK_TFLOPS / 6.0, 1),
-                    "frac_of_own_peak": round(x3_fl / max(x3_ms, 1e-9) / 1e9 / (BF16_MFMA_PEAK_TFLOPS / 6.0), 4),
-                    "note": "six bf16 MFMAs per fp32 product block: dense bf16 MFMA peak / 6; no unit of the CU is "
-                            "saturated (SQ counters, profiles/r04_k_bf16x3_pmc_table.txt: matrix pipe busy 53 % of a "
-                            "wave's life at two waves per SIMD, 49 % of it issue stalls, 20 % at barriers / waitcnt, LDS "
-                            "29 % busy without bank conflicts); on all-zero operands the same launch takes 36 instead of "
-                            "46-48 us: a quarter of its time is clock given up to the power limit "
-                            "(profiles/r04_k_diag_bf16x3_power_probe.txt), DESIGN.md section 3"},
-                "fp32 MFMA kernels (weight gradients, blended data gradients, block1_conv2, Dense, narrow layers)": {
-                    "launches_per_step": (g_n - x3_n) / args.steps, "ms_per_step": round((g_ms - x3_ms) / args.steps, 3),
-                    "achieved_tflops": round((g_flop - x3_fl) / max(g_ms - x3_ms, 1e-9) / 1e9, 1),
-                    "peak_tflops": FP32_MFMA_PEAK_TFLOPS,
-                    "frac": round((g_flop - x3_fl) / max(g_ms - x3_ms, 1e-9) / 1e9 / FP32_MFMA_PEAK_TFLOPS, 4)}}
-            roof_gemm = {"kernel": "GEMM family: gemm_f32_kernel (fp32 MFMA: weight gradients incl. the batched middle-flow dW "
-                                   "launch and split-K slab reduce, blended data gradients, residual / Dense) + "
-                                   "conv3x3_{fwd,dgrad,wgrad}_kernel (block1_conv2 implicit GEMMs) + gemm_bf16x3_fwd_kernel "
-                                   "(pointwise forward / data gradient).  `achieved` = algorithmic fp32 FLOPs of the family / its "
-                                   "time; `peak` = the fp32 MFMA peak, the yardstick of rounds 1-3 (by_kernel: each kernel "
-                                   "against its own)",
-                         "bound": "mfma", "achieved": round(gemm_tflops, 2), "peak": FP32_MFMA_PEAK_TFLOPS,
-                         "unit": "TFLOP/s", "frac": round(gemm_tflops / FP32_MFMA_PEAK_TFLOPS, 4),
-                         "traffic": None if g_traffic is None else round(g_traffic),
-                         "algorithmic_flops_per_launch": round(g_flop / g_n),
-                         "avg_launch_us": round(1e3 * g_ms / g_n, 2), "launches_per_step": g_n / args.steps,
-                         "ms_per_step": round(g_ms / args.steps, 3), "by_kernel": by_kernel}
+            # the dominant kernel of the step against its own peak; the GEMM family (every kernel against its own) beside it
+            roof_gemm = gemm_roofline_block(timer, args.steps)
+            dom = roof_gemm["kernel"].split(":")[0]
+            if dom in tr and roof_gemm["launches_per_step"] > 0:      # PMC bytes of that kernel per launch
+                roof_gemm["traffic"] = round((tr[dom]["hbm_read_bytes_per_step"] + tr[dom]["hbm_write_bytes_per_step"]) /
+                                             roof_gemm["launches_per_step"])
+            if "gemm" in tr:
+                roof_gemm["family"]["traffic_per_launch"] = round(g_traffic)
             roof_dw = {"kernel": "dw3x3_{stream,tile}_fwd_kernel + dw3x3_{stream,tile}_bwd_kernel (34 depthwise layers, fwd + fused bwd: streaming form on the entry-flow planes, LDS-tiled form with the folded BatchNorm finalize on the 12x16 / 6x8 planes)",
                        "bound": "hbm", "achieved": round(dw_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                        "frac": round(dw_gbs / HBM_PEAK_GBS, 4),
@@ -933,13 +1108,17 @@ def run(args):
                     "(weight-gradient overlap off) right after the timed region, each enqueued behind one untimed step so "
                     "that no event pair contains a host gap" % args.steps)
             roof_gemm["measured"] = roof_dw["measured"] = note
-            roof_gemm["clock_note"] = ("peak = 157.3 TFLOP/s at the 2.4 GHz maximum clock; inside this family's main loop the chip "
-                                       "holds 2.04-2.12 GHz on real operands (2.30-2.41 GHz on zeros), measured with in-kernel "
-                                       "s_memtime / s_memrealtime stamps: profiles/r02_c_diag_gemm_phases.txt, DESIGN.md section 3")
+            roof_gemm["clock_note"] = ("peaks are at the 2.4 GHz maximum clock; under this family's load the chip holds 1.7-2.1 GHz "
+                                       "on real operands (2.3-2.4 GHz on zeros): profiles/r02_c_diag_gemm_phases.txt, "
+                                       "profiles/r04_k_diag_bf16x3_power_probe.txt, profiles/r05_x3pp_knockouts.txt")
             roof_gemm["traffic_source"] = roof_dw["traffic_source"] = tr_note
             result["roofline"] = roof_gemm if g_ms >= d_ms else roof_dw
             result["roofline_secondary"] = roof_dw if g_ms >= d_ms else roof_gemm
             result["kernel_families"] = fam
+            if entry_times is not None:
+                result["roofline_other"] = other_family_rooflines(entry_times, args.steps)
+                result["roofline_other"]["measured"] = ("HIP events around every launching entry point of the C ABI (spnet_amd._lib.set_tracer) "
+                                                        "during %d further steps on one stream; bytes: bench.algorithmic_bytes" % args.steps)
         if world == 1 and not args.no_secondary:
             # the secondary configurations, in the same driver-witnessed line (N = 1 only; ~10 s): BASELINE configs[4]
             # (predict_spnet.py:84-87's FPS) on the resident pool, and the reference's own 331x331 layout

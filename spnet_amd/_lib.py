@@ -138,6 +138,16 @@ class HipError(RuntimeError):
     pass
 
 
+# Measurement hook (bench.py's per-family rooflines): while set, every launching entry point calls
+# tracer(name, args, None) -> token before and tracer(name, args, token) after it has enqueued its kernels.  None (the
+# default, and the only state outside a measurement pass): one list lookup per call.
+_TRACER = [None]
+
+
+def set_tracer(tracer):
+    _TRACER[0] = tracer
+
+
 def _bind(name, restype, argtypes):
     fn = getattr(_lib, name)      # AttributeError here = the library does not export the symbol
     fn.restype = restype
@@ -146,7 +156,13 @@ def _bind(name, restype, argtypes):
         return fn
 
     def checked(*args):
-        rc = fn(*args)
+        tr = _TRACER[0]
+        if tr is None:
+            rc = fn(*args)
+        else:
+            tok = tr(name, args, None)
+            rc = fn(*args)
+            tr(name, args, tok)
         if rc != 0:
             raise HipError("%s failed with hipError_t %d" % (name, rc))
     checked.__name__ = name

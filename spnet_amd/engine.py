@@ -908,7 +908,7 @@ class Engine:
                 for b, t in enumerate(todo):
                     L.spnet_reduce_slabs(ws + 4 * b * ks * cin * cout, ks, cin, cout, t[3].data_ptr(), cout, _stream())
             if prof is not None:
-                prof.stop("gemm", t0, 2.0 * nb * cin * cout * M, ("x3 AB x%d batched" % nb, cin, cout, M))
+                prof.stop("gemm", t0, 2.0 * nb * cin * cout * M, ("x3w AB x%d batched" % nb, cin, cout, M))
 
         if side is None:
             launch()
@@ -1344,7 +1344,7 @@ class Pointwise:
     def fwd_p(self, zp, y, colstats_region=None):
         """Forward from the planes of x (written by the producing depthwise kernel); with colstats_region the BatchNorm
         column sums of y are left there and the partial row count is returned."""
-        tag = "x3 aB" if colstats_region is None else "x3 aB+stats"
+        tag = "x3p aB" if colstats_region is None else "x3p aB+stats"
         return self._x3p(tag, zp, self.e._planes[self.wname][0], y, self.cout, self.cin, colstats_region)
 
     def bwd_p(self, zp, dyp, dx):
@@ -1356,7 +1356,7 @@ class Pointwise:
         else:
             e._flush_x3_wgrads([("x3", zp, dyp, self.gw, self.cin, self.cout, self.M)])
         if dx is not None:
-            self._x3p("x3 ab", dyp, e._planes[self.wname][1], dx, self.cin, self.cout)
+            self._x3p("x3p ab", dyp, e._planes[self.wname][1], dx, self.cin, self.cout)
 
     def fwd(self, x, y):
         if self.x3_fwd and self.e.pointwise == "bf16x3":

@@ -134,16 +134,33 @@ def test_bench_default_line_carries_every_block():
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]
     out = json.loads(lines[0])
-    for key in ("roofline", "roofline_secondary", "roofline_alt", "cpu_baseline", "predict", "layout_331", "kernel_families",
-                "irv2", "mobilenet"):
+    for key in ("roofline", "roofline_secondary", "roofline_other", "roofline_alt", "cpu_baseline", "predict", "layout_331",
+                "kernel_families", "irv2", "mobilenet"):
         assert key in out, key
     assert out["n_gpus"] == 1 and out["dtype"].startswith("f32 (") and "bf16x3" in out["dtype"] and out["value"] > 0
     assert "fp32 MFMA" in out["config"]["arithmetic"]
-    bk = out["roofline"]["by_kernel"]
-    assert len(bk) == 2 and all(v["launches_per_step"] > 0 and v["ms_per_step"] > 0 for v in bk.values())
+    # `roofline` = the dominant KERNEL against its own peak (the planes x planes bf16x3 GEMM: bf16 MFMA peak / 6), every
+    # GEMM kernel against its own beside it, the family's time-weighted fraction, the old fp32-peak figure only as legacy
+    roof = out["roofline"]
+    bk = roof["by_kernel"]
+    assert roof["kernel"].startswith("gemm_bf16x3_pp_kernel") and abs(roof["peak"] - 416.7) < 0.1 and 0 < roof["frac"] < 1
+    assert abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-3
+    assert {"gemm_bf16x3_pp_kernel", "gemm_bf16x3_wgrad_kernel"} <= set(bk) and len(bk) >= 3
+    assert all(v["launches_per_step"] > 0 and v["ms_per_step"] > 0 and 0 < v["frac"] < 1 for v in bk.values())
+    fam = roof["family"]
+    assert 0 < fam["frac_time_weighted"] < 1 and "frac_vs_fp32_peak_legacy" in fam
+    assert abs(fam["ms_per_step"] - sum(v["ms_per_step"] for v in bk.values())) < 0.01
+    assert out["predict"]["roofline"]["kernel"].startswith("gemm_bf16x3_pp_kernel") and out["predict"]["roofline"]["peak"] > 400
+    # the rest of the step: BatchNorm passes, pooling, the stem and the optimizer against the HBM peak
+    other = out["roofline_other"]
+    for famname in ("bn", "pool", "stem", "optimizer"):
+        assert other[famname]["ms_per_step"] > 0 and 0 < other[famname]["frac"] < 1, famname
+    # 28 bytes per trainable parameter (77,485,385 - 54,546 BatchNorm moving statistics, + alignment padding of the flat buffer)
+    assert abs(other["optimizer"]["algorithmic_bytes_per_step"] / (28 * 77430839.0) - 1) < 1e-3
     ts = out["roofline_alt"]["train_step"]
     assert ts["exact_fp32"]["bf16x3_launches_per_step"] == 0 and ts["bf16x3"]["bf16x3_launches_per_step"] > 40
     assert set(out["roofline_secondary"].get("sub_families", out["roofline"].get("sub_families", {}))) >= {"entry", "middle", "exit"}
     alt = out["roofline_alt"]
     assert alt["max_rel_err_vs_f64"] < 5e-7 and alt["avg_launch_us"] > 0 and 0 < alt["frac"] < 1
+    assert alt["bit_identical_to_fp32_a_kernel"] and alt["wgrad_from_planes_us"] > 0
     assert out["cpu_baseline"]["kind"] in ("port", "reference") and out["cpu_baseline"]["value"] > 0

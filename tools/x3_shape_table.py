@@ -34,7 +34,7 @@ for name, alt in (("exact", "f32"), ("x3", "bf16x3")):
     for tag, (n, ms, w) in tg.items():
         if not (isinstance(tag, tuple) and len(tag) == 4):
             continue
-        form = str(tag[0]).replace("x3 ", "")
+        form = str(tag[0]).replace("x3p ", "").replace("x3w ", "").replace("x3 ", "")
         if form not in ("aB", "aB+stats", "ab") and not form.startswith("AB"):
             continue
         res.setdefault((form,) + tuple(tag[1:]), {})[name] = (n / 8, 1e3 * ms / n)
