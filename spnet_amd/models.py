@@ -402,6 +402,8 @@ class Model:
             the same frames give the same predictions whatever container they arrive in"""
             n = hi - lo
             if frames.dtype == torch.uint8:
+                if frames.data_ptr() & 15:          # a slice of a resident uint8 tensor whose frame size is not a multiple of
+                    frames = frames.clone()         # 16 bytes (331 x 331): the kernel wants 16-byte aligned bytes
                 L.spnet_u8_to_input(frames.data_ptr(), eng.x_in.data_ptr(), n * self.H * self.W, L.current_stream())
                 if n < bs:                           # ragged tail: pad with the last frame, drop the extras
                     eng.x_in[n:].copy_(eng.x_in[n - 1:n].expand(bs - n, -1, -1, -1))
@@ -498,6 +500,12 @@ class Model:
             for cb in callbacks:
                 cb.on_epoch_begin(epoch, {})
             Xd = self._device_frames(X)
+            if Xd.dtype == torch.uint8:
+                # grey levels: the same scaling predict() applies to uint8 frames (utils.py:340-342) -- a container must
+                # not change what the network sees
+                raise TypeError("fit(): uint8 frames are grey levels; pass float32 frames in [-1, 1] "
+                                "(utils.build_X) -- predict() scales uint8 frames on the device, fit() trains in place on "
+                                "the caller's float array as the reference does")
             if Xd.dtype != torch.float32 or not Xd.is_contiguous():
                 Xd = Xd.float().contiguous()
             if world > 1:
