@@ -929,6 +929,8 @@ def run(args):
     eng = Engine(H, W, BATCH, device=str(dev), seed=0, rank=rank)
     aug = DeviceAugmenter(X_pool)
     reducer = eng.make_reducer() if world > 1 else None
+    if reducer is not None:
+        reducer.exposed = []      # Engine._step_body leaves an event pair around reducer.finish() per step
     # 1-cycle table of the reference's own run configuration (lr_max 4e-5, 40k frames, 100 epochs)
     lrs = get_1cycle_schedule(lr_max=4e-5, n_data_points=40000, epochs=100, batch_size=BATCH * world)
     order = np.random.RandomState(7).permutation(args.pool)
@@ -982,6 +984,22 @@ def run(args):
         sys.stderr.write("trace: wall %.2f ms; GPU ms per step: %s\n" % (1e3 * dt, " ".join("%.2f" % evs[i].elapsed_time(evs[i + 1]) for i in range(args.steps))))
         sys.stderr.write("trace: host ms per step: %s\n" % " ".join("%.1f" % v for v in hts))
     loss = float(out[5])
+    # N > 1: what an 8-GPU shortfall would be made of -- the part of the gradient all-reduce the main stream WAITS for
+    # between the end of backward and the optimizer (everything else ran underneath backward), the bytes, the bucket plan
+    comm = None
+    if reducer is not None:
+        pairs = reducer.exposed[-args.steps:]
+        reducer.exposed = None
+        exposed = [e0.elapsed_time(e1) for e0, e1 in pairs]
+        buckets, tail = eng.grad_buckets()
+        comm = {"allreduce_exposed_ms_per_step": round(float(np.mean(exposed)), 3),
+                "allreduce_exposed_ms_max": round(float(np.max(exposed)), 3),
+                "bytes_allreduced_per_step_per_rank": 4 * eng.n_theta,
+                "ring_bytes_sent_per_step_per_rank": round(2.0 * (world - 1) / world * 4 * eng.n_theta),
+                "buckets": {"launched_during_backward": len(buckets), "dense_head_pieces": sum(1 for b in buckets if b[2] is eng.nodes[-1]),
+                            "mb": [round(4 * (hi - lo) / 2 ** 20, 1) for lo, hi, _ in buckets],
+                            "tail_at_end_of_backward_mb": round(4 * sum(hi - lo for lo, hi in tail) / 2 ** 20, 1)},
+                "measured": "HIP events around GradReducer.finish() on the main stream, mean / max over the timed steps of rank 0"}
 
     # Host cost of enqueueing ONE step into an idle GPU (the figure above is taken under queue back-pressure: the
     # host runs ahead until the launch queue is full and then waits for the GPU, so it reads ~ the GPU step time).
@@ -1053,6 +1071,8 @@ def run(args):
                        "host_enqueue_ms_per_step_gpu_idle": round(1e3 * t_host_idle, 3),
                        "pool_source": args.pool_source, "pool_generation_s": round(t_gen, 1)},
         }
+        if comm is not None:
+            result["config"]["comm"] = comm
         if sustained is not None:
             result["sustained"] = sustained
         if timer is not None:

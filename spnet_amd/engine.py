@@ -348,6 +348,126 @@ def param_specs(H, W, n_out=576, backbone="Xception"):
     return specs
 
 
+def param_layout(H, W, n_out=576, backbone="Xception"):
+    """Offsets of every tensor in the flat parameter / statistics buffers (pure: no device needed).
+    Flat layout: [l2-regularised kernels, the Dense head's first] [all depthwise kernels] [everything else in
+    forward order].  The l2 set is a prefix (weight decay inside the fused optimizer); the head kernel (73 % of
+    the bytes, produced first in backward) is one contiguous range at offset 0; the depthwise gradients, which
+    one batched reduction finishes at the very END of backward, sit together in front of the forward-ordered
+    rest, so that suffixes of the buffer are complete -- and can be all-reduced -- as backward walks up the net.
+    Returns {p_off, s_off: name -> (offset, n, shape); l2_n, rest_lo, n_theta, n_stats, spec_order}."""
+    specs = param_specs(H, W, n_out, backbone)
+    tr = [s for s in specs if s[2]]
+    l2 = sorted((s for s in tr if s[3]), key=lambda s: s[0] != "FinalOutput/kernel")
+    dwk = [s for s in tr if not s[3] and s[0].endswith("depthwise_kernel")]
+    order = l2 + dwk + [s for s in tr if not s[3] and not s[0].endswith("depthwise_kernel")]
+    # (packs: names that sit back to back with no padding between them -- param_packs; a pack is placed where its
+    # first member comes up in `order` and starts on an aligned offset)
+    pack_of = {n: tuple(p) for p in param_packs(backbone) for n in p}
+    shape_of = {s[0]: s[1] for s in specs}
+    off = 0
+    p_off = OrderedDict()
+    l2_n = rest_lo = 0
+    for name, shape, _, l2 in order:
+        if name in p_off:
+            continue                 # placed with its pack
+        for member in pack_of.get(name, (name,)):
+            mshape = shape_of[member]
+            n = int(np.prod(mshape))
+            if member in pack_of and (n & 3):
+                raise ValueError("packed parameters must be multiples of 4 floats: %s" % member)
+            p_off[member] = (off, n, mshape)
+            off += n if member in pack_of else (n + ALIGN - 1) // ALIGN * ALIGN
+        off = (off + ALIGN - 1) // ALIGN * ALIGN
+        if l2:
+            l2_n = off               # prefix (incl. alignment padding, which stays zero)
+        if name.endswith("depthwise_kernel"):
+            rest_lo = off            # first offset behind the depthwise kernels
+    if not any(n.endswith("depthwise_kernel") for n, _, _, _ in order):
+        rest_lo = l2_n               # no depthwise kernels (InceptionResNetV2): the rest starts behind the l2 prefix
+    n_theta = off
+    so = 0
+    s_off = OrderedDict()
+    for name, shape, trn, _ in specs:
+        if not trn and name not in s_off:
+            for member in pack_of.get(name, (name,)):
+                mshape = shape_of[member]
+                n = int(np.prod(mshape))
+                s_off[member] = (so, n, mshape)
+                so += n if member in pack_of else (n + ALIGN - 1) // ALIGN * ALIGN
+            so = (so + ALIGN - 1) // ALIGN * ALIGN
+    return dict(p_off=p_off, s_off=s_off, l2_n=l2_n, rest_lo=rest_lo, n_theta=n_theta, n_stats=so,
+                spec_order=[s[0] for s in specs])
+
+
+def xception_node_pnames():
+    """Forward-ordered (key, parameter-name prefixes, is_middle_block) of the nodes Engine._build_graph creates for the
+    Xception plan -- what plan_grad_buckets needs of them (a CPU test plans the 384 x 512 engine's all-reduce from
+    this; tests/test_engine_gpu.py checks it against the live engine's nodes)."""
+    out = [("conv2d_1", ["conv2d_1"], False)]
+    for k in (1, 2, 3):
+        if k > 1:
+            out.append(("conv2d_%d" % k, ["conv2d_%d" % k], False))
+        out.append(("batch_normalization_%d" % k, ["batch_normalization_%d" % k], False))
+    out.append(("dropout", [], False))
+    out += [("block1_conv1", ["block1_conv1"], False), ("block1_conv1_bn", ["block1_conv1_bn"], False),
+            ("block1_conv2", ["block1_conv2"], False), ("block1_conv2_bn", ["block1_conv2_bn"], False)]
+    for blk in xception_plan():
+        if blk[0] == "strided":
+            b = blk[1]
+            out.append(("block%d" % b, [blk[6], blk[7]] + [n for k in (1, 2) for n in ("block%d_sepconv%d" % (b, k),
+                                                                                        "block%d_sepconv%d_bn" % (b, k))], False))
+        elif blk[0] == "middle":
+            b = blk[1]
+            out.append(("block%d" % b, [n for k in (1, 2, 3) for n in ("block%d_sepconv%d" % (b, k),
+                                                                        "block%d_sepconv%d_bn" % (b, k))], True))
+        elif blk[0] == "exit":
+            out.append(("block14", ["block14_sepconv1", "block14_sepconv1_bn", "block14_sepconv2", "block14_sepconv2_bn"], False))
+    out.append(("FinalOutput", ["FinalOutput"], False))
+    return out
+
+
+def plan_grad_buckets(p_off, rest_lo, n_theta, nodes, bucket_bytes=32 << 20):
+    """Plan of the gradient all-reduce (~32 MB buckets in reverse layer order); pure.
+
+    nodes: forward-ordered [(key, parameter-name prefixes, is_middle_block)], the last one owning the Dense head.
+    Returns (buckets, tail): buckets = [(lo, hi, trigger key)] in launch order -- float ranges of the flat
+    gradient that are COMPLETE once the node `trigger` has been back-propagated -- and tail = [(lo, hi)], what is
+    only complete when backward ends.  The Dense-head kernel (produced first, 73 % of the bytes) goes first, cut
+    into bucket-sized pieces; then suffixes of the forward-ordered region, cut at node boundaries.  The
+    middle-flow pointwise gradients are produced by ONE deferred batched launch once block 5 is done
+    (flush_deferred_wgrads), so every bucket inside the middle flow is triggered by the FIRST middle block.  The tail
+    holds the small l2 kernels, all depthwise kernels (their batched reduction is the last launch of backward) and
+    whatever forward-ordered parameters precede the first bucket cut."""
+    per = max(int(bucket_bytes) // 4, ALIGN)
+    head = nodes[-1][0]
+    hoff, hn, _ = p_off["FinalOutput/kernel"]
+    hlo, hhi = hoff, hoff + hn
+    buckets = [(lo, min(lo + per, hhi), head) for lo in range(hlo, hhi, per)]
+    first = {}                                   # node -> lowest offset of its parameters in the rest region
+    for key, pnames, _ in nodes:
+        offs = [off for name, (off, n, _s) in p_off.items() if off >= rest_lo and name.split("/")[0] in pnames]
+        if offs:
+            first[key] = min(offs)
+    first_middle = next((key for key, _, mid in nodes if mid), None)
+    owners = [(key, mid) for key, _, mid in nodes if key in first]
+    cur_hi = n_theta
+    for i in range(len(owners) - 1, -1, -1):
+        key, mid = owners[i]
+        if first[key] >= cur_hi:
+            continue
+        # cut here when the bucket is full, and on both edges of the middle flow (what lies behind it is complete
+        # long before the deferred launch; what lies in front of it is not touched by it)
+        edge = i > 0 and owners[i - 1][1] != mid
+        if (cur_hi - first[key]) >= per or edge:
+            buckets.append((first[key], cur_hi, first_middle if mid else key))
+            cur_hi = first[key]
+    tail = [(hhi, cur_hi)] if cur_hi > hhi else []
+    if hlo > 0:
+        tail.insert(0, (0, hlo))
+    return buckets, tail
+
+
 def _glorot_fans(name, shape):
     if name.endswith("depthwise_kernel"):
         return shape[2] * 9, 9
@@ -468,56 +588,15 @@ class Engine:
 
     # ------------------------------------------------------------------ parameters
     def _build_params(self, seed):
-        specs = param_specs(self.H, self.W, self.n_out, self.backbone)
-        # Flat layout: [l2-regularised kernels, the Dense head's first] [all depthwise kernels] [everything else in
-        # forward order].  The l2 set is a prefix (weight decay inside the fused optimizer); the head kernel (73 % of
-        # the bytes, produced first in backward) is one contiguous range at offset 0; the depthwise gradients, which
-        # one batched reduction finishes at the very END of backward, sit together in front of the forward-ordered
-        # rest, so that suffixes of the buffer are complete -- and can be all-reduced -- as backward walks up the net.
-        tr = [s for s in specs if s[2]]
-        l2 = sorted((s for s in tr if s[3]), key=lambda s: s[0] != "FinalOutput/kernel")
-        dwk = [s for s in tr if not s[3] and s[0].endswith("depthwise_kernel")]
-        order = l2 + dwk + [s for s in tr if not s[3] and not s[0].endswith("depthwise_kernel")]
-        # (packs: names that sit back to back with no padding between them -- param_packs; a pack is placed where its
-        # first member comes up in `order` and starts on an aligned offset)
-        pack_of = {n: tuple(p) for p in param_packs(self.backbone) for n in p}
-        shape_of = {s[0]: s[1] for s in specs}
-        off = 0
-        self.p_off = OrderedDict()
-        for name, shape, _, l2 in order:
-            if name in self.p_off:
-                continue                 # placed with its pack
-            for member in pack_of.get(name, (name,)):
-                mshape = shape_of[member]
-                n = int(np.prod(mshape))
-                if member in pack_of and (n & 3):
-                    raise ValueError("packed parameters must be multiples of 4 floats: %s" % member)
-                self.p_off[member] = (off, n, mshape)
-                off += n if member in pack_of else (n + ALIGN - 1) // ALIGN * ALIGN
-            off = (off + ALIGN - 1) // ALIGN * ALIGN
-            if l2:
-                self.l2_n = off          # prefix (incl. alignment padding, which stays zero)
-            if name.endswith("depthwise_kernel"):
-                self.rest_lo = off       # first offset behind the depthwise kernels
-        if not any(n.endswith("depthwise_kernel") for n, _, _, _ in order):
-            self.rest_lo = self.l2_n     # no depthwise kernels (InceptionResNetV2): the rest starts behind the l2 prefix
-        self.n_theta = off
-        s_off = 0
-        self.s_off = OrderedDict()
-        for name, shape, tr, _ in specs:
-            if not tr and name not in self.s_off:
-                for member in pack_of.get(name, (name,)):
-                    mshape = shape_of[member]
-                    n = int(np.prod(mshape))
-                    self.s_off[member] = (s_off, n, mshape)
-                    s_off += n if member in pack_of else (n + ALIGN - 1) // ALIGN * ALIGN
-                s_off = (s_off + ALIGN - 1) // ALIGN * ALIGN
+        lay = param_layout(self.H, self.W, self.n_out, self.backbone)
+        for k in ("p_off", "s_off", "l2_n", "rest_lo", "n_theta", "spec_order"):
+            setattr(self, k, lay[k])
+        s_off = lay["n_stats"]
         z = lambda n: torch.zeros(n, device=self.dev, dtype=torch.float32)
         self.theta = z(self.n_theta)
         self.stats = z(s_off)
         if self.train_capable:
             self.grad, self.m, self.v = z(self.n_theta), z(self.n_theta), z(self.n_theta)
-        self.spec_order = [s[0] for s in specs]
         self.init_weights(seed)
 
     def init_weights(self, seed=0):
@@ -1004,47 +1083,23 @@ class Engine:
         else:
             reducer.side_stream = self.wgrad_stream
             self.backward(on_node_done=reducer.on_node_done)
+            # (measurement hook: reducer.exposed = [] makes every step leave an event pair around finish() -- what the
+            # main stream waits for the collectives AFTER backward has ended, i.e. the all-reduce time not hidden)
+            ev = getattr(reducer, "exposed", None)
+            if ev is not None:
+                e0 = torch.cuda.Event(enable_timing=True)
+                e0.record()
             scale = reducer.finish()
+            if ev is not None:
+                e1 = torch.cuda.Event(enable_timing=True)
+                e1.record()
+                ev.append((e0, e1))
         self.adam_step(None, scale)
 
     def grad_buckets(self, bucket_bytes=32 << 20):
-        """Plan of the gradient all-reduce (~32 MB buckets in reverse layer order).
-
-        Returns (buckets, tail): buckets = [(lo, hi, trigger_node)] in launch order -- float ranges of the flat
-        gradient that are COMPLETE once `trigger_node` has been back-propagated -- and tail = [(lo, hi)], what is
-        only complete when backward ends.  The Dense-head kernel (produced first, 73 % of the bytes) goes first, cut
-        into bucket-sized pieces; then suffixes of the forward-ordered region, cut at node boundaries.  The
-        middle-flow pointwise gradients are produced by ONE deferred batched launch once block 5 is done
-        (flush_deferred_wgrads), so every bucket inside the middle flow is triggered by that block.  The tail holds
-        the small l2 kernels, all depthwise kernels (their batched reduction is the last launch of backward) and
-        whatever forward-ordered parameters precede the first bucket cut."""
-        per = max(int(bucket_bytes) // 4, ALIGN)
-        head = self.nodes[-1]
-        hlo, hhi = self.head_grad_range()
-        buckets = [(lo, min(lo + per, hhi), head) for lo in range(hlo, hhi, per)]
-        first = {}                                   # node -> lowest offset of its parameters in the rest region
-        for node in self.nodes:
-            offs = [off for name, (off, n, _) in self.p_off.items()
-                    if off >= self.rest_lo and name.split("/")[0] in getattr(node, "pnames", ())]
-            if offs:
-                first[node] = min(offs)
-        cur_hi = self.n_theta
-        owners = [n for n in self.nodes if n in first]
-        is_mid = lambda n: isinstance(n, MiddleBlock)
-        for i in range(len(owners) - 1, -1, -1):
-            node = owners[i]
-            if first[node] >= cur_hi:
-                continue
-            # cut here when the bucket is full, and on both edges of the middle flow (what lies behind it is complete
-            # long before the deferred launch; what lies in front of it is not touched by it)
-            edge = i > 0 and is_mid(owners[i - 1]) != is_mid(node)
-            if (cur_hi - first[node]) >= per or edge:
-                buckets.append((first[node], cur_hi, self._first_middle if is_mid(node) else node))
-                cur_hi = first[node]
-        tail = [(hhi, cur_hi)] if cur_hi > hhi else []
-        if hlo > 0:
-            tail.insert(0, (0, hlo))
-        return buckets, tail
+        """plan_grad_buckets over this plan's nodes: (buckets [(lo, hi, trigger node)], tail [(lo, hi)])."""
+        nodes = [(node, tuple(getattr(node, "pnames", ())), isinstance(node, MiddleBlock)) for node in self.nodes]
+        return plan_grad_buckets(self.p_off, self.rest_lo, self.n_theta, nodes, bucket_bytes)
 
     def make_reducer(self, group=None, force=False, bucket_bytes=32 << 20):
         """parallel.GradReducer over this plan's gradient buckets (force=True: run the collectives even with one

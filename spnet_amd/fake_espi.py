@@ -4,8 +4,9 @@ Follows the reference generator gen_fake_espi.py:60-279 up to, but excluding, th
 with the author's private real images (augmentation.py:10-62): 512x384 grey canvas at 128, wavy dark
 bands (draw_waves :60-80), 1..7 non-overlapping ringed ellipses (draw_antinodes :145-206, draw_rings
 :101-114), additive clipped N(40,40) noise, 50 % Bernoulli pixel dropout.  Rasterisation uses PIL
-(OpenCV is not available), the RNG is one numpy RandomState per frame -- frames are statistically,
-not bitwise, those of the reference.  Exactly one PNG per CSV is written (the reference also writes
+(OpenCV is not available); the parameter draws follow the reference's RNG call order (one `random.Random` +
+one numpy RandomState per frame: checked against oracle/espi_ref.py, which is pinned to the reference's own
+draws), the pixels are statistically, not bitwise, OpenCV's.  Exactly one PNG per CSV is written (the reference also writes
 a *_bp.png that would trip build_dataset's file-count assertion, utils.py:455-459).
 """
 import os
@@ -37,44 +38,47 @@ def _overlaps(a, b):
 
 
 def draw_params(seed, count_range=(1, 7)):
-    """All random PARAMETERS of one frame, drawn in the generator's order from RandomState(seed):
+    """All random PARAMETERS of one frame, drawn in the reference generator's own RNG call order -- it interleaves Python's
+    `random` module and numpy's generator, and so does this: one random.Random(seed) and one RandomState(seed) per frame
+    (the reference seeds both global generators once per run, gen_fake_espi.py:317-318; a generator pair per frame lets
+    frames be generated in any order and in parallel).
     waves = (amp, wavelength, thickness, slope, spacing) (draw_waves, gen_fake_espi.py:60-80) and
     nodes = [(cx, cy, a, b, angle, rings, ring_start)] (draw_antinodes :145-206 incl. the non-overlap rejection
-    loop, draw_rings' rand_start :107).  Returns (waves, nodes, rs) -- rs continues with the noise / dropout draws
-    of the host rasteriser.  count_range = (lo, hi) inclusive: the number of antinodes drawn per frame -- (1, 7) is the
-    reference's current generator (gen_fake_espi.py:250-251); its comments there date that to 'Nov 11 2020 increasing
+    loop, draw_rings' rand_start :107).  Returns (waves, nodes, (rnd, rs)) -- the generators continue with the sensor-model
+    draws of the host rasteriser.  count_range = (lo, hi) inclusive: the number of antinodes drawn per frame -- (1, 7) is
+    the reference's current generator (gen_fake_espi.py:250-251); its comments there date that to 'Nov 11 2020 increasing
     from 6 to 7 ... elminating 0', i.e. the published Dataset-A run was generated with (0, 6): 3.0 objects per frame."""
-    rs = np.random.RandomState(seed)
-    amp = rs.randint(10, 201)
-    wavelength = rs.randint(100, IM_W // 2 + 1)
-    thick = rs.randint(15, 41)
+    import random
+    rnd, rs = random.Random(seed), np.random.RandomState(seed)
+    amp = rnd.randint(10, 200)
+    wavelength = rnd.randint(100, IM_W // 2)
+    thick = rnd.randint(15, 40)
     slope = 3 * (rs.rand() - .5)
-    lo = thick + thick * int(abs(1.5 * slope))
-    spacing = rs.randint(lo, max(lo, IM_H // 3) + 1)
+    spacing = rnd.randint(thick + thick * int(abs(1.5 * slope)), IM_H // 3)
     waves = (amp, wavelength, thick, slope, spacing)
     boxes, nodes = [], []
-    for _ in range(rs.randint(count_range[0], count_range[1] + 1)):
-        axes = sorted((rs.randint(15, int(IM_W / 3.5) + 1), rs.randint(15, int(IM_H / 3.5) + 1)), reverse=True)
-        rings = rs.randint(1, min(axes[1] // 8, 11) + 1)
+    for _ in range(rnd.randint(count_range[0], count_range[1])):
+        axes = sorted((rnd.randint(15, int(IM_W / 3.5)), rnd.randint(15, int(IM_H / 3.5))), reverse=True)
+        rings = rnd.randint(1, min(axes[1] // 8, 11))
         if axes[1] / rings < MIN_LINE_WIDTH:
             rings = axes[1] // MIN_LINE_WIDTH
-        center = (rs.randint(axes[0], IM_W - axes[0] + 1), rs.randint(axes[1], IM_H - axes[1] + 1))
-        angle = rs.randint(1, 180)
+        center = (rnd.randint(axes[0], IM_W - axes[0]), rnd.randint(axes[1], IM_H - axes[1]))
+        angle = rnd.randint(1, 179)
         box = _ellipse_box(center, axes, angle)
         tries = 0
         while (any(_overlaps(box, b) for b in boxes) or box[0] < 0 or box[2] > IM_W or box[1] < 0 or box[3] > IM_H) \
                 and tries < 2000:
             tries += 1
-            axes = sorted((rs.randint(25, IM_W // 3 + 1), rs.randint(25, IM_H // 3 + 1)), reverse=True)
+            axes = sorted((rnd.randint(25, IM_W // 3), rnd.randint(25, IM_H // 3)), reverse=True)
             if axes[1] / rings < MIN_LINE_WIDTH:
                 rings = axes[1] // MIN_LINE_WIDTH
-            center = (rs.randint(axes[0], IM_W - axes[0] + 1), rs.randint(axes[1], IM_H - axes[1] + 1))
-            angle = rs.randint(1, 181)
+            center = (rnd.randint(axes[0], IM_W - axes[0]), rnd.randint(axes[1], IM_H - axes[1]))
+            angle = rnd.randint(1, 180)
             box = _ellipse_box(center, axes, angle)
         if tries < 2000:
-            nodes.append((center[0], center[1], axes[0], axes[1], angle, rings, rs.randint(0, 2)))
+            nodes.append((center[0], center[1], axes[0], axes[1], angle, rings, int(rs.choice([0, 1]))))
             boxes.append(box)
-    return waves, nodes, rs
+    return waves, nodes, (rnd, rs)
 
 
 def _draw_waves(d, waves):
@@ -111,11 +115,13 @@ def raster_host(waves, nodes):
 
 def gen_frame(seed):
     """One frame: (uint8 [384,512] image, [(cx,cy,a,b,angle,rings), ...])."""
-    waves, nodes, rs = draw_params(seed)
+    waves, nodes, (rnd, rs) = draw_params(seed)
     a = raster_host(waves, nodes).astype(np.float32)
+    if rs.random_sample() <= 0.3:             # blur_inplace (augmentation.py:66-70): a no-op on the pixels, consumes RNG
+        rnd.choice([3, 7])
     noise = np.clip(np.rint(rs.normal(40, 40, a.shape)), 0, 255)      # cv2.randn into a uint8 image saturates
     a = np.minimum(a + noise, 255)
-    a *= rs.randint(0, 2, a.shape)                                      # drop half of the pixels
+    a *= rs.choice([0, 1], size=a.shape)                                # drop half of the pixels (:262-264)
     return a.astype(np.uint8), [n[:6] for n in nodes]
 
 

@@ -231,6 +231,30 @@ def main():
         G["csv_text"] = np.array(open(out_csv).read())
     G["csv_Yt"], G["csv_Yp"], G["csv_names"] = Yt_csv, Yp_csv, np.array(names)
 
+    # ---- fake-ESPI generator (gen_fake_espi.py:60-206): the reference's own draw_waves / draw_antinodes run from seeded
+    #      generators; their OpenCV calls go to recorders, every argument they pass is stored (the parameter draws and the
+    #      geometry handed to cv2.polylines / cv2.ellipse are pure Python; the pixels are OpenCV's and are not stored) ----
+    import gen_fake_espi as gfe
+    for s in (0, 1, 2, 3, 11):
+        rec_lines, rec_ell = [], []
+        gfe.cv2.polylines = lambda img, pts, closed, color, thickness=1: rec_lines.append((np.array(pts[0]), closed, color, thickness))
+        gfe.draw_ellipse = lambda img, center, axes, angle, color=0, thickness=2, **k: rec_ell.append(
+            (center[0], center[1], axes[0], axes[1], angle, color, thickness))
+        random.seed(s)
+        np.random.seed(s)
+        img = 128 * np.ones((gfe.imHeight, gfe.imWidth, 1), np.uint8)
+        gfe.draw_waves(img)
+        n_an = random.randint(1, 7)                       # gen_images (:250-251)
+        _, cap = gfe.draw_antinodes(img, num_antinodes=n_an)
+        G["espi%d_n_lines" % s] = np.int64(len(rec_lines))
+        G["espi%d_line_thickness" % s] = np.int64(rec_lines[0][3])
+        G["espi%d_line_first" % s] = rec_lines[0][0].astype(np.int32)
+        G["espi%d_line_last" % s] = rec_lines[-1][0].astype(np.int32)
+        G["espi%d_line_y0" % s] = np.array([l[0][0, 1] for l in rec_lines], np.int32)
+        G["espi%d_ellipses" % s] = np.array(rec_ell, np.float64).reshape(-1, 7)
+        G["espi%d_caption" % s] = np.array(cap)
+        G["espi%d_rng_after" % s] = np.array([random.random(), np.random.rand()])     # pins total RNG consumption
+
     # ---- flip metadata transform (pure python part of flip_image is not separable from cv2.flip,
     #      so only cleanup_angle is pinned above) -------------------------------------------
 

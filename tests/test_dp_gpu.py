@@ -114,6 +114,11 @@ def test_bench_self_launched_two_ranks_on_one_gpu():
     assert out["value"] > 0 and np.isfinite(out["config"]["final_loss"])
     assert "cpu_baseline" not in out and "predict" not in out          # N = 1 only
     assert 0 < out["roofline"]["frac"] < 1 and out["kernel_families"]["gemm"]["launches_per_step"] == 97
+    # what an N-GPU shortfall is attributable to: exposed all-reduce time, bytes, the bucket plan
+    comm = out["config"]["comm"]
+    assert comm["allreduce_exposed_ms_per_step"] >= 0 and comm["bytes_allreduced_per_step_per_rank"] == 309739008
+    assert comm["ring_bytes_sent_per_step_per_rank"] == 309739008 and comm["buckets"]["dense_head_pieces"] == 7
+    assert abs(sum(comm["buckets"]["mb"]) + comm["buckets"]["tail_at_end_of_backward_mb"] - 309739008 / 2 ** 20) < 1.0
 
 
 def test_bench_default_line_carries_every_block():

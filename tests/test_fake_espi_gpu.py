@@ -1,6 +1,9 @@
-"""Device fake-ESPI generator (csrc/espi.hip) against the host generator (spnet_amd/fake_espi.py, PIL):
-same parameters and labels by construction; pixels statistically (two rasterisers draw outlines a fraction of a pixel
-apart), sensor model by its distribution."""
+"""Device fake-ESPI generator (csrc/espi.hip + the host parameter draw of spnet_amd/fake_espi.py) against
+oracle/espi_ref.py, the CPU restatement of gen_fake_espi.py:60-279 that tests/test_oracle_numpy.py pins to the reference's
+own draws: parameters and labels exactly; pixels statistically (OpenCV's, the restatement's and the device's rasterisers
+draw outlines a fraction of a pixel apart); the sensor model by its distribution."""
+import random
+
 import numpy as np
 import pytest
 import torch
@@ -13,33 +16,52 @@ def _need_gpu():
         pytest.skip("no GPU")
 
 
-def test_device_generator_matches_host_generator():
+def test_device_generator_matches_the_restated_reference_generator():
     _need_gpu()
+    from oracle import espi_ref as E
     from spnet_amd import fake_espi as F
-    n, seed = 24, 5
-    Xh, labels_h = F.generate(n, seed=seed, workers=1)
-    # noise-free canvas: analytic device raster vs PIL raster of the same parameters
+    n, seed = 12, 5
+    seeds = F.frame_seeds(n, seed)
+    # 1. parameters and labels: the product's draw == the restatement's, generator pair by generator pair
+    ref = [E.frame_params(random.Random(s), np.random.RandomState(s)) for s in seeds]
     Xc, labels_d, Uc = F.generate_device(n, seed=seed, noise=False, want_u8=True)
-    assert labels_d == labels_h
-    host_canvas = np.stack([F.raster_host(*F.draw_params(s)[:2]) for s in F.frame_seeds(n, seed)])
+    for k, s in enumerate(seeds):
+        waves, nodes, _ = F.draw_params(s)
+        rw, rows, calls = ref[k]
+        assert tuple(waves) == tuple(rw[:5])
+        assert [tuple(nd[:6]) for nd in nodes] == [tuple(r) for r in rows] == [tuple(r) for r in labels_d[k]]
+        # ring_start of every antinode = the colour of its innermost ring in the restatement's call list
+        j = 0
+        for nd, r in zip(nodes, rows):
+            assert (calls[j][3] == E.BLACK) == (nd[6] == 0)
+            j += max(2 * r[5], 1)
+    # 2. noise-free canvas: the analytic device raster against the restatement's numpy raster (and the host PIL raster)
     dev_canvas = Uc.cpu().numpy()
+    ref_canvas = np.stack([E.raster(r[0], r[2]) for r in ref])
+    host_canvas = np.stack([F.raster_host(*F.draw_params(s)[:2]) for s in seeds])
     assert set(np.unique(dev_canvas)) <= {0, 128, 138}
-    differ = float((dev_canvas != host_canvas).mean())
-    print("canvas pixels that differ between the two rasterisers: %.2f %%" % (100 * differ))
-    assert differ < 0.06                      # outline edges only
-    for v in (0, 128, 138):                   # the same area of black bands / grey canvas / bright rings
-        assert abs(float((dev_canvas == v).mean()) - float((host_canvas == v).mean())) < 0.02, v
+    for name, other in (("device vs restatement", dev_canvas), ("host PIL vs restatement", host_canvas)):
+        differ = float((other != ref_canvas).mean())
+        print("%s: canvas pixels that differ: %.2f %%" % (name, 100 * differ))
+        assert differ < 0.06, name                  # outline edges only
+        for v in (0, 128, 138):                     # the same area of black bands / grey canvas / bright rings
+            assert abs(float((other == v).mean()) - float((ref_canvas == v).mean())) < 0.02, (name, v)
     np.testing.assert_allclose(Xc.cpu().numpy()[..., 0], (dev_canvas.astype(np.float32) / 255 - 0.5) * 2, atol=1e-6)
-    # full sensor model: clipped N(40,40) noise + 50 % dropout
+    # 3. full sensor model: clipped N(40,40) noise + 50 % dropout, against the restatement's
     Xd, _, Ud = F.generate_device(n, seed=seed, noise=True, want_u8=True)
     ud = Ud.cpu().numpy().astype(np.float64)
-    assert abs(float((ud == 0).mean()) - float((Xh == 0).mean())) < 0.01          # dropout + black bands
-    kept_d, kept_h = ud[ud > 0], Xh[Xh > 0].astype(np.float64)
-    assert abs(kept_d.mean() - kept_h.mean()) < 2.0 and abs(kept_d.std() - kept_h.std()) < 2.0
-    bg = (host_canvas == 128) & (dev_canvas == 128)    # flat background in both: 128 + clip(rint(N(40,40)), 0, 255), saturated
-    for arr, name in ((ud, "device"), (Xh.astype(np.float64), "host")):
+    ur = np.stack([E.sensor(ref_canvas[k], random.Random(s + 1), np.random.RandomState(s + 1)) for k, s in enumerate(seeds)]).astype(np.float64)
+    assert abs(float((ud == 0).mean()) - float((ur == 0).mean())) < 0.01          # dropout + black bands
+    kept_d, kept_r = ud[ud > 0], ur[ur > 0]
+    assert abs(kept_d.mean() - kept_r.mean()) < 2.0 and abs(kept_d.std() - kept_r.std()) < 2.0
+    bg = (ref_canvas == 128) & (dev_canvas == 128)    # flat background in both: 128 + clip(rint(N(40,40)), 0, 255), saturated
+    for arr, name in ((ud, "device"), (ur, "restatement")):
         px = arr[bg & (arr > 0)]
         assert abs(px.mean() - 171.1) < 1.0 and abs(px.std() - 34.1) < 1.0, (name, px.mean(), px.std())
+    # the host generator (PIL raster + numpy sensor model) shares the labels and the statistics
+    Xh, labels_h = F.generate(n, seed=seed, workers=1)
+    assert labels_h == labels_d
+    assert abs(float((Xh == 0).mean()) - float((ur == 0).mean())) < 0.01
     # determinism
     Xd2, _ = F.generate_device(n, seed=seed, noise=True)
     assert torch.equal(Xd, Xd2)

@@ -237,6 +237,95 @@ def test_gradient_allreduce_and_sharding_on_gloo(tmp_path, world):
         assert "rank %d ok" % r in o
 
 
+_PLAN_WORKER = r'''
+import os, sys, time, numpy as np, torch, torch.distributed as dist
+sys.path.insert(0, sys.argv[1])
+torch.set_num_threads(1)
+from spnet_amd import parallel
+from spnet_amd import engine as E
+rank, local, world = parallel.init_distributed("gloo")
+lay = E.param_layout(384, 512)
+nodes = E.xception_node_pnames()
+buckets, tail = E.plan_grad_buckets(lay["p_off"], lay["rest_lo"], lay["n_theta"], nodes)
+n = lay["n_theta"]
+pattern = (torch.arange(n, dtype=torch.int64) % 7).float()
+g = pattern * (rank + 1)
+red = parallel.GradReducer(g, buckets, tail=tail, force=True)
+assert red.active and red.world == world
+launched = []
+orig = red._launch
+def spy(lo, hi):
+    launched.append((lo, hi))
+    return orig(lo, hi)
+red._launch = spy
+for key, _, _ in reversed(nodes):          # Engine.backward walks the nodes in reverse and reports each one
+    red.on_node_done(key)
+n_before_tail = len(launched)
+scale = red.finish()
+assert scale == 1.0 / world
+assert torch.equal(g, pattern * sum(r + 1 for r in range(world)))
+assert [tuple(b[:2]) for b in buckets] == launched[:n_before_tail] and [tuple(t) for t in tail] == launched[n_before_tail:]
+dist.barrier()
+dist.destroy_process_group()
+print("rank", rank, "ok", len(buckets), len(tail))
+'''
+
+
+def test_allreduce_plan_of_the_benchmark_engine():
+    """The gradient all-reduce plan of the 384 x 512 Xception engine (SURVEY.md section 8e; replaces
+    spnet/multi_gpu.py:35-88), computed without a device: it tiles the 310 MB flat gradient exactly once, sends the Dense
+    head first in ~32 MB pieces, then suffixes of the forward-ordered region in reverse layer order with cuts on both edges
+    of the middle flow (whose 24 weight gradients come out of one deferred launch, triggered by block 5), and leaves only
+    the small prefix (l2 kernels, depthwise kernels, stem / entry-flow parameters) for the end of backward."""
+    from spnet_amd import engine as E
+    lay = E.param_layout(384, 512)
+    nodes = E.xception_node_pnames()
+    assert sum(n for _, n, _ in lay["p_off"].values()) == 77485385 - 54546          # trainable parameters
+    buckets, tail = E.plan_grad_buckets(lay["p_off"], lay["rest_lo"], lay["n_theta"], nodes)
+    per = (32 << 20) // 4
+    cover = sorted([(lo, hi) for lo, hi, _ in buckets] + list(tail))
+    assert cover[0][0] == 0 and cover[-1][1] == lay["n_theta"] and all(a[1] == b[0] for a, b in zip(cover, cover[1:]))
+    hoff, hn, _ = lay["p_off"]["FinalOutput/kernel"]
+    head = [b for b in buckets if b[2] == "FinalOutput"]
+    assert hoff == 0 and hn == 98304 * 576 and len(head) == -(-hn // per) and buckets[:len(head)] == head
+    assert all(hi - lo <= per for lo, hi, _ in head) and head[0][0] == 0 and head[-1][1] == hn
+    rest = buckets[len(head):]
+    assert all(a[0] == b[1] for a, b in zip(rest, rest[1:]))                 # descending, contiguous suffixes
+    assert rest[0][1] == lay["n_theta"]
+    order = [k for k, _, _ in nodes]
+    owner = {pn: k for k, pns, _ in nodes for pn in pns}
+    trig = [order.index(t) for _, _, t in rest]
+    assert trig == sorted(trig, reverse=True)                                # fired in backward order
+    mid = [b for b in rest if b[2] == "block5"]
+    names_in = lambda lo, hi: {n.split("/")[0] for n, (o, k, _) in lay["p_off"].items() if lo <= o < hi}
+    for lo, hi, t in rest:          # a bucket is complete when its trigger is done: nothing in it belongs to an earlier node
+        assert all(order.index(owner[nm]) >= order.index(t) for nm in names_in(lo, hi)), (lo, hi, t)
+    mid_names = set().union(*[names_in(lo, hi) for lo, hi, _ in mid])
+    assert mid and all(nm.startswith(("block5_", "block6_", "block7_", "block8_", "block9_", "block10_", "block11_", "block12_"))
+                       for nm in mid_names) and len(mid_names) == 8 * 6
+    assert sum(hi - lo for lo, hi in tail) * 4 < (16 << 20)                   # what waits for the end of backward: < 16 MB
+    assert 4 * lay["n_theta"] == 309739008                                    # bytes all-reduced per step and rank
+
+
+@pytest.mark.parametrize("world", [8])
+def test_allreduce_plan_runs_on_eight_gloo_ranks(tmp_path, world):
+    """... and eight gloo ranks execute that plan on full-size gradient buffers: every bucket is launched by the node that
+    completes it, in the planned order, the tail at finish(), and every element comes out as the sum over ranks."""
+    script = tmp_path / "w8.py"
+    script.write_text(_PLAN_WORKER)
+    procs = []
+    port = _free_port()
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=port, OMP_NUM_THREADS="1")
+        procs.append(subprocess.Popen([sys.executable, str(script), ROOT], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.STDOUT, text=True))
+    outs = [p.communicate(timeout=600)[0] for p in procs]
+    for r, (p, o) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, o
+        assert "rank %d ok" % r in o
+
+
 def test_prediction_csv_matches_reference_writer(golden, tmp_path):
     """hawley_spnet.csv (SURVEY 8f-3): byte-for-byte the text the reference's own show_pred_ellipses wrote for the same
     de-normalised grids (utils.py:67-137; golden generated with the image / drawing calls stubbed out)."""

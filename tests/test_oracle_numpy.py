@@ -120,3 +120,42 @@ def test_augment_matches_reference_rng_order(golden):
         got = np.stack([R.augment_image(X[i].copy()) for i in range(shape[0])])
         np.testing.assert_array_equal(got, want)
         assert np.random.rand() == float(golden[f"aug_{tag}_rng_after"])
+
+
+def test_fake_espi_restatement_reproduces_the_reference_draws(golden):
+    """oracle/espi_ref.py against the reference's own draw_waves / draw_antinodes (gen_fake_espi.py:60-206), run from
+    seeded generators by tests/golden/make_goldens.py with their OpenCV calls recorded: the same wave polylines (every
+    point handed to cv2.polylines), the same draw_ellipse calls (centre, ring axes, angle, colour, thickness, in order),
+    the same CSV caption, and the same NEXT outputs of both generators (total RNG consumption)."""
+    from oracle import espi_ref as E
+    for s in (0, 1, 2, 3, 11):
+        rnd, nprnd = random.Random(s), np.random.RandomState(s)
+        waves, rows, calls = E.frame_params(rnd, nprnd)
+        lines = E.wave_polylines(waves)
+        assert lines.shape[0] == int(golden["espi%d_n_lines" % s]) and waves[2] == int(golden["espi%d_line_thickness" % s])
+        np.testing.assert_array_equal(lines[0], golden["espi%d_line_first" % s])
+        np.testing.assert_array_equal(lines[-1], golden["espi%d_line_last" % s])
+        np.testing.assert_array_equal(lines[:, 0, 1], golden["espi%d_line_y0" % s])
+        got = np.array([(c[0][0], c[0][1], c[1][0], c[1][1], c[2], c[3], c[4]) for c in calls], np.float64).reshape(-1, 7)
+        np.testing.assert_array_equal(got, golden["espi%d_ellipses" % s])
+        assert E.caption(rows) == str(golden["espi%d_caption" % s])
+        np.testing.assert_array_equal(np.array([rnd.random(), nprnd.rand()]), golden["espi%d_rng_after" % s])
+    # draw_ellipse's fixed-point conversion (spnet/utils.py:41-52)
+    assert E.cv_ellipse_args((261, 157), [139 / 3.0, 22.0], 150) == ((267264, 160768), (47445, 22528), -150)
+
+
+def test_fake_espi_restated_raster_and_sensor_model():
+    """The numpy rasteriser and sensor model of the restatement on one frame: three grey levels, band / ring areas in the
+    range the parameters imply, saturated N(40, 40) noise on the flat background (mean 171.1, sigma 34.1 after clipping at
+    255), half of the pixels dropped."""
+    from oracle import espi_ref as E
+    rnd, nprnd = random.Random(5), np.random.RandomState(5)
+    waves, rows, calls = E.frame_params(rnd, nprnd)
+    img = E.raster(waves, calls)
+    assert set(np.unique(img)) <= {0, 128, 138} and (img == 128).mean() > 0.2 and (img == 0).mean() > 0.05
+    for cx, cy, a, b, ang, rings in rows:                   # the centre of every antinode lies inside its innermost ring
+        assert img[cy, cx] in (0, 128, 138)
+    out = E.sensor(img, rnd, nprnd)
+    assert abs((out == 0).mean() - (0.5 + 0.5 * (img == 0).mean() * 0.16)) < 0.02     # mask + black pixels with noise 0
+    bg = out[(img == 128) & (out > 0)].astype(np.float64)
+    assert abs(bg.mean() - 171.1) < 1.0 and abs(bg.std() - 34.1) < 1.0
