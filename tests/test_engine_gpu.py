@@ -199,6 +199,33 @@ def test_graph_replayed_training_invalidates_inference_coefficients():
     np.testing.assert_allclose(outs[1].numpy(), outs[0].numpy(), rtol=0, atol=1e-5)
 
 
+def test_captured_train_step_contains_the_weight_split():
+    """SPNET_TRAIN_GRAPH=1 with the bf16x3 planes kernels on (x3_min_tiles=0): a predict pass between the warm eager step
+    and the capturing step used to leave the weight planes "fresh", so the captured graph held no split and every replay
+    multiplied with the weights of the capture step (round-4 ADVICE).  The split now runs inside the optimizer step: twin
+    engines, eager and replaying, step -> predict -> three more steps, must end with the same weights."""
+    _need_gpu()
+    from spnet_amd.engine import Engine
+    h, w, b = 64, 96, 2
+    rs = np.random.RandomState(4)
+    X = torch.tensor(rs.rand(b, h, w, 1) * 2 - 1, dtype=torch.float32).cuda()
+    Y = torch.tensor(rs.rand(b, 576), dtype=torch.float32).cuda()
+    res = []
+    for graph in (False, True):
+        eng = Engine(h, w, b, device="cuda:0", seed=5, x3_min_tiles=0)
+        assert any(u.x3_fwd for u in eng._pw_layers)
+        eng.use_graph = graph
+        eng.train_step(X, Y, 1e-3)                 # warm (eager)
+        eng.x_in.copy_(X)
+        eng.predict_step(use_graph=False)          # a forward of a plan over the same weights: refreshes the planes
+        losses = [eng.train_step(X, Y, 1e-3)[:7].clone() for _ in range(3)]      # capture, replay, replay
+        torch.cuda.synchronize()
+        assert (eng._graph is not None) == graph
+        res.append((eng.theta.clone(), torch.stack(losses)))
+    np.testing.assert_allclose(res[1][1].cpu().numpy(), res[0][1].cpu().numpy(), rtol=1e-5, atol=1e-7)
+    np.testing.assert_allclose(res[1][0].cpu().numpy(), res[0][0].cpu().numpy(), rtol=0, atol=2e-6)
+
+
 def test_one_stream_step_equals_two_stream_step(monkeypatch):
     """SPNET_OVERLAP_WGRAD=0 (weight gradients on the main stream instead of the side stream that is joined before
     Adam; what bench.py's roofline leg runs): the same arithmetic in another launch order -- weights, Adam moments and

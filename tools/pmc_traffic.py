@@ -15,17 +15,18 @@ import collections, csv, json, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 FAMILIES = {
-    "gemm": ("gemm_f32_kernel", "gemm_bf16x3_fwd_kernel", "reduce_slabs_kernel", "conv3x3_fwd_kernel", "conv3x3_dgrad_kernel", "conv3x3_wgrad_kernel"),
+    "gemm": ("gemm_f32_kernel", "gemm_bf16x3_", "reduce_slabs_kernel", "conv3x3_fwd_kernel", "conv3x3_dgrad_kernel", "conv3x3_wgrad_kernel"),
     "dw_fwd": ("dw3x3_tile_fwd_kernel", "dw3x3_stream_fwd_kernel"),
     "dw_bwd": ("dw3x3_tile_bwd_kernel", "dw3x3_stream_bwd_kernel"),
+    # single kernels (bench.py quotes the dominant kernel's own traffic)
+    "gemm_bf16x3_pp_kernel": ("gemm_bf16x3_pp_kernel",),
+    "gemm_bf16x3_wgrad_kernel": ("gemm_bf16x3_wgrad_kernel",),
+    "bn_bwd_fused_vec_kernel": ("bn_bwd_fused_vec_kernel",),
 }
 
 
-def family(name):
-    for fam, keys in FAMILIES.items():
-        if any(k in name for k in keys):
-            return fam
-    return None
+def families(name):
+    return [fam for fam, keys in FAMILIES.items() if any(k in name for k in keys)]
 
 
 def fold(path, counter):
@@ -33,11 +34,9 @@ def fold(path, counter):
     for r in csv.DictReader(open(path)):
         if r["Counter_Name"] != counter:
             continue
-        fam = family(r["Kernel_Name"])
-        if fam is None:
-            continue
-        tot[fam] += float(r["Counter_Value"])
-        launches[fam].add(r["Dispatch_Id"])
+        for fam in families(r["Kernel_Name"]):
+            tot[fam] += float(r["Counter_Value"])
+            launches[fam].add(r["Dispatch_Id"])
     return tot, {k: len(v) for k, v in launches.items()}
 
 
