@@ -1092,7 +1092,10 @@ def run(args):
                             (tr["dw_fwd"]["launches"] + tr["dw_bwd"]["launches"])
             g_n, g_ms, g_flop = tot["gemm"]
             d_n, d_ms, d_bytes = tot["dw"]
-            dw_gbs = DW_TRAIN_BYTES_PER_IMAGE * BATCH * args.steps / (d_ms * 1e-3) / 1e9
+            # depthwise family: the algorithmic bytes of the launches that EXIST (8 B per element forward, 12 B backward:
+            # SURVEY 8(d)); the backward of the layers fused into the data-gradient GEMM's epilogue moves no dz any more
+            dw_gbs = d_bytes / (d_ms * 1e-3) / 1e9
+            dw_fused_bytes = DW_TRAIN_BYTES_PER_IMAGE * BATCH - d_bytes / args.steps
             # the dominant kernel of the step against its own peak; the GEMM family (every kernel against its own) beside it
             roof_gemm = gemm_roofline_block(timer, args.steps)
             dom = roof_gemm["kernel"].split(":")[0]
@@ -1105,7 +1108,12 @@ def run(args):
                        "bound": "hbm", "achieved": round(dw_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                        "frac": round(dw_gbs / HBM_PEAK_GBS, 4),
                        "traffic": None if d_traffic is None else round(d_traffic),
-                       "algorithmic_bytes_per_launch": round(DW_TRAIN_BYTES_PER_IMAGE * BATCH * args.steps / d_n),
+                       "algorithmic_bytes_per_launch": round(d_bytes / d_n),
+                       "algorithmic_bytes_per_step": round(d_bytes / args.steps),
+                       "bytes_per_step_of_layers_fused_into_the_gemm_epilogue": round(max(dw_fused_bytes, 0.0)),
+                       "fused_note": "SURVEY 8(d)'s 157.6 MB per image count every depthwise layer forward + backward; the backward "
+                                     "of the 12x16 / 6x8-plane layers runs in gemm_bf16x3_pp_dwbwd_kernel's epilogue (dz never "
+                                     "reaches HBM): their 12 B per element are not in `achieved`, their time is in the GEMM family",
                        "avg_launch_us": round(1e3 * d_ms / d_n, 2), "launches_per_step": d_n / args.steps,
                        "ms_per_step": round(d_ms / args.steps, 3)}
             # the depthwise family by sub-family: entry flow (blocks 2-4: 93x125 / 47x63 / 24x32 planes, large tensors),

@@ -69,6 +69,19 @@ int spnet_gemm_bf16x3_fwd_colstats(const float* A, int lda, const void* planes, 
 int spnet_gemm_bf16x3_pp(const void* a_planes, const void* b_planes, float* C, int ldc, int M, int N, int K, float* colstats,
                          int* stat_rows, void* stream);
 long spnet_gemm_bf16x3_wgrad_ksplit(int cin, int cout, int M, int nbatch);
+/* The data-gradient GEMM of a SeparableConv2D's pointwise step with the backward of its DEPTHWISE step fused into the
+ * epilogue (keras SeparableConv2D inside Xception's middle / exit flow; spnet/models.py:357-359): dz = dy W^T stays in LDS.
+ * dy_planes = planes of dL/d(pointwise output) [B*H*W][cout], w_planes = planes of W as stored ([cin][cout]); the plane must
+ * satisfy spnet_gemm_bf16x3_dwbwd_ok(H, W, cin) (192 % (H*W) == 0, W <= 16: a 192-pixel tile holds whole images).  Every
+ * other argument and every output is spnet_dwconv3x3_tiled_bwd's (x_fwd = the depthwise input, w = its [3][3][cin] kernel,
+ * dx bit-identical to the two-launch path; the dw / BatchNorm partial sums in spnet_gemm_bf16x3_dwbwd_rows(B*H*W) rows).
+ * spnet_gemm_bf16x3_dwbwd_ok returns 1 | 0 (a predicate, not a launch status). */
+long spnet_gemm_bf16x3_dwbwd_rows(long M);
+long spnet_gemm_bf16x3_dwbwd_ok(int H, int W, int cin);
+int spnet_gemm_bf16x3_pp_dwbwd(const void* dy_planes, const void* w_planes, int B, int H, int W, int cin, int cout,
+                               const float* x_fwd, const float* w, float* dx, int relu_in, const float* add, float* partial,
+                               const float* in_scale, const float* in_shift, const float* bn_mean, const float* bn_invstd,
+                               float* bn_partial, const float* bn_x, void* stream);
 int spnet_gemm_bf16x3_wgrad_batched(const void* jobs, int nbatch, int cin, int cout, int M, int ksplit, void* stream);
 /* C += A B, formed in the epilogue (no K split): a data gradient added onto what another consumer of the same tensor
  * has already left in C (the branch convolutions of an inception block; call site spnet/models.py:357-359). */

@@ -25,6 +25,7 @@
 //                              producer does not write planes (strided residual convolutions, MobileNet)
 //   split kernels              W (either operand form) or any fp32 matrix -> planes, one wave per piece
 #include "x3t.h"
+#include <type_traits>
 
 typedef short bf16x8 __attribute__((ext_vector_type(8)));
 typedef short bf16x4 __attribute__((ext_vector_type(4)));
@@ -44,6 +45,8 @@ typedef __attribute__((address_space(3))) bf16x4* lds_b64_t;
 #define X3_STEP (6 * X3_PLANE)          // bf16 elements of one K step in LDS: three A planes, three B planes (36 KB)
 #define X3_PIECES 36
 #define X3_PER 9                        // pieces per wave and K step
+#define X3_NDMA X3_PER                  // (LDS-DMA instructions per wave and K step of the kernel being compiled: the pipeline
+                                        // macros below count them; the 192-row kernel redefines it)
 
 // ------------------------------------------------------------------------------------------------ split kernels
 // Job j = {src, planes, K, N, sn, sk} (six 64-bit words, device memory): element (n, k) = src[n * sn + k * sk] becomes
@@ -123,7 +126,7 @@ __global__ __launch_bounds__(256) void split_bf16x3_one_kernel(const float* __re
     if ((DMA_) && (RD_)) {                                                                                     \
       _Pragma("unroll") for (int g = 0; g < 18; ++g) {                                                         \
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                                     \
-        if (g % 2 == 0 && g / 2 < X3_PER) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                   \
+        if (g % 2 == 0 && g / 2 < X3_NDMA) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                  \
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                                     \
         __builtin_amdgcn_sched_group_barrier(0x100, RPG_, 0);                                                  \
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                                     \
@@ -137,7 +140,7 @@ __global__ __launch_bounds__(256) void split_bf16x3_one_kernel(const float* __re
     X3_ISSUE(0, 0);                                                                                            \
     if ((NSTEPS_) > 1) {                                                                                       \
       X3_ISSUE(1, 1);                                                                                          \
-      asm volatile("s_waitcnt vmcnt(9)" ::: "memory");                                                         \
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(X3_NDMA) : "memory");                                            \
     } else {                                                                                                   \
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                         \
     }                                                                                                          \
@@ -255,6 +258,217 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16x3_pp_kernel(const unsigned s
   X3_STORE_C(C, ldc, m0, n0, M, N);
   if (colstats) X3_COLSTATS();
 }
+
+// ------------------------------------------------------------------------------------------------ data gradient + depthwise backward
+// The data-gradient GEMM of a separable convolution's pointwise step with the FUSED BACKWARD OF ITS DEPTHWISE STEP in the
+// epilogue (round 5): dz = dy W^T never reaches HBM and the depthwise-backward launch disappears.
+// A workgroup owns 192 pixels x 96 channels of dz -- whole images of the plane (12 x 16: one, 6 x 8: four), so the 3 x 3
+// neighbourhoods need no halo from another workgroup and, channels being independent, nothing is recomputed per column
+// tile.  Main loop: gemm_bf16x3_pp_kernel with a 192-row A tile (8 waves of 48 x 48, one workgroup per CU, 2 x 54 KB of
+// LDS, 7 LDS-DMA pieces per wave and K step).  Epilogue: the accumulators go to LDS as an fp32 tile [192][100]; a thread
+// then owns one channel quad and 12 pixels (a column of a 12-row image, or two columns of 6-row ones), fetches x (the
+// depthwise input: for the ReLU mask and the tap sums), the residual-branch gradient `add` and bn_x up front (the GEMM's
+// registers are dead: 36 loads in flight), and computes exactly what dw3x3_tile_bwd_kernel (dwconv.hip) computes:
+//   dx[q] = (sum_d dz[q-d] k[d]) * relu'(x*scale + shift) + add        (its fmaf order: dx is bit-identical)
+//   dk[d] partial sums over the tile's pixels, the producer BatchNorm's (sum dx, sum dx*xhat) partial sums
+// one partial row per workgroup row (ceil(M / 192) rows, [rows][9][C] and [rows][2][C]), reduced over the 16 pixel groups
+// through LDS in a fixed order.  Planes: 12 x 16 and 6 x 8 (Xception's middle and exit flow at 384 x 512 frames).
+#undef X3_NDMA
+#define X3_NDMA 7
+#define FB_BM 192
+#define FB_STEP (3 * (FB_BM + X3_BN) * X3_LDR)      // bf16 elements of one K step: 54 KB
+#define FB_LD 100                                   // fp32 row stride of the dz tile in LDS
+template <bool ADD, bool BNX>
+__global__ __launch_bounds__(512, 2) void gemm_bf16x3_pp_dwbwd_kernel(
+    const unsigned short* __restrict__ Ap, long a_ps, const unsigned short* __restrict__ Bp, long b_ps, int M, int N, int nk,
+    int tiles_n, int H, int W, const float* __restrict__ x, const float* __restrict__ wt, float* __restrict__ dx, int relu_in,
+    const float* __restrict__ add, float* __restrict__ partial, const float* __restrict__ in_scale,
+    const float* __restrict__ in_shift, const float* __restrict__ bn_mean, const float* __restrict__ bn_invstd,
+    float* __restrict__ bn_partial, const float* __restrict__ bn_x) {
+  __shared__ __attribute__((aligned(16))) unsigned short smem[2 * FB_STEP];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int lid = xcd_remap(blockIdx.x, gridDim.x);
+  const int tn = lid % tiles_n, tm = lid / tiles_n;
+  const int m0 = tm * FB_BM, n0 = tn * X3_BN;
+  const int rg_a = (M + 15) / 16, rg_b = (N + 15) / 16;
+  const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc((void*)Ap, 0, (int)(3 * a_ps * 2), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc((void*)Bp, 0, (int)(3 * b_ps * 2), 0x00020000);
+  // 54 pieces per K step: A planes 0..2 x 12 row groups (0..35), B planes x 6 (36..53); wave w moves pieces w + 8 i
+  // (i = 0..6; the two surplus slots repeat piece 53: same bytes): pieces w + 8 i are A's for i <= 3, B's for i >= 5
+  int soff[X3_NDMA];
+#pragma unroll
+  for (int i = 0; i < X3_NDMA; ++i) {
+    const int c = min(wave + 8 * i, 53);
+    soff[i] = c < 36 ? (int)(((c / 12) * a_ps + (long)min(m0 / 16 + c % 12, rg_a - 1) * nk * 512) * 2)
+                     : (int)((((c - 36) / 6) * b_ps + (long)min(n0 / 16 + (c - 36) % 6, rg_b - 1) * nk * 512) * 2);
+  }
+#define X3_ISSUE(KS_, BUF_)                                                                                    \
+  do {                                                                                                         \
+    unsigned short* base_ = smem + ((BUF_) & 1) * FB_STEP;                                                     \
+    _Pragma("unroll") for (int i = 0; i < X3_NDMA; ++i) {                                                      \
+      const int c = min(wave + 8 * i, 53);                                                                     \
+      const bool is_a = i < 4 ? true : (i > 4 ? false : (c < 36));                                             \
+      const __amdgpu_buffer_rsrc_t rs_ = is_a ? rs_a : rs_b;                                                   \
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_, (lds_ptr_t)(base_ + c * 512), 16, lane * 16,               \
+                                               soff[i] + (KS_) * 1024, 0, 0);                                  \
+    }                                                                                                          \
+  } while (0)
+  f32x4v acc[3][3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[i][j][r] = 0.f;
+  const int p16 = lane & 15, kg = lane >> 4;
+  constexpr int TA[6] = {2, 1, 0, 1, 0, 0}, TB[6] = {0, 1, 2, 0, 1, 0};
+  const int a_off = (wm * 48 + p16) * X3_LDR + X3_SWZ(p16, kg);
+  const int b_off = (3 * FB_BM + wn * 48 + p16) * X3_LDR + X3_SWZ(p16, kg);
+#define FB_READ_ROWS(KS_, FA_, FB_)                                                                            \
+  do {                                                                                                         \
+    const unsigned short* base_ = smem + ((KS_) & 1) * FB_STEP;                                                \
+    _Pragma("unroll") for (int p = 0; p < 3; ++p)                                                              \
+    _Pragma("unroll") for (int t = 0; t < 3; ++t) {                                                            \
+      FA_[t][p] = *reinterpret_cast<const bf16x8*>(base_ + a_off + (p * FB_BM + t * 16) * X3_LDR);             \
+      FB_[t][p] = *reinterpret_cast<const bf16x8*>(base_ + b_off + (p * X3_BN + t * 16) * X3_LDR);             \
+    }                                                                                                          \
+  } while (0)
+  X3_PIPELINE(nk, FB_READ_ROWS, 1);
+#undef X3_ISSUE
+
+  // ---- epilogue: dz tile -> LDS, then the depthwise backward over it
+#ifdef FB_SKIP_EPILOGUE       // (diagnostic build, tools/dwfuse_bwd_time.py: the main loop alone; results wrong)
+  {
+    float keep = 0.f;       // (every accumulator stays live: a dead one would take its MFMAs with it)
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+      for (int j = 0; j < 3; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) keep += acc[i][j][r];
+    if (keep == 1.2345f) dx[0] = keep;
+    return;
+  }
+#endif
+  __syncthreads();
+  float* ct = reinterpret_cast<float*>(smem);
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int j = 0; j < 3; ++j)
+        ct[(wm * 48 + i * 16 + kg * 4 + r) * FB_LD + wn * 48 + j * 16 + p16] = acc[i][j][r];
+  const int cq = tid & 31, pg = tid >> 5;               // channel quad of the tile (24 of 32 lanes work), pixel group
+  const int c = n0 + cq * 4;                            // first channel of the quad
+  const bool active = cq < 24 && c < N;
+  typedef float v4 __attribute__((ext_vector_type(4)));
+  const v4 zero = {0.f, 0.f, 0.f, 0.f};
+  v4 accw[9], bsg = zero, bsgx = zero;
+#pragma unroll
+  for (int tp = 0; tp < 9; ++tp) accw[tp] = zero;
+  // A thread walks down image columns: 12 pixels in all (one column of a 12 x 16 image, or one column each of two 6 x 8
+  // images) -- the plane is a template parameter, so every index below is a constant or a shift, the 3 x 3 window slides
+  // (3 LDS reads per pixel) and nothing branches: the epilogue runs at 2 waves per SIMD and is instruction-bound otherwise.
+  auto walk_columns = [&](auto ph_tag, auto pw_tag) {
+    constexpr int PH = decltype(ph_tag)::value, PW = decltype(pw_tag)::value, HW = PH * PW;
+    constexpr int WALKS = (FB_BM / PH) / 16;
+    static_assert(PH * WALKS == 12, "12 pixels per thread");
+    v4 xq[12], aq[ADD ? 12 : 1], bq[BNX ? 12 : 1];
+    int base[WALKS];
+    bool ok[WALKS], lft[WALKS], rgt[WALKS];
+#pragma unroll
+    for (int wk = 0; wk < WALKS; ++wk) {
+      const int col = pg + 16 * wk, img = col / PW, w = col % PW;
+      base[wk] = img * HW + w;                          // tile-local pixel of row 0 of this column
+      ok[wk] = active && m0 + img * HW < M;             // (M is a multiple of H*W: an image is inside or outside as a whole)
+      lft[wk] = w > 0;
+      rgt[wk] = w < PW - 1;
+#pragma unroll
+      for (int h = 0; h < PH; ++h) {
+        const long o = (long)(m0 + (ok[wk] ? base[wk] + h * PW : 0)) * N + (active ? c : 0);
+        xq[wk * PH + h] = *reinterpret_cast<const v4*>(x + o);
+        if (ADD) aq[wk * PH + h] = *reinterpret_cast<const v4*>(add + o);
+        if (BNX) bq[wk * PH + h] = *reinterpret_cast<const v4*>(bn_x + o);
+      }
+    }
+    v4 k[9], sc = {1.f, 1.f, 1.f, 1.f}, sh = zero, mu = zero, is = zero;
+    const int cc = active ? c : 0;
+#pragma unroll
+    for (int tp = 0; tp < 9; ++tp) k[tp] = *reinterpret_cast<const v4*>(wt + (long)tp * N + cc);
+    const bool affine = in_scale != nullptr;
+    if (affine) { sc = *reinterpret_cast<const v4*>(in_scale + cc); sh = *reinterpret_cast<const v4*>(in_shift + cc); }
+    if (bn_partial) { mu = *reinterpret_cast<const v4*>(bn_mean + cc); is = *reinterpret_cast<const v4*>(bn_invstd + cc); }
+    __syncthreads();                                    // the dz tile is complete
+#define FB_FMA(D_, A_, B_) D_ = v4{fmaf(A_.x, B_.x, D_.x), fmaf(A_.y, B_.y, D_.y), fmaf(A_.z, B_.z, D_.z), fmaf(A_.w, B_.w, D_.w)}
+#pragma unroll
+    for (int wk = 0; wk < WALKS; ++wk) {
+      const float* col0 = ct + base[wk] * FB_LD + cq * 4;       // row 0 of the column; the neighbours 1 pixel = FB_LD floats away
+      const int ol = lft[wk] ? -FB_LD : 0, orr = rgt[wk] ? FB_LD : 0;
+      const float fl = lft[wk] ? 1.f : 0.f, fr = rgt[wk] ? 1.f : 0.f;
+      v4 m0_ = zero, m1 = zero, m2 = zero;                        // row h - 1 (zeros above the image)
+      v4 c0 = *reinterpret_cast<const v4*>(col0 + ol) * fl, c1 = *reinterpret_cast<const v4*>(col0),
+         c2 = *reinterpret_cast<const v4*>(col0 + orr) * fr;
+#pragma unroll
+      for (int h = 0; h < PH; ++h) {
+        v4 n0_ = zero, n1 = zero, n2 = zero;                      // row h + 1 (zeros below the image)
+        if (h + 1 < PH) {
+          const float* rn = col0 + (h + 1) * PW * FB_LD;
+          n0_ = *reinterpret_cast<const v4*>(rn + ol) * fl;
+          n1 = *reinterpret_cast<const v4*>(rn);
+          n2 = *reinterpret_cast<const v4*>(rn + orr) * fr;
+        }
+        const v4 raw = xq[wk * PH + h];
+        v4 a = raw;
+        if (affine) a = v4{fmaf(raw.x, sc.x, sh.x), fmaf(raw.y, sc.y, sh.y), fmaf(raw.z, sc.z, sh.z), fmaf(raw.w, sc.w, sh.w)};
+        const v4 xin = relu_in ? v4{fmaxf(a.x, 0.f), fmaxf(a.y, 0.f), fmaxf(a.z, 0.f), fmaxf(a.w, 0.f)} : a;
+        v4 res = n2 * k[0];                                       // (the tile kernel's order: dx comes out bit-identical)
+        FB_FMA(res, n1, k[1]); FB_FMA(res, n0_, k[2]);
+        FB_FMA(res, c2, k[3]); FB_FMA(res, c1, k[4]); FB_FMA(res, c0, k[5]);
+        FB_FMA(res, m2, k[6]); FB_FMA(res, m1, k[7]); FB_FMA(res, m0_, k[8]);
+        if (relu_in) res = v4{a.x > 0.f ? res.x : 0.f, a.y > 0.f ? res.y : 0.f, a.z > 0.f ? res.z : 0.f, a.w > 0.f ? res.w : 0.f};
+        if (ADD) res += aq[wk * PH + h];
+        if (ok[wk]) {
+          FB_FMA(accw[0], xin, n2); FB_FMA(accw[1], xin, n1); FB_FMA(accw[2], xin, n0_);
+          FB_FMA(accw[3], xin, c2); FB_FMA(accw[4], xin, c1); FB_FMA(accw[5], xin, c0);
+          FB_FMA(accw[6], xin, m2); FB_FMA(accw[7], xin, m1); FB_FMA(accw[8], xin, m0_);
+          *reinterpret_cast<v4*>(dx + (long)(m0 + base[wk] + h * PW) * N + c) = res;
+          if (bn_partial) {                             // res = dL/d(BN output of the producer); xhat from the pre-BN value
+            const v4 pre = BNX ? bq[wk * PH + h] : raw;
+            bsg += res;
+            bsgx = v4{fmaf(res.x, (pre.x - mu.x) * is.x, bsgx.x), fmaf(res.y, (pre.y - mu.y) * is.y, bsgx.y),
+                      fmaf(res.z, (pre.z - mu.z) * is.z, bsgx.z), fmaf(res.w, (pre.w - mu.w) * is.w, bsgx.w)};
+          }
+        }
+        m0_ = c0; m1 = c1; m2 = c2;
+        c0 = n0_; c1 = n1; c2 = n2;
+      }
+    }
+  };
+  if (H == 12) walk_columns(std::integral_constant<int, 12>{}, std::integral_constant<int, 16>{});
+  else walk_columns(std::integral_constant<int, 6>{}, std::integral_constant<int, 8>{});
+  // the 9 tap sums (+ the 2 BatchNorm sums) over the 16 pixel groups of each channel quad, fixed order
+  __syncthreads();
+  v4* red = reinterpret_cast<v4*>(smem);                // [11][16 groups][32 quads]
+#pragma unroll
+  for (int tp = 0; tp < 9; ++tp) red[(tp * 16 + pg) * 32 + cq] = accw[tp];
+  red[(9 * 16 + pg) * 32 + cq] = bsg;
+  red[(10 * 16 + pg) * 32 + cq] = bsgx;
+  __syncthreads();
+  for (int q = tid; q < 11 * 32; q += 512) {
+    const int tp = q / 32, ll = q % 32, co = n0 + ll * 4;
+    if (ll < 24 && co < N && (tp < 9 || bn_partial)) {
+      v4 sum = red[(tp * 16) * 32 + ll];
+      for (int g = 1; g < 16; ++g) sum += red[(tp * 16 + g) * 32 + ll];
+      if (tp < 9) *reinterpret_cast<v4*>(partial + ((long)tm * 9 + tp) * N + co) = sum;
+      else *reinterpret_cast<v4*>(bn_partial + ((long)tm * 2 + (tp - 9)) * N + co) = sum;
+    }
+  }
+}
+#undef X3_NDMA
+#define X3_NDMA X3_PER
 
 // ------------------------------------------------------------------------------------------------ weight gradient
 // dW[cin][cout] = sum over pixels m of z[m][cin] dy[m][cout], both operands the planes of [M][cin] / [M][cout] (the planes
@@ -564,6 +778,39 @@ extern "C" int spnet_gemm_bf16x3_pp(const void* a_planes, const void* b_planes, 
                      reinterpret_cast<const unsigned short*>(a_planes), x3t_plane_elems(M, K),
                      reinterpret_cast<const unsigned short*>(b_planes), x3t_plane_elems(N, K), C, ldc, M, N, (K + 31) / 32, tn,
                      colstats);
+  SPNET_RETURN_LAUNCH_STATUS();
+}
+
+// Data-gradient GEMM of a pointwise convolution + the fused backward of the depthwise convolution in front of it
+// (gemm_bf16x3_pp_dwbwd_kernel): dy_planes = planes of dL/d(pointwise output) [M][cout], w_planes = planes of W as stored
+// ([cin][cout]: the data-gradient form), M = B*H*W pixels of an H x W plane with 192 % (H*W) == 0 and W <= 16 (a 192-row tile
+// holds whole images); the remaining arguments and every output are spnet_dwconv3x3_tiled_bwd's (x_fwd = the depthwise
+// input, w = its [3][3][cin] kernel, dx, partial rows for dw / the producer BatchNorm's sums) with
+// spnet_gemm_bf16x3_dwbwd_rows(M) partial rows.  dz is never written.
+extern "C" long spnet_gemm_bf16x3_dwbwd_rows(long M) { return (M + FB_BM - 1) / FB_BM; }
+extern "C" long spnet_gemm_bf16x3_dwbwd_ok(int H, int W, int cin) {      // the planes of Xception's middle and exit flow
+  return (((H == 12 && W == 16) || (H == 6 && W == 8)) && !(cin & 3)) ? 1 : 0;
+}
+extern "C" int spnet_gemm_bf16x3_pp_dwbwd(const void* dy_planes, const void* w_planes, int B, int H, int W, int cin, int cout,
+                                          const float* x_fwd, const float* w, float* dx, int relu_in, const float* add,
+                                          float* partial, const float* in_scale, const float* in_shift, const float* bn_mean,
+                                          const float* bn_invstd, float* bn_partial, const float* bn_x, void* stream) {
+  const long M = (long)B * H * W;
+  if (!x_fwd || !w || !dx || !partial || B < 1 || !spnet_gemm_bf16x3_dwbwd_ok(H, W, cin)) return (int)hipErrorInvalidValue;
+  if (bn_partial && (!bn_mean || !bn_invstd)) return (int)hipErrorInvalidValue;
+  if (!x3_planes_ok(dy_planes, M, cout) || !x3_planes_ok(w_planes, cin, cout)) return (int)hipErrorInvalidValue;
+  if ((((uintptr_t)x_fwd) | ((uintptr_t)dx) | ((uintptr_t)add) | ((uintptr_t)bn_x) | ((uintptr_t)w)) & 15) return (int)hipErrorInvalidValue;
+  const int tm = spnet_cdiv(M, FB_BM), tn = spnet_cdiv(cin, X3_BN);
+#define FB_LAUNCH(ADD_, BNX_)                                                                                  \
+  hipLaunchKernelGGL((gemm_bf16x3_pp_dwbwd_kernel<ADD_, BNX_>), dim3(tm * tn), dim3(512), 0, (hipStream_t)stream,                   \
+                     reinterpret_cast<const unsigned short*>(dy_planes), x3t_plane_elems(M, cout),                              \
+                     reinterpret_cast<const unsigned short*>(w_planes), x3t_plane_elems(cin, cout), (int)M, cin, (cout + 31) / 32, tn, \
+                     H, W, x_fwd, w, dx, relu_in, add, partial, in_scale, in_shift, bn_mean, bn_invstd, bn_partial, bn_x)
+  if (add && bn_x) FB_LAUNCH(true, true);
+  else if (add) FB_LAUNCH(true, false);
+  else if (bn_x) FB_LAUNCH(false, true);
+  else FB_LAUNCH(false, false);
+#undef FB_LAUNCH
   SPNET_RETURN_LAUNCH_STATUS();
 }
 

@@ -480,7 +480,7 @@ def _glorot_fans(name, shape):
 class Engine:
     def __init__(self, H, W, batch, n_out=576, device="cuda:0", loss_type="same", seed=0,
                  train=True, adam_eps=1e-7, share_from=None, rank=0, sigmoid_cols=None, backbone="Xception",
-                 pointwise="bf16x3", x3_min_tiles=192):
+                 pointwise="bf16x3", x3_min_tiles=192, fuse_dw_bwd=True):
         """rank: data-parallel rank, mixed into the initial dropout seed so that replicas draw different masks.
         pointwise: which kernel runs the forward and data-gradient GEMMs of the pointwise (1x1) convolutions with >= 256
         output columns -- "bf16x3" (csrc/gemm_bf16x3.hip: fp32 operands as three bf16 pieces on the bf16 matrix cores, fp32
@@ -490,7 +490,14 @@ class Engine:
         if pointwise not in ("bf16x3", "f32"):
             raise ValueError("pointwise must be 'bf16x3' or 'f32'")
         self._pointwise = pointwise     # fixed for the life of the plan: the operand buffers depend on it (`pointwise` property)
+        # the depthwise backward inside the pointwise data-gradient GEMM's epilogue where a 192-pixel tile holds whole
+        # images AND the 192 x 96 tiles fill the chip (12 x 16 planes at batch 32: the middle flow and block 13;
+        # spnet_gemm_bf16x3_pp_dwbwd) -- False: the two launches everywhere.  Measured (tools/dwfuse_bwd_time.py,
+        # profiles/r05_dwfuse_bwd.txt): 41.3 us against 48.4 us for the pair on the middle-flow layer, 45.5 against 56.5 with
+        # the residual-branch gradient; the 6 x 8 planes of the exit flow (128 tiles) lose (74 against 60 us) and keep the pair.
+        self.fuse_dw_bwd = bool(fuse_dw_bwd)
         self.x3_min_tiles = int(x3_min_tiles)
+        self.fuse_min_tiles = 256 if self.x3_min_tiles else 0       # (x3_min_tiles = 0, the parity tests: small plans fuse too)
         if not torch.cuda.is_available():
             raise RuntimeError("spnet_amd.Engine needs a HIP device (no CPU fallback)")
         self.H, self.W, self.B, self.n_out = int(H), int(W), int(batch), int(n_out)
@@ -1710,6 +1717,13 @@ class SepConvBN:
         self.bn = BN(eng, cout, self.M, name + "_bn")
         self.y = eng.new(B, H, W, cout) if mode == "apply" else None
         self.dwb = _DwBwdPlan(B, H, W, cin)
+        # planes-mode units on planes whose 192-pixel GEMM tiles hold whole images: depthwise backward fused into the
+        # data-gradient GEMM (dz never written, one launch less on the dependency chain)
+        self.fuse_bwd = bool(self.x3p and eng.train_capable and eng.fuse_dw_bwd and L.spnet_gemm_bf16x3_dwbwd_ok(H, W, cin)
+                             and ((self.M + 191) // 192) * ((cin + 95) // 96) >= eng.fuse_min_tiles)
+        if self.fuse_bwd:
+            self.dwb.rows = int(L.spnet_gemm_bf16x3_dwbwd_rows(self.M))
+            self.dwb.ws_floats = self.dwb.rows * 9 * cin
         self.rows_src = self.dwb.rows                                # partial rows this unit emits for src.bn
         if self.rows_src * 2 * cin > WS_BNP[1]:
             raise RuntimeError("workspace regions too small for %s" % name)
@@ -1718,7 +1732,7 @@ class SepConvBN:
         self.pending_rows = 0               # > 0: partial rows waiting in WS_BNP for the consumer's prologue
         if eng.train_capable:
             self.gwd = eng.G(name + "/depthwise_kernel")
-            self.dz = eng.new(B, H, W, cin)
+            self.dz = None if self.fuse_bwd else eng.new(B, H, W, cin)
             self.dx = eng.new(B, H, W, cin)
             # This unit's depthwise weight-gradient partial sums [rows][9][cin]: kept in a buffer of its own so
             # that ALL units' reductions run as one launch at the end of backward, off the dependency chain.
@@ -1800,7 +1814,20 @@ class SepConvBN:
                 self.bn.bwd_from_partials_x3(self.yp, g, self.dyp, self.consumer_rows)
             else:
                 self.bn.bwd_full_x3(self.yp, g, self.dyp, self.act if self.mode == "apply" else ACT_NONE)
-            self.pw.bwd_p(self.zp, self.dyp, self.dz)
+            self.pw.bwd_p(self.zp, self.dyp, self.dz)        # (fuse_bwd: dz is None -> the weight gradient only)
+            if self.fuse_bwd:
+                st = self.src.stats_bn if self.src.stats_bn is not None else sb
+                prof = e.prof
+                t0 = prof.start() if prof is not None else None
+                L.spnet_gemm_bf16x3_pp_dwbwd(L.ptr(self.dyp), L.ptr(e._planes[self.pw.wname][1]), e.B, self.H, self.W, self.cin,
+                                             self.cout, L.ptr(self.src.t), L.ptr(self.wd), L.ptr(self.dx), self.relu_in,
+                                             L.ptr(add), L.ptr(self.wpart), sb.scale_ptr if sb else None,
+                                             sb.shift_ptr if sb else None, st.mean_ptr if st else None,
+                                             st.invstd_ptr if st else None, e.ws_ptr(WS_BNP) if st else None,
+                                             L.ptr(self.src.stats_x), _stream())
+                if prof is not None:
+                    prof.stop("gemm", t0, 2.0 * self.M * self.cin * self.cout, ("x3p ab+dwbwd", self.M, self.cin, self.cout))
+                return self.dx
         else:
             out = g if self.bwd_inplace else self.dbn
             if from_partials:

@@ -41,16 +41,22 @@ def test_inference_forward_at_benchmark_geometry(case):
     assert_forward_mse(got, want)      # north-star tolerance: 1e-4; fp32 against fp32 is far tighter
 
 
-def test_training_forward_and_every_gradient_at_benchmark_geometry(case):
-    """Gradients against the fp64 oracle on the device's own ReLU / max-pool decisions (see tests/test_shapes_gpu.py:
+@pytest.mark.parametrize("fuse_dw_bwd", [False, True])
+def test_training_forward_and_every_gradient_at_benchmark_geometry(case, fuse_dw_bwd):
+    """(fuse_dw_bwd: the depthwise backward of the 12x16 / 6x8-plane layers inside the data-gradient GEMM's epilogue,
+    spnet_gemm_bf16x3_pp_dwbwd -- an option of the plan, off by default; the same gradients either way.)
+    Gradients against the fp64 oracle on the device's own ReLU / max-pool decisions (see tests/test_shapes_gpu.py:
     at this size some of the ~30 million ReLU inputs always sit within fp32 rounding of zero, and the fp32 CPU oracle
     itself is 2e-1 away from its fp64 evaluation in single tensors); every decision that differs must be a tie."""
     from spnet_amd.engine import Engine
     P, X, Y, mask, dseed = case
     # x3_min_tiles = 0: the pointwise forward / data-gradient GEMMs on the bf16x3 kernel as in the batch-32 benchmark plan
     # (batch 2 has too few rows for the engine's own 192-tile rule)
-    eng = Engine(H, W, 2, device="cuda:0", seed=1, x3_min_tiles=0)
+    eng = Engine(H, W, 2, device="cuda:0", seed=1, x3_min_tiles=0, fuse_dw_bwd=fuse_dw_bwd)
     assert sum(p.x3_fwd for p in eng._pw_layers) >= 30 and sum(p.x3_dgrad for p in eng._pw_layers) >= 28
+    from spnet_amd.engine import MiddleBlock
+    assert all(u.fuse_bwd == fuse_dw_bwd for n in eng.nodes if isinstance(n, MiddleBlock) for u in (n.u1, n.u2, n.u3))
+    assert eng.nodes[-2].u1.fuse_bwd == fuse_dw_bwd           # (x3_min_tiles = 0: the exit flow's 6 x 8 planes fuse as well)
     eng.load_state_dict(P)
     eng.set_drop_seed(dseed)
     out = eng.forward(X.cuda(), training=True)

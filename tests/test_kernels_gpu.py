@@ -423,6 +423,67 @@ def test_batchnorm_backward_writes_bf16x3_planes(L, M, C, P, act):
     _planes_equal_split_of(L, planes, dx, M, C)
 
 
+@pytest.mark.parametrize("B,H,W,cin,cout", [(32, 12, 16, 728, 728), (3, 12, 16, 256, 260), (5, 6, 8, 1024, 1536), (2, 6, 8, 100, 96),
+                                            (1, 12, 16, 96, 32), (7, 6, 8, 36, 64)])
+@pytest.mark.parametrize("with_add,with_bnx", [(0, 0), (1, 0), (1, 1), (0, 1)])
+def test_gemm_bf16x3_dgrad_with_fused_depthwise_backward(L, B, H, W, cin, cout, with_add, with_bnx):
+    """spnet_gemm_bf16x3_pp_dwbwd: the pointwise data-gradient GEMM with the depthwise backward in its epilogue == the two
+    launches it replaces (spnet_gemm_bf16x3_pp into dz, then spnet_dwconv3x3_tiled_bwd over dz): dx bit for bit, the
+    depthwise weight-gradient sums and the producer BatchNorm's backward sums (partial rows group the pixels differently)
+    to rounding; batch sizes whose last 192-pixel tile is ragged, channel counts that are not multiples of 96."""
+    assert L.spnet_gemm_bf16x3_dwbwd_ok(H, W, cin) == 1 and L.spnet_gemm_bf16x3_dwbwd_ok(24, 32, cin) == 0
+    assert L.spnet_gemm_bf16x3_dwbwd_ok(3, 4, cin) == 0
+    rs = np.random.RandomState(B * H + cin + cout)
+    M = B * H * W
+    dy = dev(rs.randn(M, cout) * 0.5)
+    wpw = dev(rs.randn(cin, cout) * 0.1)
+    x = dev(rs.randn(B, H, W, cin))
+    wd = dev(rs.randn(3, 3, cin))
+    add = dev(rs.randn(B, H, W, cin)) if with_add else None
+    bnx = dev(rs.randn(B, H, W, cin)) if with_bnx else None
+    sc, sh = dev(rs.rand(cin) + 0.5), dev(rs.randn(cin) * 0.3)
+    mu, isd = dev(rs.randn(cin) * 0.1), dev(rs.rand(cin) + 0.5)
+    dyp, wp = x3_planes(L, M, cout), x3_planes(L, cin, cout)
+    L.spnet_split_rows_bf16x3(dy.data_ptr(), cout, dyp.data_ptr(), M, cout, st())
+    jobs = torch.tensor([wpw.data_ptr(), wp.data_ptr(), cout, cin, cout, 1], dtype=torch.int64, device="cuda")    # W as stored
+    L.spnet_split_bf16x3_batched(jobs.data_ptr(), 1, int(L.spnet_bf16x3_plane_elems(cin, cout)), st())
+    # reference path: dz = dy W^T, then the tile kernel
+    dz = torch.empty(M, cin, device="cuda")
+    L.spnet_gemm_bf16x3_pp(dyp.data_ptr(), wp.data_ptr(), dz.data_ptr(), cin, M, cin, cout, None, None, st())
+    rows0 = int(L.spnet_dwconv3x3_tiled_rows(B, H, W, cin))
+    ws0 = torch.zeros(int(L.spnet_dwconv3x3_tiled_bwd_ws(B, H, W, cin)), device="cuda")
+    bnp0 = torch.zeros(rows0 * 2 * cin, device="cuda")
+    dx0 = torch.full((B, H, W, cin), float("nan"), device="cuda")
+    p = lambda t: None if t is None else t.data_ptr()
+    L.spnet_dwconv3x3_tiled_bwd(dz.data_ptr(), x.data_ptr(), wd.data_ptr(), dx0.data_ptr(), None, B, H, W, cin, 1, p(add),
+                                ws0.data_ptr(), sc.data_ptr(), sh.data_ptr(), mu.data_ptr(), isd.data_ptr(), bnp0.data_ptr(), p(bnx), st())
+    # fused
+    rows1 = int(L.spnet_gemm_bf16x3_dwbwd_rows(M))
+    assert rows1 == (M + 191) // 192
+    part1 = torch.full((rows1 * 9 * cin,), float("nan"), device="cuda")
+    bnp1 = torch.full((rows1 * 2 * cin,), float("nan"), device="cuda")
+    dx1 = torch.full((B * H * W + 1, cin), 7.0, device="cuda")
+    L.spnet_gemm_bf16x3_pp_dwbwd(dyp.data_ptr(), wp.data_ptr(), B, H, W, cin, cout, x.data_ptr(), wd.data_ptr(), dx1.data_ptr(), 1,
+                                 p(add), part1.data_ptr(), sc.data_ptr(), sh.data_ptr(), mu.data_ptr(), isd.data_ptr(),
+                                 bnp1.data_ptr(), p(bnx), st())
+    torch.cuda.synchronize()
+    assert torch.equal(dx1[:M].reshape(B, H, W, cin), dx0) and bool((dx1[M] == 7.0).all())
+    dk0 = ws0[:rows0 * 9 * cin].reshape(rows0, 9, cin).double().sum(0)
+    dk1 = part1.reshape(rows1, 9, cin).double().sum(0)
+    scale = float(dk0.abs().max())
+    assert float((dk1 - dk0).abs().max()) <= 2e-5 * scale * np.sqrt(M / 192.0)
+    b0 = bnp0.reshape(rows0, 2, cin).double().sum(0)
+    b1 = bnp1.reshape(rows1, 2, cin).double().sum(0)
+    assert float((b1 - b0).abs().max()) <= 2e-5 * float(b0.abs().max()) * np.sqrt(M / 192.0)
+    # relu_in = 0 and no BatchNorm sums (the exit flow's first unit): dx again bit for bit
+    dx0.fill_(float("nan")); dx1.fill_(7.0)
+    L.spnet_dwconv3x3_tiled_bwd(dz.data_ptr(), x.data_ptr(), wd.data_ptr(), dx0.data_ptr(), None, B, H, W, cin, 0, p(add),
+                                ws0.data_ptr(), None, None, None, None, None, None, st())
+    L.spnet_gemm_bf16x3_pp_dwbwd(dyp.data_ptr(), wp.data_ptr(), B, H, W, cin, cout, x.data_ptr(), wd.data_ptr(), dx1.data_ptr(), 0,
+                                 p(add), part1.data_ptr(), None, None, None, None, None, None, st())
+    assert torch.equal(dx1[:M].reshape(B, H, W, cin), dx0)
+
+
 @pytest.mark.parametrize("tile", [0, 3, 5, 6])
 def test_gemm_batched_wgrad_form(L, tile):
     """Several weight-gradient problems of one shape in one launch == the same problems one by one."""
