@@ -492,10 +492,10 @@ def predict_measure(X_pool, dev, steps, warmup, host_frames=1024):
     dt_eager = timed(steps, False)
     tim = time_families(eng, lambda: step(False), steps, torch.cuda.synchronize)
     tot = tim.totals()
-    d_n, d_ms, _ = tot["dw"]
+    d_n, d_ms, d_bytes = tot["dw"]
     n_prof = steps
     roof = gemm_roofline_block(tim, n_prof)
-    dw_gbs = DW_FWD_BYTES_PER_IMAGE * PB * n_prof / (d_ms * 1e-3) / 1e9
+    dw_gbs = d_bytes / (d_ms * 1e-3) / 1e9        # the launches that exist (8 B per element); the rest run in GEMM epilogues
     del eng
     # PCIe-inclusive: model.predict over host frames, as predict_spnet.py calls it
     nh = min(pool, host_frames) // PB * PB
@@ -524,9 +524,13 @@ def predict_measure(X_pool, dev, steps, warmup, host_frames=1024):
         "host_frames_note": "Model.predict over %d host frames: pageable -> pinned ring -> HBM on a copy stream, "
                             "overlapped with the forward passes (PCIe-inclusive; not `value`)" % nh,
         "roofline": dict(roof, measured=note),
-        "roofline_secondary": {"kernel": "dw3x3_stream_fwd_kernel (34 depthwise layers, forward)", "bound": "hbm",
+        "roofline_secondary": {"kernel": "dw3x3_stream_fwd_kernel (the depthwise layers that run as launches of their own; the "
+                                         "others -- second / third units of the 12x16-plane blocks -- run in the producing GEMM's "
+                                         "epilogue, gemm_bf16x3_pp_dwbwd_kernel<1>)", "bound": "hbm",
                                "achieved": round(dw_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                "frac": round(dw_gbs / HBM_PEAK_GBS, 4), "traffic": None,
+                               "algorithmic_bytes_per_step": round(d_bytes / n_prof),
+                               "bytes_per_step_of_layers_fused_into_gemm_epilogues": round(max(DW_FWD_BYTES_PER_IMAGE * PB - d_bytes / n_prof, 0.0)),
                                "launches_per_step": d_n / n_prof, "ms_per_step": round(d_ms / n_prof, 3), "measured": note},
     }
 

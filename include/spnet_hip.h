@@ -76,6 +76,13 @@ long spnet_gemm_bf16x3_wgrad_ksplit(int cin, int cout, int M, int nbatch);
  * other argument and every output is spnet_dwconv3x3_tiled_bwd's (x_fwd = the depthwise input, w = its [3][3][cin] kernel,
  * dx bit-identical to the two-launch path; the dw / BatchNorm partial sums in spnet_gemm_bf16x3_dwbwd_rows(B*H*W) rows).
  * spnet_gemm_bf16x3_dwbwd_ok returns 1 | 0 (a predicate, not a launch status). */
+/* Inference counterpart: the FORWARD pointwise GEMM (z_planes [B*H*W][cin] x w_planes in the forward form) with, in its
+ * epilogue, the folded BatchNormalization (scale_shift[2*cout] or NULL) + ReLU (relu_next) of its output and the depthwise
+ * 3x3 of the NEXT SeparableConv2D (w_next [3][3][cout]); out_planes = planes of [B*H*W][cout], bit-identical to
+ * spnet_gemm_bf16x3_pp followed by spnet_dwconv3x3_stream_fwd_x3 -- the pointwise output never reaches HBM (keras Xception
+ * middle flow, sepconv -> BN -> relu -> sepconv chains; spnet/models.py:357-359; predict_spnet.py:84-87). */
+int spnet_gemm_bf16x3_pp_dwfwd(const void* z_planes, const void* w_planes, int B, int H, int W, int cin, int cout,
+                               const float* scale_shift, int relu_next, const float* w_next, void* out_planes, void* stream);
 long spnet_gemm_bf16x3_dwbwd_rows(long M);
 long spnet_gemm_bf16x3_dwbwd_ok(int H, int W, int cin);
 int spnet_gemm_bf16x3_pp_dwbwd(const void* dy_planes, const void* w_planes, int B, int H, int W, int cin, int cout,

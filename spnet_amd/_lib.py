@@ -35,6 +35,7 @@ _SIGS = {
     "spnet_gemm_bf16x3_dwbwd_rows": (c_long, [c_long]),
     "spnet_gemm_bf16x3_dwbwd_ok": (c_long, [c_int, c_int, c_int]),
     "spnet_gemm_bf16x3_pp_dwbwd": (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, P, P, P, c_int, P, P, P, P, P, P, P, P, P]),
+    "spnet_gemm_bf16x3_pp_dwfwd": (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, P, c_int, P, P, P]),
     "spnet_gemm_bf16x3_wgrad_batched": (c_int, [P, c_int, c_int, c_int, c_int, c_int, P]),
     "spnet_split_bf16x3_batched": (c_int, [P, c_int, c_long, P]),
     "spnet_gemm_bf16x3_fwd": (c_int, [P, c_int, P, P, c_int, c_int, c_int, c_int, P]),

@@ -278,13 +278,19 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16x3_pp_kernel(const unsigned s
 #define FB_BM 192
 #define FB_STEP (3 * (FB_BM + X3_BN) * X3_LDR)      // bf16 elements of one K step: 54 KB
 #define FB_LD 100                                   // fp32 row stride of the dz tile in LDS
-template <bool ADD, bool BNX>
+// MODE 1 (inference): the FORWARD GEMM of a pointwise convolution with, in its epilogue, the BatchNorm affine + ReLU of its
+// output and the depthwise step of the NEXT separable convolution -- the tile holds whole images, so
+// z'[q] = sum_d relu(C[q+d] * scale + shift) k'[d] comes straight out of the C tile in LDS and is written as the bf16x3
+// planes the next pointwise GEMM reads: the pre-normalisation tensor never reaches HBM, the next unit's depthwise launch
+// disappears (wt = that depthwise kernel, in_scale / in_shift = this layer's folded BatchNorm, relu_in = the ReLU in
+// front of the next depthwise; dw3x3_stream_fwd_kernel's fmaf order: the planes are bit-identical to the two launches').
+template <int MODE, bool ADD, bool BNX>
 __global__ __launch_bounds__(512, 2) void gemm_bf16x3_pp_dwbwd_kernel(
     const unsigned short* __restrict__ Ap, long a_ps, const unsigned short* __restrict__ Bp, long b_ps, int M, int N, int nk,
     int tiles_n, int H, int W, const float* __restrict__ x, const float* __restrict__ wt, float* __restrict__ dx, int relu_in,
     const float* __restrict__ add, float* __restrict__ partial, const float* __restrict__ in_scale,
     const float* __restrict__ in_shift, const float* __restrict__ bn_mean, const float* __restrict__ bn_invstd,
-    float* __restrict__ bn_partial, const float* __restrict__ bn_x) {
+    float* __restrict__ bn_partial, const float* __restrict__ bn_x, unsigned short* __restrict__ out_planes, long out_ps) {
   __shared__ __attribute__((aligned(16))) unsigned short smem[2 * FB_STEP];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -352,6 +358,79 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16x3_pp_dwbwd_kernel(
     return;
   }
 #endif
+  if constexpr (MODE == 1) {
+    typedef float v4 __attribute__((ext_vector_type(4)));
+    const v4 zero = {0.f, 0.f, 0.f, 0.f};
+    __syncthreads();
+    float* ct = reinterpret_cast<float*>(smem);
+    float scv[3], shv[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const int col = min(n0 + wn * 48 + j * 16 + p16, N - 1);
+      scv[j] = in_scale ? in_scale[col] : 1.f;
+      shv[j] = in_scale ? in_shift[col] : 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+          float v = acc[i][j][r];
+          if (in_scale) v = fmaf(v, scv[j], shv[j]);
+          if (relu_in) v = fmaxf(v, 0.f);
+          ct[(wm * 48 + i * 16 + kg * 4 + r) * FB_LD + wn * 48 + j * 16 + p16] = v;
+        }
+    const int cq = tid & 31, pg = tid >> 5;
+    const int c = n0 + cq * 4;
+    const bool active = cq < 24 && c < N;
+    const int nk_out = (N + 31) >> 5;
+    auto walk_fwd = [&](auto ph_tag, auto pw_tag) {
+      constexpr int PH = decltype(ph_tag)::value, PW = decltype(pw_tag)::value, HW = PH * PW;
+      constexpr int WALKS = (FB_BM / PH) / 16;
+      v4 k[9];
+      const int cc = active ? c : 0;
+#pragma unroll
+      for (int tp = 0; tp < 9; ++tp) k[tp] = *reinterpret_cast<const v4*>(wt + (long)tp * N + cc);
+      __syncthreads();                                  // the activated tile is complete
+#define FB_FMA(D_, A_, B_) D_ = v4{fmaf(A_.x, B_.x, D_.x), fmaf(A_.y, B_.y, D_.y), fmaf(A_.z, B_.z, D_.z), fmaf(A_.w, B_.w, D_.w)}
+#pragma unroll
+      for (int wk = 0; wk < WALKS; ++wk) {
+        const int col = pg + 16 * wk, img = col / PW, w = col % PW;
+        const int base = img * HW + w;
+        const bool ok = active && m0 + img * HW < M;
+        const float* col0 = ct + base * FB_LD + cq * 4;
+        const int ol = w > 0 ? -FB_LD : 0, orr = w < PW - 1 ? FB_LD : 0;
+        const float fl = w > 0 ? 1.f : 0.f, fr = w < PW - 1 ? 1.f : 0.f;
+        v4 a_prev = zero, a_cur = zero;
+        // input row r feeds output rows r + 1 (taps 0-2), r (3-5), r - 1 (6-8): dw3x3_stream_fwd_kernel's march, zero rows
+        // above and below the image included
+#pragma unroll
+        for (int r = -1; r <= PH; ++r) {
+          v4 v0 = zero, v1 = zero, v2 = zero;
+          if (r >= 0 && r < PH) {
+            const float* rp = col0 + r * PW * FB_LD;
+            v0 = *reinterpret_cast<const v4*>(rp + ol) * fl;
+            v1 = *reinterpret_cast<const v4*>(rp);
+            v2 = *reinterpret_cast<const v4*>(rp + orr) * fr;
+          }
+          FB_FMA(a_prev, v0, k[6]); FB_FMA(a_prev, v1, k[7]); FB_FMA(a_prev, v2, k[8]);
+          FB_FMA(a_cur, v0, k[3]); FB_FMA(a_cur, v1, k[4]); FB_FMA(a_cur, v2, k[5]);
+          v4 a_next = v0 * k[0];
+          FB_FMA(a_next, v1, k[1]); FB_FMA(a_next, v2, k[2]);
+          const int t = r - 1;
+          if (t >= 0 && t < PH && ok)
+            x3t_store4(out_planes, out_ps, x3t_off(m0 + base + t * PW, c, nk_out), a_prev.x, a_prev.y, a_prev.z, a_prev.w);
+          a_prev = a_cur;
+          a_cur = a_next;
+        }
+      }
+#undef FB_FMA
+    };
+    if (H == 12) walk_fwd(std::integral_constant<int, 12>{}, std::integral_constant<int, 16>{});
+    else walk_fwd(std::integral_constant<int, 6>{}, std::integral_constant<int, 8>{});
+    return;
+  }
   __syncthreads();
   float* ct = reinterpret_cast<float*>(smem);
 #pragma unroll
@@ -802,15 +881,39 @@ extern "C" int spnet_gemm_bf16x3_pp_dwbwd(const void* dy_planes, const void* w_p
   if ((((uintptr_t)x_fwd) | ((uintptr_t)dx) | ((uintptr_t)add) | ((uintptr_t)bn_x) | ((uintptr_t)w)) & 15) return (int)hipErrorInvalidValue;
   const int tm = spnet_cdiv(M, FB_BM), tn = spnet_cdiv(cin, X3_BN);
 #define FB_LAUNCH(ADD_, BNX_)                                                                                  \
-  hipLaunchKernelGGL((gemm_bf16x3_pp_dwbwd_kernel<ADD_, BNX_>), dim3(tm * tn), dim3(512), 0, (hipStream_t)stream,                   \
+  hipLaunchKernelGGL((gemm_bf16x3_pp_dwbwd_kernel<0, ADD_, BNX_>), dim3(tm * tn), dim3(512), 0, (hipStream_t)stream,                \
                      reinterpret_cast<const unsigned short*>(dy_planes), x3t_plane_elems(M, cout),                              \
                      reinterpret_cast<const unsigned short*>(w_planes), x3t_plane_elems(cin, cout), (int)M, cin, (cout + 31) / 32, tn, \
-                     H, W, x_fwd, w, dx, relu_in, add, partial, in_scale, in_shift, bn_mean, bn_invstd, bn_partial, bn_x)
+                     H, W, x_fwd, w, dx, relu_in, add, partial, in_scale, in_shift, bn_mean, bn_invstd, bn_partial, bn_x,        \
+                     (unsigned short*)nullptr, 0L)
   if (add && bn_x) FB_LAUNCH(true, true);
   else if (add) FB_LAUNCH(true, false);
   else if (bn_x) FB_LAUNCH(false, true);
   else FB_LAUNCH(false, false);
 #undef FB_LAUNCH
+  SPNET_RETURN_LAUNCH_STATUS();
+}
+
+// Inference: the forward GEMM of a pointwise convolution (z_planes = planes of its input [B*H*W][cin], w_planes = planes of
+// W in the forward form) with the folded BatchNorm (scale_shift[2 * cout] or NULL) + ReLU (relu_next) of its output and the
+// depthwise 3x3 of the NEXT separable convolution (w_next [3][3][cout]) in the epilogue; the result goes out as the planes
+// of [B*H*W][cout] that the next pointwise GEMM reads.  Same planes, bit for bit, as spnet_gemm_bf16x3_pp followed by
+// spnet_dwconv3x3_stream_fwd_x3; the pointwise output itself is never written.  Planes: spnet_gemm_bf16x3_dwbwd_ok.
+extern "C" int spnet_gemm_bf16x3_pp_dwfwd(const void* z_planes, const void* w_planes, int B, int H, int W, int cin, int cout,
+                                          const float* scale_shift, int relu_next, const float* w_next, void* out_planes,
+                                          void* stream) {
+  const long M = (long)B * H * W;
+  if (!w_next || B < 1 || !spnet_gemm_bf16x3_dwbwd_ok(H, W, cout)) return (int)hipErrorInvalidValue;
+  if (!x3_planes_ok(z_planes, M, cin) || !x3_planes_ok(w_planes, cout, cin) || !x3_planes_ok(out_planes, M, cout))
+    return (int)hipErrorInvalidValue;
+  if ((((uintptr_t)w_next) | ((uintptr_t)scale_shift)) & 15) return (int)hipErrorInvalidValue;
+  const int tm = spnet_cdiv(M, FB_BM), tn = spnet_cdiv(cout, X3_BN);
+  hipLaunchKernelGGL((gemm_bf16x3_pp_dwbwd_kernel<1, false, false>), dim3(tm * tn), dim3(512), 0, (hipStream_t)stream,
+                     reinterpret_cast<const unsigned short*>(z_planes), x3t_plane_elems(M, cin),
+                     reinterpret_cast<const unsigned short*>(w_planes), x3t_plane_elems(cout, cin), (int)M, cout, (cin + 31) / 32, tn,
+                     H, W, (const float*)nullptr, w_next, (float*)nullptr, relu_next, (const float*)nullptr, (float*)nullptr,
+                     scale_shift, scale_shift ? scale_shift + cout : nullptr, (const float*)nullptr, (const float*)nullptr,
+                     (float*)nullptr, (const float*)nullptr, reinterpret_cast<unsigned short*>(out_planes), x3t_plane_elems(M, cout));
   SPNET_RETURN_LAUNCH_STATUS();
 }
 

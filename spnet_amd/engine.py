@@ -496,6 +496,9 @@ class Engine:
         # profiles/r05_dwfuse_bwd.txt): 41.3 us against 48.4 us for the pair on the middle-flow layer, 45.5 against 56.5 with
         # the residual-branch gradient; the 6 x 8 planes of the exit flow (128 tiles) lose (74 against 60 us) and keep the pair.
         self.fuse_dw_bwd = bool(fuse_dw_bwd)
+        # inference counterpart: the consumer's depthwise forward inside the producer's forward GEMM (sepconv -> BN -> relu
+        # -> sepconv chains of the middle flow / block 13-14 on 12 x 16 | 6 x 8 planes; spnet_gemm_bf16x3_pp_dwfwd)
+        self.fuse_dw_fwd = bool(fuse_dw_bwd)
         self.x3_min_tiles = int(x3_min_tiles)
         self.fuse_min_tiles = 256 if self.x3_min_tiles else 0       # (x3_min_tiles = 0, the parity tests: small plans fuse too)
         if not torch.cuda.is_available():
@@ -1728,6 +1731,8 @@ class SepConvBN:
         if self.rows_src * 2 * cin > WS_BNP[1]:
             raise RuntimeError("workspace regions too small for %s" % name)
         self.consumer_rows = 0              # set by the consumer (lazy mode)
+        self.consumer_unit = None           # the SepConvBN that reads this unit's un-materialised BatchNorm output, if any
+        self._dw_done = False               # inference: this unit's depthwise output was written by the producer's GEMM epilogue
         self.fin_by_consumer = False        # set by a SepConvBN consumer: it finalizes this unit's BatchNorm forward
         self.pending_rows = 0               # > 0: partial rows waiting in WS_BNP for the consumer's prologue
         if eng.train_capable:
@@ -1746,6 +1751,7 @@ class SepConvBN:
             self.dyp = eng.new_planes(self.M, cout) if self.x3p else None
         if src.bn is not None and hasattr(src, "owner"):
             src.owner.consumer_rows = self.rows_src
+            src.owner.consumer_unit = self           # (inference: the producer's GEMM may run this unit's depthwise, below)
             # the producer's training-forward BatchNorm finalize runs inside this unit's depthwise prologue
             # (spnet_dwconv3x3_tiled_fwd_bnfin) whenever its GEMM leaves at most 128 partial rows
             src.owner.fin_by_consumer = eng.train_capable
@@ -1763,7 +1769,10 @@ class SepConvBN:
         if prof is not None:
             t0 = prof.start()
         owner = getattr(self.src, "owner", None)
-        if training and owner is not None and owner.pending_rows:
+        ran_dw = True
+        if self._dw_done and not training:      # the producer's forward GEMM ran this depthwise in its epilogue
+            self._dw_done = ran_dw = False
+        elif training and owner is not None and owner.pending_rows:
             bnfin = L.spnet_dwconv3x3_tiled_fwd_bnfin_x3 if self.x3p else L.spnet_dwconv3x3_tiled_fwd_bnfin
             bnfin(L.ptr(self.src.t), L.ptr(self.wd), L.ptr(self.zp if self.x3p else self.z), e.B, self.H, self.W,
                   self.cin, self.relu_in, e.ws_ptr(WS_BNP), owner.pending_rows, sb.M,
@@ -1774,7 +1783,7 @@ class SepConvBN:
             (_dw_fwd_x3 if self.x3p else _dw_fwd)(self.src.t, self.wd, self.zp if self.x3p else self.z, e.B, self.H, self.W,
                                                   self.cin, self.relu_in, sb.scale_ptr if sb else None,
                                                   sb.shift_ptr if sb else None)
-        if prof is not None:
+        if prof is not None and ran_dw:
             prof.stop("dw", t0, 2.0 * 4 * self.M * self.cin, ("dw fwd", self.H, self.W, self.cin))   # read x + write z
         if training:
             rows = self.pw.fwd_p(self.zp, self.yp, WS_BNP) if self.x3p else self.pw.fwd_colstats(self.z, self.yp)
@@ -1790,6 +1799,20 @@ class SepConvBN:
             else:
                 self.bn.finalize(rows)
         else:
+            nxt = self.consumer_unit
+            if (self.x3p and self.mode == "lazy" and nxt is not None and nxt.x3p and e.fuse_dw_fwd
+                    and L.spnet_gemm_bf16x3_dwbwd_ok(self.H, self.W, self.cout)
+                    and ((self.M + 191) // 192) * ((self.cout + 95) // 96) >= e.fuse_min_tiles):
+                # inference: pointwise GEMM + this BatchNorm's affine + the consumer's ReLU and depthwise in ONE launch,
+                # the result written as the consumer's z planes (spnet_gemm_bf16x3_pp_dwfwd); yp is never written
+                self.bn.infer()
+                t0 = prof.start() if prof is not None else None
+                L.spnet_gemm_bf16x3_pp_dwfwd(L.ptr(self.zp), L.ptr(e._planes[self.pw.wname][0]), e.B, self.H, self.W, self.cin,
+                                             self.cout, L.ptr(self.bn.ss), nxt.relu_in, L.ptr(nxt.wd), L.ptr(nxt.zp), _stream())
+                if prof is not None:
+                    prof.stop("gemm", t0, 2.0 * self.M * self.cin * self.cout, ("x3p aB+dwfwd", self.M, self.cout, self.cin))
+                nxt._dw_done = True
+                return
             if self.x3p:
                 self.pw.fwd_p(self.zp, self.yp)
             else:

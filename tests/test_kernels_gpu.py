@@ -484,6 +484,33 @@ def test_gemm_bf16x3_dgrad_with_fused_depthwise_backward(L, B, H, W, cin, cout, 
     assert torch.equal(dx1[:M].reshape(B, H, W, cin), dx0)
 
 
+@pytest.mark.parametrize("B,H,W,cin,cout", [(128, 12, 16, 728, 728), (3, 12, 16, 256, 260), (5, 6, 8, 1024, 1536), (7, 6, 8, 36, 64)])
+@pytest.mark.parametrize("affine,relu", [(1, 1), (0, 1), (1, 0)])
+def test_gemm_bf16x3_forward_with_the_next_depthwise_fused(L, B, H, W, cin, cout, affine, relu):
+    """spnet_gemm_bf16x3_pp_dwfwd (inference): pointwise GEMM + folded BatchNorm + ReLU + the next unit's depthwise in the
+    epilogue == spnet_gemm_bf16x3_pp into yp followed by spnet_dwconv3x3_stream_fwd_x3(yp): the planes bit for bit."""
+    rs = np.random.RandomState(B * H + cin + cout)
+    M = B * H * W
+    z = dev(rs.randn(M, cin))
+    wpw = dev(rs.randn(cin, cout) * 0.1)
+    wd = dev(rs.randn(3, 3, cout))
+    ss = dev(np.concatenate([rs.rand(cout) + 0.5, rs.randn(cout) * 0.3]))
+    zp, wp = x3_planes(L, M, cin), x3_planes(L, cout, cin)
+    L.spnet_split_rows_bf16x3(z.data_ptr(), cin, zp.data_ptr(), M, cin, st())
+    L.spnet_split_bf16x3(wpw.data_ptr(), wp.data_ptr(), cin, cout, st())
+    yp = torch.empty(M, cout, device="cuda")
+    L.spnet_gemm_bf16x3_pp(zp.data_ptr(), wp.data_ptr(), yp.data_ptr(), cout, M, cout, cin, None, None, st())
+    ref = x3_planes(L, M, cout)
+    L.spnet_dwconv3x3_stream_fwd_x3(yp.data_ptr(), wd.data_ptr(), ref.data_ptr(), B, H, W, cout, relu, ss.data_ptr() if affine else None,
+                                    ss[cout:].data_ptr() if affine else None, 0, st())
+    out = x3_planes(L, M, cout)
+    L.spnet_gemm_bf16x3_pp_dwfwd(zp.data_ptr(), wp.data_ptr(), B, H, W, cin, cout, ss.data_ptr() if affine else None, relu,
+                                 wd.data_ptr(), out.data_ptr(), st())
+    torch.cuda.synchronize()
+    assert torch.equal(out, ref)
+    assert float(x3_untile(out, M, cout).abs().max()) > 0.1
+
+
 @pytest.mark.parametrize("tile", [0, 3, 5, 6])
 def test_gemm_batched_wgrad_form(L, tile):
     """Several weight-gradient problems of one shape in one launch == the same problems one by one."""
