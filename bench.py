@@ -130,7 +130,13 @@ def time_families(eng, step, steps, sync, cushions=2):
     return agg
 
 
-GEMM_KERNELS = (        # (kernel, tag prefix of Engine's KernelTimer, peak TFLOP/s, what it runs)
+GEMM_KERNELS = (        # (kernel, tag prefix of Engine's KernelTimer, peak TFLOP/s, what it runs); first match wins
+    ("gemm_bf16x3_pp_dwbwd_kernel<0>", "x3p ab+dwbwd", X3_PEAK_TFLOPS,
+     "data-gradient GEMM on 192x96 tiles with the depthwise backward as its epilogue (FLOPs: the GEMM's alone; the time also "
+     "holds the epilogue's one pass over x / dx, 8-16 B per element of HBM traffic)"),
+    ("gemm_bf16x3_pp_dwbwd_kernel<1>", "x3p aB+dwfwd", X3_PEAK_TFLOPS,
+     "inference forward GEMM on 192x96 tiles with BatchNorm affine + ReLU + the next layer's depthwise forward as its epilogue "
+     "(FLOPs: the GEMM's alone)"),
     ("gemm_bf16x3_pp_kernel", "x3p ", X3_PEAK_TFLOPS, "pointwise forward (+ BatchNorm sums) and data gradient from bf16 planes"),
     ("gemm_bf16x3_wgrad_kernel", "x3w ", X3_PEAK_TFLOPS, "pointwise weight gradients from the same planes (transposing LDS reads)"),
     ("gemm_bf16x3_fwd_kernel", "x3 ", X3_PEAK_TFLOPS, "pointwise forward on an fp32 A operand split in the kernel (strided residual convolutions)"),
@@ -144,12 +150,14 @@ def gemm_family_by_kernel(tim, steps):
     {kernel: {launches_per_step, ms_per_step, achieved, peak, frac, ...}}, the dominant kernel's name, and the family's
     time-weighted fraction sum_k(flops_k / peak_k) / sum_k(time_k)."""
     tot_n, tot_ms, tot_fl = tim.totals()["gemm"]
-    rows, seen = {}, [0, 0.0, 0.0]
+    rows, seen, taken = {}, [0, 0.0, 0.0], set()
     for kern, prefix, peak, what in GEMM_KERNELS:
         if prefix is None:
             n, ms, fl = tot_n - seen[0], tot_ms - seen[1], tot_fl - seen[2]
         else:
-            sel = [v for t, v in tim.tagged().items() if isinstance(t, tuple) and str(t[0]).startswith(prefix)]
+            hit = [t for t in tim.tagged() if isinstance(t, tuple) and str(t[0]).startswith(prefix) and t not in taken]
+            taken.update(hit)
+            sel = [tim.tagged()[t] for t in hit]
             n, ms, fl = (sum(v[i] for v in sel) for i in range(3))
             seen = [seen[0] + n, seen[1] + ms, seen[2] + fl]
         if n <= 0:
@@ -161,7 +169,10 @@ def gemm_family_by_kernel(tim, steps):
                       "frac": round(tf / peak, 4)}
     ideal_ms = sum(r["algorithmic_flops_per_launch"] * r["launches_per_step"] / (r["peak"] * 1e9) for r in rows.values())
     fam_ms = sum(r["ms_per_step"] for r in rows.values())
-    dominant = max(rows, key=lambda k: rows[k]["ms_per_step"])
+    # the dominant KERNEL: a single kernel, not the group row (a dozen gemm_f32_kernel<...> instantiations and the three
+    # conv3x3 kernels, the largest of them 0.27 ms per step in profiles/r05_*_step_table.txt)
+    single = [k for k, pre, _, _ in GEMM_KERNELS if pre is not None and k in rows]
+    dominant = max(single or rows, key=lambda k: rows[k]["ms_per_step"])
     return rows, dominant, round(ideal_ms / max(fam_ms, 1e-9), 4), (tot_n, tot_ms, tot_fl)
 
 
@@ -194,7 +205,8 @@ def gemm_roofline_block(tim, steps, traffic=None):
 
 FAMILY_OF = (("spnet_bn_", "bn"), ("spnet_maxpool", "pool"), ("spnet_avgpool", "pool"), ("spnet_gather_s2", "pool"),
              ("spnet_scatter_add_s2", "pool"), ("spnet_stem_head", "stem"), ("spnet_conv3x3_small", "stem"),
-             ("spnet_dropout", "stem"), ("spnet_adam_step", "optimizer"), ("spnet_dwconv", "dw"), ("spnet_gemm", "gemm"),
+             ("spnet_dropout", "stem"), ("spnet_adam_step", "optimizer"), ("spnet_adam_part", "optimizer"),
+             ("spnet_adam_l2_sum", "optimizer"), ("spnet_dwconv", "dw"), ("spnet_gemm", "gemm"),
              ("spnet_conv3x3_", "gemm"), ("spnet_reduce_slabs", "gemm"), ("spnet_split_bf16x3", "gemm"),
              ("spnet_transpose_batched", "gemm"), ("spnet_cutout", "augment"), ("spnet_saltpepper", "augment"),
              ("spnet_minmax", "augment"), ("spnet_gather_rows", "augment"), ("spnet_ellipse_loss", "loss"))
@@ -236,8 +248,10 @@ def algorithmic_bytes(name, a):
         B, Hh, Ww, C = a[2:6]
         o = B * ((Hh + 1) // 2) * ((Ww + 1) // 2) * C
         return f4 * o * (2 if name == "spnet_gather_s2" else 3)
-    if name == "spnet_adam_step":
+    if name in ("spnet_adam_step", "spnet_adam_part"):
         return 28 * a[4]                                                                # w, g, m, v read; w, m, v written
+    if name == "spnet_adam_l2_sum":
+        return 0
     if name == "spnet_dropout":
         return 2 * f4 * a[2]
     if name == "spnet_conv3x3_small":

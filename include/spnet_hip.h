@@ -405,6 +405,15 @@ int spnet_calc_errors(const float* yp, const float* yt, long N, int ncols, int* 
 int spnet_adam_step(float* p, const float* g, float* m, float* v, long n, long l2_n, float lr_t,
                     float beta1, float beta2, float eps, float l2, float grad_scale, const float* mask,
                     float* sq_scratch, float* l2_loss_out, const float* lr_t_dev, void* stream);
+/* The same step over a RANGE of the flat buffers (pointers to the range's first element, n % 4 == 0, l2_n = how many of
+ * its leading elements are l2-regularised): the Dense head's range is updated as soon as its gradient is final, underneath
+ * the backbone's backward; the rest when backward has ended.  Leaves spnet_adam_parts(n) sum-of-squares partials in
+ * sq_partial; spnet_adam_l2_sum folds the partials of every range of a step into l2_loss_out[0] = l2 * sum(w^2). */
+long spnet_adam_parts(long n);
+int spnet_adam_part(float* p, const float* g, float* m, float* v, long n, long l2_n, float lr_t, float beta1, float beta2,
+                    float eps, float l2, float grad_scale, const float* mask, float* sq_partial, const float* lr_t_dev,
+                    void* stream);
+int spnet_adam_l2_sum(const float* sq_partial, int count, float l2, float* l2_loss_out, void* stream);
 
 /* ---- input codec on the device (spnet/utils.py:340-342, load_X_one_proc) ------------------------------------------ */
 /* uint8 grey levels -> float32 network input, dst = (src / 255 - 0.5) * 2 with numpy's float32 roundings (bit-identical

@@ -123,6 +123,9 @@ _SIGS = {
     "spnet_ellipse_iou": (c_int, [P, P, c_long, c_int, c_int, P, P]),
     "spnet_calc_errors": (c_int, [P, P, c_long, c_int, P, P, P]),
     "spnet_adam_step": (c_int, [P, P, P, P, c_long, c_long, c_float, c_float, c_float, c_float, c_float, c_float, P, P, P, P, P]),
+    "spnet_adam_parts": (c_long, [c_long]),
+    "spnet_adam_part": (c_int, [P, P, P, P, c_long, c_long, c_float, c_float, c_float, c_float, c_float, c_float, P, P, P, P]),
+    "spnet_adam_l2_sum": (c_int, [P, c_int, c_float, P, P]),
     "spnet_u8_to_input": (c_int, [P, P, c_long, P]),
     "spnet_gather_rows": (c_int, [P, c_long, P, c_int, P, c_int, c_long, P]),
     "spnet_minmax": (c_int, [P, c_int, c_long, P, P, P]),

@@ -556,26 +556,30 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16x3_pp_dwbwd_kernel(
 // 36 KB).  An MFMA operand needs 8 consecutive PIXELS of one channel per lane -- a column of the image -- which
 // ds_read_b64_tr_b16 delivers (4 rows x 16 columns per 16 lanes, transposed; two reads per fragment; conflict-free under
 // the piece's swizzle: the two 16-lane groups of a half wave read rows 8 apart = the two 32-byte halves of the same
-// 64-byte segments).  Job b = {z planes, dy planes, dst} (three 64-bit words); blockIdx.y = job, blockIdx.z = K slice:
-// slice s of `ksplit` covers steps [s * per, (s + 1) * per) and writes dst + s * cin * cout (slabs for
-// spnet_reduce_slabs) -- deterministic either way.
+// 64-byte segments).  Job b = {z planes, dy planes, dst} (three 64-bit words).  Slice s of `ksplit` covers steps
+// [s * per, (s + 1) * per) and writes dst + s * cin * cout (slabs for spnet_reduce_slabs) -- deterministic either way.
+// One-dimensional grid of ksplit x nbatch x tiles workgroups, XCD-aware: the workgroups the dispatcher deals to one XCD
+// (id % 8) get a CONTIGUOUS range of (slice, job, tile) triples, tile fastest -- every tile of a job's slice streams the
+// same z and dy pixels, so they must share one L2.  (Round 5, PMC: with the remap applied per job -- eight tiles of each
+// job on every XCD -- each XCD fetched all of dy and the launch read 4.7 x its algorithmic bytes past the L2, 6 TB/s.)
 __global__ __launch_bounds__(256, 2) void gemm_bf16x3_wgrad_kernel(const long long* __restrict__ jobs, int cin, int cout, int M,
-                                                                   int tiles_n, int steps_per_slice) {
+                                                                   int tiles_n, int tiles, int nbatch, int steps_per_slice) {
   __shared__ __attribute__((aligned(16))) unsigned short smem[2 * X3_STEP];
-  const long long* jb = jobs + 3 * blockIdx.y;
+  const int wid = xcd_remap(blockIdx.x, gridDim.x);
+  const int lid = wid % tiles, job = (wid / tiles) % nbatch, slice = wid / (tiles * nbatch);
+  const long long* jb = jobs + 3 * job;
   const unsigned short* __restrict__ Zp = reinterpret_cast<const unsigned short*>(jb[0]);
   const unsigned short* __restrict__ Gp = reinterpret_cast<const unsigned short*>(jb[1]);
-  float* __restrict__ dst = reinterpret_cast<float*>(jb[2]) + (long)blockIdx.z * cin * cout;
+  float* __restrict__ dst = reinterpret_cast<float*>(jb[2]) + (long)slice * cin * cout;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
-  const int lid = xcd_remap(blockIdx.x, gridDim.x);
   const int tn = lid % tiles_n, tm = lid / tiles_n;
   const int m0 = tm * X3_BM, n0 = tn * X3_BN;             // first cin / cout of the tile
   const int nkz = (cin + 31) / 32, nkg = (cout + 31) / 32, rgm = (M + 15) / 16;
   const long z_ps = (long)rgm * nkz * 512, g_ps = (long)rgm * nkg * 512;
   const int nsteps_all = (M + 31) / 32;
-  const int s_beg = blockIdx.z * steps_per_slice, nsteps = min(steps_per_slice, nsteps_all - s_beg);
+  const int s_beg = slice * steps_per_slice, nsteps = min(steps_per_slice, nsteps_all - s_beg);
   const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc((void*)Zp, 0, (int)(3 * z_ps * 2), 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc((void*)Gp, 0, (int)(3 * g_ps * 2), 0x00020000);
   // piece c of an operand: plane c / 6, channel chunk (c % 6) / 2, row group half c % 2
@@ -942,7 +946,8 @@ extern "C" int spnet_gemm_bf16x3_wgrad_batched(const void* jobs, int nbatch, int
   const int per = (steps + ksplit - 1) / ksplit;
   if ((long)per * (ksplit - 1) >= steps) return (int)hipErrorInvalidValue;       // (an empty last slice)
   const int tm = spnet_cdiv(cin, X3_BM), tn = spnet_cdiv(cout, X3_BN);
-  hipLaunchKernelGGL(gemm_bf16x3_wgrad_kernel, dim3(tm * tn, nbatch, ksplit), dim3(256), 0, (hipStream_t)stream,
-                     reinterpret_cast<const long long*>(jobs), cin, cout, M, tn, per);
+  if ((long)tm * tn * nbatch * ksplit >= (1L << 31)) return (int)hipErrorInvalidValue;
+  hipLaunchKernelGGL(gemm_bf16x3_wgrad_kernel, dim3(tm * tn * nbatch * ksplit), dim3(256), 0, (hipStream_t)stream,
+                     reinterpret_cast<const long long*>(jobs), cin, cout, M, tn, tm * tn, nbatch, per);
   SPNET_RETURN_LAUNCH_STATUS();
 }

@@ -86,6 +86,32 @@ __global__ __launch_bounds__(256) void sum_partials_kernel(const float* __restri
 
 #define ADAM_BLOCKS 2048
 
+static int adam_grid(long n) {
+  long g4 = (n / 4 + 255) / 256;
+  return (int)(g4 > ADAM_BLOCKS ? ADAM_BLOCKS : (g4 < 1 ? 1 : g4));
+}
+
+// The optimizer step over a RANGE of the flat buffer (round 5): the caller passes pointers to the range's first element,
+// its length n (multiple of 4) and l2_n = how many of its leading elements are l2-regularised.  No reduction of the
+// sum-of-squares partials: spnet_adam_parts(n) floats are left in sq_partial, spnet_adam_l2_sum folds the partials of all
+// ranges of a step.  Lets the Dense head's 73 % of the parameters be updated as soon as their gradient is final -- on a
+// side stream underneath the backbone's backward -- while the rest waits for the end of backward.
+extern "C" long spnet_adam_parts(long n) { return n < 4 ? 0 : adam_grid(n); }
+extern "C" int spnet_adam_part(float* p, const float* g, float* m, float* v, long n, long l2_n, float lr_t, float beta1,
+                               float beta2, float eps, float l2, float grad_scale, const float* mask, float* sq_partial,
+                               const float* lr_t_dev, void* stream) {
+  if (n < 4 || (n & 3) || !p || !g || !m || !v) return (int)hipErrorInvalidValue;
+  hipLaunchKernelGGL(adam_l2_kernel, dim3(adam_grid(n)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, l2_n, lr_t, beta1,
+                     beta2, eps, l2, grad_scale, mask, sq_partial, lr_t_dev);
+  SPNET_RETURN_LAUNCH_STATUS();
+}
+// l2_loss_out[0] = l2 * sum of `count` partials (double accumulation, fixed order)
+extern "C" int spnet_adam_l2_sum(const float* sq_partial, int count, float l2, float* l2_loss_out, void* stream) {
+  if (!sq_partial || !l2_loss_out || count < 1) return (int)hipErrorInvalidValue;
+  hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, sq_partial, count, l2, l2_loss_out);
+  SPNET_RETURN_LAUNCH_STATUS();
+}
+
 // n must be a multiple of 4 (the flat buffer is padded).  sq_scratch: ADAM_BLOCKS floats.
 // l2_loss_out[0] = l2 * sum_{i<l2_n} p_i^2 evaluated BEFORE the update (the penalty of this step's loss).
 extern "C" int spnet_adam_step(float* p, const float* g, float* m, float* v, long n, long l2_n,

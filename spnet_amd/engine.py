@@ -480,7 +480,7 @@ def _glorot_fans(name, shape):
 class Engine:
     def __init__(self, H, W, batch, n_out=576, device="cuda:0", loss_type="same", seed=0,
                  train=True, adam_eps=1e-7, share_from=None, rank=0, sigmoid_cols=None, backbone="Xception",
-                 pointwise="bf16x3", x3_min_tiles=192, fuse_dw_bwd=True):
+                 pointwise="bf16x3", x3_min_tiles=192, fuse_dw_bwd=True, early_head=True):
         """rank: data-parallel rank, mixed into the initial dropout seed so that replicas draw different masks.
         pointwise: which kernel runs the forward and data-gradient GEMMs of the pointwise (1x1) convolutions with >= 256
         output columns -- "bf16x3" (csrc/gemm_bf16x3.hip: fp32 operands as three bf16 pieces on the bf16 matrix cores, fp32
@@ -499,6 +499,9 @@ class Engine:
         # inference counterpart: the consumer's depthwise forward inside the producer's forward GEMM (sepconv -> BN -> relu
         # -> sepconv chains of the middle flow / block 13-14 on 12 x 16 | 6 x 8 planes; spnet_gemm_bf16x3_pp_dwfwd)
         self.fuse_dw_fwd = bool(fuse_dw_bwd)
+        # the Dense head's weight gradient on the weight-gradient stream and its optimizer step right behind it, underneath
+        # the backbone's backward (adam_head_early) -- False: both on the dependency chain as in rounds 1-4 (A/B only)
+        self.early_head = bool(early_head)
         self.x3_min_tiles = int(x3_min_tiles)
         self.fuse_min_tiles = 256 if self.x3_min_tiles else 0       # (x3_min_tiles = 0, the parity tests: small plans fuse too)
         if not torch.cuda.is_available():
@@ -759,7 +762,13 @@ class Engine:
             self.dout = self.new(B, self.n_out)
             self.loss_parts = self.new(B, 5)
             self.loss_out = self.new(8)            # center,size,angle,noobj,class,total, l2, total+l2
-            self.sq_scratch = self.new(2048)
+            self.sq_scratch = self.new(2 * 2048)        # sum-of-squares partials of the optimizer's two ranges
+            off, n, _ = self.p_off["FinalOutput/kernel"]
+            self._head_hi = n if (off == 0 and n % 4 == 0) else 0
+            self._head_parts = int(L.spnet_adam_parts(self._head_hi))
+            self._rest_parts = int(L.spnet_adam_parts(self.n_theta - self._head_hi))
+            self._opt_stream = None
+            self._head_done = False
             # per-step scalars the kernels read from device memory: [lr_t (f32), dropout seed (u32)]
             self.step_params = torch.zeros(4, device=self.dev, dtype=torch.int32)
             self._step_upload = L.AsyncUploader(self.dev, depth=8)
@@ -806,9 +815,11 @@ class Engine:
         self._igraph.replay()
         return self.out
 
-    def backward(self, on_node_done=None):
+    def backward(self, on_node_done=None, after_head=None):
         """Back-propagates self.dout (filled by loss()) into self.grad.  on_node_done(node) is called
-        after each node's launches are enqueued (used to start the gradient all-reduce early)."""
+        after each node's launches are enqueued (used to start the gradient all-reduce early); after_head() once the
+        Dense head -- the first node of backward -- has been back-propagated (and its buckets launched): _step_body
+        starts the head's optimizer step there."""
         g = self.dout
         if self.sigmoid_cols is not None:      # through the sigmoid columns: dout *= y (1 - y)
             L.spnet_selective_sigmoid(L.ptr(self.out), L.ptr(self.dout), self.B, self.n_out, self.sigmoid_cols[0],
@@ -823,6 +834,8 @@ class Engine:
                 self.flush_deferred_wgrads()
             if on_node_done is not None:
                 on_node_done(node)
+            if after_head is not None and node is self.nodes[-1]:
+                after_head()
         self.flush_deferred_wgrads()
         self.reduce_depthwise_wgrads()
         if self.wgrad_stream is not None:      # every weight gradient must have landed before the optimizer
@@ -1037,16 +1050,56 @@ class Engine:
         self.drop_seed = int(seed) & 0xFFFFFFFF
         self._publish_step_params()
 
-    def adam_step(self, lr=None, grad_scale=1.0):
-        """Fused Keras-Adam + l2 over the flat buffers.  lr=None: the step size already sits in device
-        memory (train_step); a float: stand-alone use."""
+    def _adam_range(self, which, grad_scale):
+        """The fused Keras-Adam + l2 kernel over one of the optimizer's two ranges of the flat buffers: 0 = the Dense
+        head's kernel (offset 0, 73 % of the parameters at the benchmark geometry), 1 = everything else."""
         b1, b2 = 0.9, 0.999
+        lo, hi = (0, self._head_hi) if which == 0 else (self._head_hi, self.n_theta)
+        if hi <= lo:
+            return
+        mask = None if self.update_mask is None else self.update_mask.data_ptr() + 4 * lo
+        L.spnet_adam_part(self.theta.data_ptr() + 4 * lo, self.grad.data_ptr() + 4 * lo, self.m.data_ptr() + 4 * lo,
+                          self.v.data_ptr() + 4 * lo, hi - lo, max(0, min(self.l2_n, hi) - lo), 0.0, b1, b2, self.adam_eps,
+                          L2_COEF, grad_scale, mask, self.sq_scratch.data_ptr() + 4 * (0 if which == 0 else self._head_parts),
+                          self.lr_ptr, _stream())
+
+    def adam_head_early(self, grad_scale=1.0):
+        """The head range's optimizer step, launched from backward as soon as the head's gradient is final (the Dense
+        node is the first of backward; single-process training only): on a stream of its own, underneath the backbone's
+        backward.  Waits for the data-gradient GEMM that reads the head's weights (main stream) and for the
+        weight-gradient GEMM (weight-gradient stream).  One-stream plans (SPNET_OVERLAP_WGRAD=0, bench.py's roofline
+        leg) run it in line.  Measured (tools/ab_engine_flags.py early_head=True,False, one box): 10.000 against
+        10.048 ms per step -- the 0.34 ms of launches that leave the dependency chain come back as slower neighbours,
+        the step is bound by what its kernels move, not by their order."""
+        self._head_done = True
+        side = self.wgrad_stream
+        if side is None:
+            self._adam_range(0, grad_scale)
+            return
+        if self._opt_stream is None:
+            self._opt_stream = torch.cuda.Stream(device=self.dev)
+        opt = self._opt_stream
+        opt.wait_stream(torch.cuda.current_stream())
+        opt.wait_stream(side)
+        with torch.cuda.stream(opt):
+            self._adam_range(0, grad_scale)
+
+    def adam_step(self, lr=None, grad_scale=1.0):
+        """Fused Keras-Adam + l2 over the flat buffers, in two ranges (the Dense head's kernel; everything else) so that
+        the first can run early (adam_head_early) -- the same two launches, the same bits, wherever they run.
+        lr=None: the step size already sits in device memory (train_step); a float: stand-alone use."""
         if lr is not None:
             self._upload_step_params(lr)
         self._wver[0] += 1
-        L.spnet_adam_step(L.ptr(self.theta), L.ptr(self.grad), L.ptr(self.m), L.ptr(self.v), self.n_theta,
-                          self.l2_n, 0.0, b1, b2, self.adam_eps, L2_COEF, grad_scale, L.ptr(self.update_mask),
-                          L.ptr(self.sq_scratch), self.loss_out[6:].data_ptr(), self.lr_ptr, _stream())
+        if self._head_done:
+            if self._opt_stream is not None:
+                torch.cuda.current_stream().wait_stream(self._opt_stream)
+        else:
+            self._adam_range(0, grad_scale)
+        self._head_done = False
+        self._adam_range(1, grad_scale)
+        L.spnet_adam_l2_sum(L.ptr(self.sq_scratch), self._head_parts + self._rest_parts, L2_COEF, self.loss_out[6:].data_ptr(),
+                            _stream())
         self._tver[0] += 1
         self.refresh_transposes()
         # ... and the bf16x3 planes of the new weights, here and not lazily at the next forward: a captured train step
@@ -1088,10 +1141,12 @@ class Engine:
         self.forward(None, training=True)
         self.loss(None)
         if reducer is None:
-            self.backward()
             scale = 1.0 if scale is None else scale
+            self.backward(after_head=(lambda: self.adam_head_early(scale)) if self.early_head else None)
         else:
             reducer.side_stream = self.wgrad_stream
+            # (the head's optimizer step stays behind finish() here: launching it behind the head buckets' all-reduce is the
+            # same two launches, but nothing on the build's one-GPU boxes can time it against RCCL's channel kernels)
             self.backward(on_node_done=reducer.on_node_done)
             # (measurement hook: reducer.exposed = [] makes every step leave an event pair around finish() -- what the
             # main stream waits for the collectives AFTER backward has ended, i.e. the all-reduce time not hidden)
@@ -2719,7 +2774,14 @@ class Dense(Node):
 
     def bwd(self, g):
         e = self.e
-        _gemm(self.x, OUT_MAJOR, self.K, g, OUT_MAJOR, self.n_out, self.gw, self.n_out, self.K, self.n_out, e.B, e)
+        side = e.wgrad_stream if e.early_head else None
+        if side is None:
+            _gemm(self.x, OUT_MAJOR, self.K, g, OUT_MAJOR, self.n_out, self.gw, self.n_out, self.K, self.n_out, e.B, e)
+        else:       # the 226 MB weight gradient (an outer product over the batch: pure HBM writes) leaves the dependency chain
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                _gemm(self.x, OUT_MAJOR, self.K, g, OUT_MAJOR, self.n_out, self.gw, self.n_out, self.K, self.n_out, e.B, e,
+                      region=WS_GEMM2)
         L.spnet_reduce_rows(L.ptr(g), e.B, self.n_out, L.ptr(self.gb), _stream())
         _gemm(g, K_MAJOR, self.n_out, self.w, K_MAJOR, self.n_out, self.dx, self.K, e.B, self.K, self.n_out, e)
         return self.dx

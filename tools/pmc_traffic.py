@@ -21,6 +21,8 @@ FAMILIES = {
     # single kernels (bench.py quotes the dominant kernel's own traffic)
     "gemm_bf16x3_pp_kernel": ("gemm_bf16x3_pp_kernel",),
     "gemm_bf16x3_wgrad_kernel": ("gemm_bf16x3_wgrad_kernel",),
+    "gemm_bf16x3_pp_dwbwd_kernel<0>": ("gemm_bf16x3_pp_dwbwd_kernel<0",),
+    "gemm_bf16x3_pp_dwbwd_kernel<1>": ("gemm_bf16x3_pp_dwbwd_kernel<1",),
     "bn_bwd_fused_vec_kernel": ("bn_bwd_fused_vec_kernel",),
 }
 

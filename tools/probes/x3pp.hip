@@ -392,6 +392,136 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void x3pp2_kernel(const unsigned s
 #endif
 }
 
+// Bigger WAVE tiles (round 5, second half): per K step a CU needs as many LDS cycles (fragment reads 8 waves x 18 KB + the
+// DMA's 72 KB at 128 B per clock = 1,728 clocks) as MFMA cycles (108 per SIMD x 16 = 1,728): both pipes at ~67 % is what
+// 1.29 us per step is.  The MFMA work is fixed; the fragment traffic is not: a wave that owns TI x TJ MFMA tiles reads
+// (TI + TJ) x 3 KiB per step for TI x TJ x 6 MFMAs.  3 x 3 (48 x 48): 18 KB for 54; 6 x 3 (96 x 48): 27 KB for 108.
+// Tiled planes only; one wave per SIMD when the workgroup has four waves and OCC = 1 (accumulators in AGPRs, two fragment
+// register sets in VGPRs).
+template <int TI, int TJ, int WM, int WN, int OCC>
+__global__ __launch_bounds__(WM * WN * 64, OCC) void x3pp3_kernel(const unsigned short* __restrict__ Ap, long a_ps,
+                                                         const unsigned short* __restrict__ Bp, long b_ps,
+                                                         float* __restrict__ C, int ldc, int M, int N, int Kp, int tiles_n) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  constexpr int BM = 16 * TI * WM, BN = 16 * TJ * WN, NW = WM * WN;
+  constexpr int STEP = 3 * (BM + BN) * PP_LDR;
+  constexpr int PIECES = 3 * (BM + BN) / 16, PA = 3 * BM / 16, PER = (PIECES + NW - 1) / NW;
+  extern __shared__ __attribute__((aligned(16))) unsigned short smem3[];
+  unsigned short* smem = smem3;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN, wn = wave % WN;
+  const int lid = xcd_remap(blockIdx.x, gridDim.x);
+  const int tn = lid % tiles_n, tm = lid / tiles_n;
+  const int m0 = tm * BM, n0 = tn * BN;
+  const int nk = Kp / 32;
+  const int rg_a = (M + 15) / 16, rg_b = (N + 15) / 16;
+  const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc((void*)Ap, 0, (int)(3 * a_ps * 2), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc((void*)Bp, 0, (int)(3 * b_ps * 2), 0x00020000);
+  int soff[PER];
+#pragma unroll
+  for (int i = 0; i < PER; ++i) {
+    const int c = min(wave + NW * i, PIECES - 1);
+    soff[i] = c < PA ? (int)((c / (BM / 16)) * a_ps + (long)min(m0 / 16 + c % (BM / 16), rg_a - 1) * nk * 512) * 2
+                     : (int)(((c - PA) / (BN / 16)) * b_ps + (long)min(n0 / 16 + (c - PA) % (BN / 16), rg_b - 1) * nk * 512) * 2;
+  }
+#define PP3_ISSUE(KS_, BUF_)                                                                                   \
+  do {                                                                                                         \
+    unsigned short* base_ = smem + ((BUF_) & 1) * STEP;                                                        \
+    _Pragma("unroll") for (int i = 0; i < PER; ++i) {                                                          \
+      const int c = min(wave + NW * i, PIECES - 1);                                                            \
+      const bool is_a = (NW * i + NW - 1 < PA) ? true : (NW * i >= PA) ? false : (c < PA);                     \
+      const __amdgpu_buffer_rsrc_t rs_ = is_a ? rs_a : rs_b;                                                   \
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_, (lds_ptr_t)(base_ + c * 512), 16, lane * 16,               \
+                                               soff[i] + (KS_) * 1024, 0, 0);                                  \
+    }                                                                                                          \
+  } while (0)
+  f32x4v acc[TI][TJ];
+#pragma unroll
+  for (int i = 0; i < TI; ++i)
+#pragma unroll
+    for (int j = 0; j < TJ; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[i][j][r] = 0.f;
+  const int p16 = lane & 15, kg = lane >> 4;
+  constexpr int TA[6] = {2, 1, 0, 1, 0, 0}, TB[6] = {0, 1, 2, 0, 1, 0};
+  const int a_off = (wm * 16 * TI + p16) * PP_LDR + PP_SWZ(p16, kg);
+  const int b_off = (3 * BM + wn * 16 * TJ + p16) * PP_LDR + PP_SWZ(p16, kg);
+#define PP3_READ(KS_, FA_, FB_)                                                                                \
+  do {                                                                                                         \
+    const unsigned short* base_ = smem + ((KS_) & 1) * STEP;                                                   \
+    _Pragma("unroll") for (int p = 0; p < 3; ++p) {                                                            \
+      _Pragma("unroll") for (int t = 0; t < TI; ++t)                                                           \
+        FA_[t][p] = *reinterpret_cast<const bf16x8*>(base_ + a_off + (p * BM + t * 16) * PP_LDR);              \
+      _Pragma("unroll") for (int t = 0; t < TJ; ++t)                                                           \
+        FB_[t][p] = *reinterpret_cast<const bf16x8*>(base_ + b_off + (p * BN + t * 16) * PP_LDR);              \
+    }                                                                                                          \
+  } while (0)
+#define PP3_MFMA(FA_, FB_)                                                                                     \
+  _Pragma("unroll") for (int t = 0; t < 6; ++t)                                                                \
+  _Pragma("unroll") for (int i = 0; i < TI; ++i)                                                               \
+  _Pragma("unroll") for (int j = 0; j < TJ; ++j)                                                               \
+      acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(FA_[i][TA[t]], FB_[j][TB[t]], acc[i][j], 0, 0, 0)
+  constexpr int NMF = 6 * TI * TJ, NRD = 3 * (TI + TJ);
+  constexpr int PER_RD = NMF / NRD;                      // MFMAs per fragment read
+#define PP3_BODY(KS_, CA_, CB_, NA_, NB_, DMA_, RD_)                                                           \
+  do {                                                                                                         \
+    __syncthreads();                                                                                           \
+    if (DMA_) PP3_ISSUE((KS_) + 2, (KS_));                                                                      \
+    if (RD_) PP3_READ((KS_) + 1, NA_, NB_);                                                                    \
+    PP3_MFMA(CA_, CB_);                                                                                        \
+    if ((DMA_) && (RD_)) {                                                                                     \
+      _Pragma("unroll") for (int g = 0; g < NRD; ++g) {                                                        \
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                                     \
+        if (g % 2 == 0 && g / 2 < PER) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                      \
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                                     \
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                                     \
+        __builtin_amdgcn_sched_group_barrier(0x008, PER_RD - 2, 0);                                            \
+      }                                                                                                        \
+    }                                                                                                          \
+    __builtin_amdgcn_sched_barrier(0);                                                                         \
+  } while (0)
+  bf16x8 xa[TI][3], xb[TJ][3], ya[TI][3], yb[TJ][3];
+  PP3_ISSUE(0, 0);
+  if (nk > 1) {
+    PP3_ISSUE(1, 1);
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER) : "memory");
+  } else {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  __builtin_amdgcn_s_barrier();
+  PP3_READ(0, xa, xb);
+  int ks = 0;
+  for (; ks + 3 < nk; ks += 2) {
+    PP3_BODY(ks, xa, xb, ya, yb, true, true);
+    PP3_BODY(ks + 1, ya, yb, xa, xb, true, true);
+  }
+  for (; ks < nk; ks += 2) {
+    if (ks + 2 < nk) PP3_BODY(ks, xa, xb, ya, yb, true, true);
+    else if (ks + 1 < nk) PP3_BODY(ks, xa, xb, ya, yb, false, true);
+    else PP3_BODY(ks, xa, xb, ya, yb, false, false);
+    if (ks + 1 < nk) {
+      if (ks + 3 < nk) PP3_BODY(ks + 1, ya, yb, xa, xb, true, true);
+      else if (ks + 2 < nk) PP3_BODY(ks + 1, ya, yb, xa, xb, false, true);
+      else PP3_BODY(ks + 1, ya, yb, xa, xb, false, false);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < TI; ++i)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = m0 + (wm * TI + i) * 16 + kg * 4 + r;
+      if (row < M) {
+#pragma unroll
+        for (int j = 0; j < TJ; ++j) {
+          const int col = n0 + (wn * TJ + j) * 16 + p16;
+          if (col < N) C[(long)row * ldc + col] = acc[i][j][r];
+        }
+      }
+    }
+#endif
+}
+
 // The product kernel (csrc/gemm_bf16x3.hip: fp32 A split in the kernel) with B read from TILED planes: same registers,
 // same stores, but a wave's B load reads 1 KiB of contiguous memory.
 // Two fp32 -> two bf16 (round to nearest even) in one v_cvt_pk_bf16_f32; the pieces of a pair come back as floats by a
@@ -683,6 +813,26 @@ extern "C" int probe_x3pp(int variant, const void* Ap, long a_ps, int lda, const
       const int tm = spnet_cdiv(M, 96), tn = spnet_cdiv(N, 96);
       hipLaunchKernelGGL(x3ab_kernel, dim3(tm * tn), dim3(256), 0, st, (const float*)Ap, lda, b, Kp, C, ldc, M, N, lda, tn, (float*)nullptr);
     } break;
+#define PP3_LAUNCH(TI_, TJ_, WM_, WN_, OCC_)                                                                   \
+  do {                                                                                                         \
+    constexpr int bm_ = 16 * TI_ * WM_, bn_ = 16 * TJ_ * WN_;                                                  \
+    constexpr int lds_ = 2 * 3 * (bm_ + bn_) * PP_LDR * 2;                                                     \
+    const int tm = spnet_cdiv(M, bm_), tn = spnet_cdiv(N, bn_);                                                \
+    static bool once_ = false;                                                                                 \
+    if (!once_) {                                                                                              \
+      (void)hipFuncSetAttribute((const void*)x3pp3_kernel<TI_, TJ_, WM_, WN_, OCC_>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_); \
+      once_ = true;                                                                                            \
+    }                                                                                                          \
+    hipLaunchKernelGGL((x3pp3_kernel<TI_, TJ_, WM_, WN_, OCC_>), dim3(tm * tn), dim3(64 * WM_ * WN_), lds_, st, a, a_ps, b, b_ps, \
+                       C, ldc, M, N, Kp, tn);                                                                  \
+  } while (0)
+    case 30: PP3_LAUNCH(3, 3, 2, 2, 2); break;   // = v11 (check of the generalisation)
+    case 31: PP3_LAUNCH(6, 3, 2, 2, 1); break;   // 192 x 96, four waves of 96 x 48, one per SIMD
+    case 32: PP3_LAUNCH(6, 3, 1, 2, 1); break;   // 96 x 96, two waves of 96 x 48, two workgroups per CU (one wave per SIMD)
+    case 33: PP3_LAUNCH(3, 6, 2, 2, 1); break;   // 96 x 192, four waves of 48 x 96
+    case 34: PP3_LAUNCH(6, 4, 2, 2, 1); break;   // 192 x 128, four waves of 96 x 64
+    case 35: PP3_LAUNCH(4, 4, 2, 2, 1); break;   // 128 x 128, four waves of 64 x 64
+    case 36: PP3_LAUNCH(3, 3, 4, 2, 1); break;   // 192 x 96, eight waves of 48 x 48 (= v15)
     case 10: PP2_LAUNCH(2, 2, 1, 0); break;      // tiled planes, simple loop
     case 11: PP2_LAUNCH(2, 2, 1, 1); break;      // tiled planes, pipelined
     case 12: PP2_LAUNCH(2, 4, 1, 0); break;

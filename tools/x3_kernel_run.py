@@ -14,6 +14,13 @@ Kp = int(L.spnet_bf16x3_kp(K))
 planes = torch.zeros(3 * int(L.spnet_bf16x3_plane_elems(N, K)), dtype=torch.int16, device="cuda")
 L.spnet_split_bf16x3(w.data_ptr(), planes.data_ptr(), K, N, st())
 c = torch.empty(M, N, device="cuda")
+ap = []
+for x in a:                                    # A as planes in 1-KiB pieces (what the depthwise kernels write in the product)
+    pl = torch.zeros(3 * int(L.spnet_bf16x3_plane_elems(M, K)), dtype=torch.int16, device="cuda")
+    L.spnet_split_rows_bf16x3(x.data_ptr(), K, pl.data_ptr(), M, K, st())
+    ap.append(pl)
+for i in range(20):
+    L.spnet_gemm_bf16x3_pp(ap[i % 4].data_ptr(), planes.data_ptr(), c.data_ptr(), N, M, N, K, None, 0, st())
 for i in range(20):
     L.spnet_gemm_bf16x3_fwd(a[i % 4].data_ptr(), K, planes.data_ptr(), c.data_ptr(), N, M, N, K, st())
 for i in range(20):

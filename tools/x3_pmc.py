@@ -33,14 +33,15 @@ for gi, g in enumerate(groups):
         continue
     for f in glob.glob(d + "/*/*_counter_collection.csv"):
         for row in csv.DictReader(open(f)):
-            kn = "bf16x3" if "gemm_bf16x3" in row["Kernel_Name"] else "f32" if "gemm_f32" in row["Kernel_Name"] else None
+            kn = "pp" if "gemm_bf16x3_pp_kernel" in row["Kernel_Name"] else "bf16x3" if "gemm_bf16x3_fwd" in row["Kernel_Name"] \
+                else "f32" if "gemm_f32" in row["Kernel_Name"] else None
             if kn:
                 e = table.setdefault((kn, row["Counter_Name"]), [0.0, set()])
                 e[0] += float(row["Counter_Value"])
                 e[1].add(row["Dispatch_Id"])
 with open(os.path.join(out, "x3_pmc_table.txt"), "w") as fh:
-    for line in ["%-32s %16s %16s   (per launch, 6144 x 728 x 728)" % ("counter", "bf16x3", "exact fp32")] + [
-            "%-32s %16.0f %16.0f" % (c, *(table.get((k, c), [0, {0}])[0] / max(1, len(table.get((k, c), [0, {0}])[1])) for k in ("bf16x3", "f32")))
+    for line in ["%-32s %16s %16s %16s   (per launch, 6144 x 728 x 728)" % ("counter", "planes x planes", "fp32 A (round 4)", "exact fp32")] + [
+            "%-32s %16.0f %16.0f %16.0f" % (c, *(table.get((k, c), [0, {0}])[0] / max(1, len(table.get((k, c), [0, {0}])[1])) for k in ("pp", "bf16x3", "f32")))
             for c in sorted({c for _, c in table})]:
         print(line)
         fh.write(line + "\n")
