@@ -248,6 +248,34 @@ def test_one_stream_step_equals_two_stream_step(monkeypatch):
         assert torch.equal(a, c)
 
 
+def test_early_head_optimizer_step_equals_the_step_at_the_end():
+    """Engine(early_head=True) -- the Dense head's weight gradient on the weight-gradient stream and its range of the
+    optimizer step on a third stream right behind it, underneath the backbone's backward -- against early_head=False (both
+    on the main stream, the optimizer's two launches after backward): the same launches in another order, so weights, Adam
+    moments, losses (incl. the l2 penalty the optimizer kernel sums) of three steps are bit-identical; eager and as a
+    captured graph."""
+    _need_gpu()
+    from spnet_amd.engine import Engine
+    h, w, b = 96, 128, 2
+    rs = np.random.RandomState(9)
+    X = torch.tensor(rs.rand(b, h, w, 1) * 2 - 1, dtype=torch.float32).cuda()
+    Y = torch.tensor(rs.rand(b, 576), dtype=torch.float32).cuda()
+    res = []
+    for early, graph in ((True, False), (False, False), (True, True)):
+        eng = Engine(h, w, b, device="cuda:0", seed=13, early_head=early)
+        eng.use_graph = graph
+        assert eng._head_hi > 0 and eng._head_hi % 4 == 0 and eng._head_hi == eng.p_off["FinalOutput/kernel"][1]
+        losses = [eng.train_step(X, Y, 1e-3)[:7].clone() for _ in range(4)]
+        torch.cuda.synchronize()
+        assert (eng._graph is not None) == graph
+        assert (eng._opt_stream is not None) == early
+        res.append((eng.theta.clone(), eng.m.clone(), eng.v.clone(), torch.stack(losses)))
+    for other in res[1:]:
+        for a, c in zip(res[0], other):
+            assert torch.equal(a, c)
+    assert float(res[0][3][-1, 6]) > 0          # the l2 penalty of the regularised kernels, folded over both ranges
+
+
 def test_graph_capture_survives_garbage_of_an_earlier_plan():
     """The abort of round 3 (`Fatal Python error: Aborted ... Garbage-collecting` under predict_step), reproduced on
     purpose in a child process: an earlier plan's graph / streams / events reachable only through reference cycles, the

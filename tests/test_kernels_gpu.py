@@ -1189,6 +1189,44 @@ def test_adam_matches_keras_form(L):
     close(l2out[0], 1e-4 * np.sum(p[:l2n].astype(np.float64) ** 2), rtol=1e-5, atol=0)
 
 
+def test_adam_in_two_ranges_equals_the_one_launch_step(L):
+    """spnet_adam_part over [0, cut) and [cut, n) + spnet_adam_l2_sum (the engine's optimizer step: the Dense head's range
+    early, the rest at the end of backward) against spnet_adam_step over the whole buffer: parameters and moments bit for bit
+    (the update is element-wise), the l2 penalty to rounding (its partial sums are cut differently); l2 prefix ending inside
+    either range, with and without a frozen-element mask."""
+    rs = np.random.RandomState(11)
+    n = 300_000
+    p, g = rs.randn(n).astype(np.float32), (rs.randn(n) * 0.1).astype(np.float32)
+    m, v = (rs.randn(n) * 0.01).astype(np.float32), (rs.rand(n) * 0.01).astype(np.float32)
+    mask = (rs.rand(n) > 0.3).astype(np.float32)
+    lr_dev = torch.full((1,), 2.5e-4, device="cuda")
+    for cut, l2n, use_mask in ((200_000, 120_000, False), (200_000, 250_004, True), (4, 2, True), (n - 4, n, False)):
+        one = [dev(a) for a in (p, g, m, v)]
+        two = [dev(a) for a in (p, g, m, v)]
+        md = dev(mask)
+        mp = md.data_ptr() if use_mask else None
+        sq1, l2a = torch.empty(2048, device="cuda"), torch.zeros(2, device="cuda")
+        L.spnet_adam_step(*(t.data_ptr() for t in one), n, l2n, 0.0, 0.9, 0.999, 1e-7, 1e-4, 0.5, mp, sq1.data_ptr(),
+                          l2a.data_ptr(), lr_dev.data_ptr(), st())
+        parts = [int(L.spnet_adam_parts(cut)), int(L.spnet_adam_parts(n - cut))]
+        assert all(0 < q <= 2048 for q in parts)
+        sq2, l2b = torch.empty(4096, device="cuda"), torch.zeros(2, device="cuda")
+        for lo, hi, so in ((0, cut, 0), (cut, n, parts[0])):
+            L.spnet_adam_part(*(t.data_ptr() + 4 * lo for t in two), hi - lo, max(0, min(l2n, hi) - lo), 0.0, 0.9, 0.999, 1e-7,
+                              1e-4, 0.5, None if mp is None else mp + 4 * lo, sq2.data_ptr() + 4 * so, lr_dev.data_ptr(), st())
+        L.spnet_adam_l2_sum(sq2.data_ptr(), sum(parts), 1e-4, l2b.data_ptr(), st())
+        torch.cuda.synchronize()
+        for a, b, name in zip(one, two, "pgmv"):
+            assert torch.equal(a, b), (name, cut, l2n)
+        assert not torch.equal(one[0], dev(p))
+        close(l2b[0], 1e-4 * np.sum(p[:l2n].astype(np.float64) ** 2), rtol=1e-5, atol=0)
+        close(l2b[0], l2a[0], rtol=1e-6, atol=0)
+    assert int(L.spnet_adam_parts(0)) == 0
+    with pytest.raises(L.HipError):
+        L.spnet_adam_part(one[0].data_ptr(), one[1].data_ptr(), one[2].data_ptr(), one[3].data_ptr(), 6, 0, 0.0, 0.9, 0.999,
+                          1e-7, 1e-4, 1.0, None, sq2.data_ptr(), None, st())
+
+
 def test_adam_many_steps_full_size_with_mask_and_device_lr(L):
     """The optimizer path to rounding, at scale: 3.1 M parameters (ragged vector tail), l2 prefix, frozen-element mask,
     gradient scale (1/world), the step size read from device memory (train_step's path), five consecutive steps against

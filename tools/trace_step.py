@@ -1,11 +1,14 @@
 #!/usr/bin/env python3
 """Dev tool: per-kernel table of ONE train step out of a rocprofv3 --kernel-trace CSV (steps are delimited
-by the adam_l2_kernel launches).  usage: trace_step.py <kernel_trace.csv> [step_index]"""
+by the optimizer's closing sum_partials_kernel launch: since round 5 a step holds two adam_l2_kernel launches -- the Dense
+head's range and the rest).  usage: trace_step.py <kernel_trace.csv> [step_index]"""
 import collections, csv, re, sys
 
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-idx = [i for i, r in enumerate(rows) if r["Kernel_Name"].startswith("adam_l2")]
+idx = [i for i, r in enumerate(rows) if r["Kernel_Name"].startswith("sum_partials_kernel")]
+if len(idx) < 2:
+    idx = [i for i, r in enumerate(rows) if r["Kernel_Name"].startswith("adam_l2")]
 k = int(sys.argv[2]) if len(sys.argv) > 2 else 3
 seg = rows[idx[k] + 1: idx[k + 1] + 1]
 span = (int(seg[-1]["End_Timestamp"]) - int(rows[idx[k]]["End_Timestamp"])) / 1e6
