@@ -1220,7 +1220,7 @@ def test_adam_in_two_ranges_equals_the_one_launch_step(L):
             assert torch.equal(a, b), (name, cut, l2n)
         assert not torch.equal(one[0], dev(p))
         close(l2b[0], 1e-4 * np.sum(p[:l2n].astype(np.float64) ** 2), rtol=1e-5, atol=0)
-        close(l2b[0], l2a[0], rtol=1e-6, atol=0)
+        close(l2b[0], float(l2a[0]), rtol=2e-6, atol=0)
     assert int(L.spnet_adam_parts(0)) == 0
     with pytest.raises(L.HipError):
         L.spnet_adam_part(one[0].data_ptr(), one[1].data_ptr(), one[2].data_ptr(), one[3].data_ptr(), 6, 0, 0.0, 0.9, 0.999,

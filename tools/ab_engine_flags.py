@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Dev tool (GPU box): the benchmark train step (Xception, batch 32, 384x512, fixed frames) on two engines that differ in one
 constructor flag, alternating in ONE process (cdna_hip_programming.md rule 24).
-usage: ab_engine_flags.py flag=valueA,valueB [rounds] [steps]     e.g.  fuse_dw_bwd=True,False"""
+usage: ab_engine_flags.py flag=valueA,valueB [rounds] [steps]     e.g.  fuse_dw_bwd=True,False
+       ab_engine_flags.py attr:name=valueA,valueB ...             sets an attribute after construction (attr:use_graph=True,False)"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -11,7 +12,12 @@ flag, vals = sys.argv[1].split("=")
 vals = [eval(v) for v in vals.split(",")]
 rounds = int(sys.argv[2]) if len(sys.argv) > 2 else 4
 steps = int(sys.argv[3]) if len(sys.argv) > 3 else 30
-engs = [Engine(384, 512, 32, device="cuda:0", seed=0, **{flag: v}) for v in vals]
+if flag.startswith("attr:"):
+    engs = [Engine(384, 512, 32, device="cuda:0", seed=0) for v in vals]
+    for e, v in zip(engs, vals):
+        setattr(e, flag[5:], v)
+else:
+    engs = [Engine(384, 512, 32, device="cuda:0", seed=0, **{flag: v}) for v in vals]
 X = torch.rand(32, 384, 512, 1, device="cuda") * 2 - 1
 Y = torch.rand(32, 576, device="cuda")
 res = [[] for _ in vals]
