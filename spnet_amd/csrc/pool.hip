@@ -124,32 +124,57 @@ __global__ __launch_bounds__(256) void maxpool_bwd_bnsums_kernel(const float* __
     const float4 mu = *reinterpret_cast<const float4*>(mean + c4 * 4);
     const float4 is = *reinterpret_cast<const float4*>(invstd + c4 * 4);
     const long npix = (long)Bn * H * W;
-    for (long r = (long)blockIdx.y * blockDim.y + threadIdx.y; r < npix; r += (long)gridDim.y * blockDim.y) {
+    // The windows that contain (h, w): rows oh1 = (h + pt) / 2 (tap row kh1 = (h + pt) % 2) and, when kh1 == 0, oh1 - 1
+    // (tap row 2); columns likewise.  All four candidates are fetched at once -- clamped addresses, no branches -- and
+    // added in maxpool_bwd_kernel's order (oh ascending, ow ascending; a candidate that does not exist adds 0): 0.317 ->
+    // 0.261 ms per step over the four pooling layers (two pixels per trip measured slower: 0.280).
+    struct Px {
+      float4 v, g00, g01, g10, g11;
+      uint32_t i00, i01, i10, i11, kh1, kw1;
+      bool v00, v01, v10, v11;
+    };
+    auto fetch = [&](long r, Px& p) {
       const int w = (int)(r % W);
-      long t = r / W;
+      const long t = r / W;
       const int h = (int)(t % H);
       const int b = (int)(t / H);
-      const float4 v = *reinterpret_cast<const float4*>(yp + r * C + c4 * 4);
+      p.v = *reinterpret_cast<const float4*>(yp + r * C + c4 * 4);
+      const int hp = h + pt, wp = w + pl;
+      const int oh1 = hp >> 1, ow1 = wp >> 1;
+      p.kh1 = hp & 1;
+      p.kw1 = wp & 1;
+      const bool vh1 = oh1 < OH, vh0 = p.kh1 == 0 && oh1 >= 1, vw1 = ow1 < OW, vw0 = p.kw1 == 0 && ow1 >= 1;
+      p.v00 = vh0 && vw0; p.v01 = vh0 && vw1; p.v10 = vh1 && vw0; p.v11 = vh1 && vw1;
+      const int oh0 = max(oh1 - 1, 0), ow0 = max(ow1 - 1, 0), oh1c = min(oh1, OH - 1), ow1c = min(ow1, OW - 1);
+      const long rb = (long)b * OH;
+      const long o00 = ((rb + oh0) * OW + ow0) * c4n + c4, o01 = ((rb + oh0) * OW + ow1c) * c4n + c4;
+      const long o10 = ((rb + oh1c) * OW + ow0) * c4n + c4, o11 = ((rb + oh1c) * OW + ow1c) * c4n + c4;
+      p.i00 = idx4[o00]; p.i01 = idx4[o01]; p.i10 = idx4[o10]; p.i11 = idx4[o11];
+      p.g00 = *reinterpret_cast<const float4*>(dy + o00 * 4); p.g01 = *reinterpret_cast<const float4*>(dy + o01 * 4);
+      p.g10 = *reinterpret_cast<const float4*>(dy + o10 * 4); p.g11 = *reinterpret_cast<const float4*>(dy + o11 * 4);
+    };
+    auto sum = [&](long r, const Px& p) {
       float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-      const int oh_lo = max(0, (h + pt - 2 + 1) >> 1), oh_hi = min(OH - 1, (h + pt) >> 1);
-      const int ow_lo = max(0, (w + pl - 2 + 1) >> 1), ow_hi = min(OW - 1, (w + pl) >> 1);
-      for (int oh = oh_lo; oh <= oh_hi; ++oh) {
-        const uint32_t kh = h - (oh * 2 - pt);
-        for (int ow = ow_lo; ow <= ow_hi; ++ow) {
-          const uint32_t tap = kh * 3 + (w - (ow * 2 - pl));
-          const long o = (((long)b * OH + oh) * OW + ow) * c4n + c4;
-          const uint32_t id = idx4[o];
-          const float4 g = *reinterpret_cast<const float4*>(dy + o * 4);
-          if ((id & 0xffu) == tap) s.x += g.x;
-          if (((id >> 8) & 0xffu) == tap) s.y += g.y;
-          if (((id >> 16) & 0xffu) == tap) s.z += g.z;
-          if ((id >> 24) == tap) s.w += g.w;
-        }
-      }
+      auto take = [&](bool valid, uint32_t id, const float4 g, uint32_t tap) {
+        s.x += (valid && (id & 0xffu) == tap) ? g.x : 0.f;
+        s.y += (valid && ((id >> 8) & 0xffu) == tap) ? g.y : 0.f;
+        s.z += (valid && ((id >> 16) & 0xffu) == tap) ? g.z : 0.f;
+        s.w += (valid && (id >> 24) == tap) ? g.w : 0.f;
+      };
+      take(p.v00, p.i00, p.g00, 2 * 3 + 2);
+      take(p.v01, p.i01, p.g01, 2 * 3 + p.kw1);
+      take(p.v10, p.i10, p.g10, p.kh1 * 3 + 2);
+      take(p.v11, p.i11, p.g11, p.kh1 * 3 + p.kw1);
       *reinterpret_cast<float4*>(dx + r * C + c4 * 4) = s;
+      const float4 v = p.v;
       s0.x += s.x; s0.y += s.y; s0.z += s.z; s0.w += s.w;
       s1.x = fmaf(s.x, (v.x - mu.x) * is.x, s1.x); s1.y = fmaf(s.y, (v.y - mu.y) * is.y, s1.y);
       s1.z = fmaf(s.z, (v.z - mu.z) * is.z, s1.z); s1.w = fmaf(s.w, (v.w - mu.w) * is.w, s1.w);
+    };
+    for (long r = (long)blockIdx.y * blockDim.y + threadIdx.y; r < npix; r += (long)gridDim.y * blockDim.y) {
+      Px p;
+      fetch(r, p);
+      sum(r, p);
     }
   }
   const int bx = blockDim.x, by = blockDim.y;

@@ -50,6 +50,74 @@ __global__ __launch_bounds__(256) void conv3x3_small_fwd_kernel(const float* __r
   }
 }
 
+// The two 3 -> 3 stem convolutions ('same', stride 1), forward and data gradient, round 5: a thread owns a RUN of four
+// pixels of one image row.  Per tap row it loads the run as three aligned 16-byte words plus the pixel on either side
+// (two 12-byte loads) -- 15 loads per four pixels where one thread per pixel issued 108 -- and the 81 weights sit in scalar
+// registers (uniform loads from constant indices) instead of LDS.  Every output's fmaf chain keeps the order of
+// conv3x3_small_{fwd,bwd_data}_kernel (tap rows, tap columns, then channels), so the results are theirs bit for bit;
+// the taps that fall outside the image multiply a zero input instead of being skipped.  W % 4 == 0.
+//   BWD = 0:  y[p][co]  = sum_{kh,kw,ci} x[h + kh - 1][w + kw - 1][ci] * k[kh][kw][ci][co]
+//   BWD = 1:  dx[p][ci] = sum_{kh,kw,co} dy[h + 1 - kh][w + 1 - kw][co] * k[kh][kw][ci][co]
+struct c3_px { float c[3]; };
+template <int BWD>
+__global__ __launch_bounds__(256) void conv3x3_c3_run4_kernel(const float* __restrict__ in, const float* __restrict__ k,
+                                                              float* __restrict__ out, int Bn, int H, int W) {
+  const int runs_w = W >> 2;
+  const long total = (long)Bn * H * runs_w;
+  for (long q = (long)xcd_remap(blockIdx.x, gridDim.x) * blockDim.x + threadIdx.x; q < total;
+       q += (long)gridDim.x * blockDim.x) {
+    const int rw = (int)(q % runs_w);
+    const long t = q / runs_w;
+    const int h = (int)(t % H);
+    const long img = t / H;
+    const int w0 = rw * 4;
+    float acc[4][3];
+#pragma unroll
+    for (int p = 0; p < 4; ++p)
+#pragma unroll
+      for (int c = 0; c < 3; ++c) acc[p][c] = 0.f;
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh) {
+      const int rr = BWD ? h + 1 - kh : h + kh - 1;
+      if (rr < 0 || rr >= H) continue;
+      const float* rp = in + ((img * H + rr) * W + w0) * 3;
+      float v[18];                                 // pixels w0 - 1 .. w0 + 4, three channels each
+      const float4 a0 = *reinterpret_cast<const float4*>(rp), a1 = *reinterpret_cast<const float4*>(rp + 4),
+                   a2 = *reinterpret_cast<const float4*>(rp + 8);
+      v[3] = a0.x; v[4] = a0.y; v[5] = a0.z; v[6] = a0.w; v[7] = a1.x; v[8] = a1.y; v[9] = a1.z; v[10] = a1.w;
+      v[11] = a2.x; v[12] = a2.y; v[13] = a2.z; v[14] = a2.w;
+      c3_px l = {{0.f, 0.f, 0.f}}, r = {{0.f, 0.f, 0.f}};
+      if (w0 > 0) l = *reinterpret_cast<const c3_px*>(rp - 3);
+      if (w0 + 4 < W) r = *reinterpret_cast<const c3_px*>(rp + 12);
+      v[0] = l.c[0]; v[1] = l.c[1]; v[2] = l.c[2]; v[15] = r.c[0]; v[16] = r.c[1]; v[17] = r.c[2];
+#pragma unroll
+      for (int kw = 0; kw < 3; ++kw) {
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+          const int px = BWD ? p + 2 - kw : p + kw;          // index of the input pixel in v (pixel w0 - 1 is 0)
+          if (!BWD) {
+#pragma unroll
+            for (int ci = 0; ci < 3; ++ci)
+#pragma unroll
+              for (int co = 0; co < 3; ++co)
+                acc[p][co] = fmaf(v[px * 3 + ci], k[((kh * 3 + kw) * 3 + ci) * 3 + co], acc[p][co]);
+          } else {
+#pragma unroll
+            for (int co = 0; co < 3; ++co)
+#pragma unroll
+              for (int ci = 0; ci < 3; ++ci)
+                acc[p][ci] = fmaf(v[px * 3 + co], k[((kh * 3 + kw) * 3 + ci) * 3 + co], acc[p][ci]);
+          }
+        }
+      }
+    }
+    float* op = out + ((img * H + h) * W + w0) * 3;
+    *reinterpret_cast<float4*>(op) = make_float4(acc[0][0], acc[0][1], acc[0][2], acc[1][0]);
+    *reinterpret_cast<float4*>(op + 4) = make_float4(acc[1][1], acc[1][2], acc[2][0], acc[2][1]);
+    *reinterpret_cast<float4*>(op + 8) = make_float4(acc[2][2], acc[3][0], acc[3][1], acc[3][2]);
+  }
+}
+
 // dx[b,h,w,ci] = sum_{kh,kw,co} dy[b,oh,ow,co] * w[kh,kw,ci,co],  oh*S - PAD + kh = h
 template <int CIN, int COUT, int STRIDE, int PAD>
 __global__ __launch_bounds__(256) void conv3x3_small_bwd_data_kernel(const float* __restrict__ dy,
@@ -471,6 +539,16 @@ static int conv_small_dispatch(int op, const float* a, const float* b, float* ou
       return spnet_reduce_rows(workspace, (int)parts, NW, out, (void*)st);
     }
     return (int)hipGetLastError();
+  }
+  if constexpr (CIN == 3 && COUT == 3 && STRIDE == 1 && PAD == 1) {
+    if (op < 2 && (W & 3) == 0 && !((((uintptr_t)a) | ((uintptr_t)out)) & 15)) {     // runs of four pixels (bit-identical)
+      const long total = (long)B * H * (W / 4);
+      if (op == 0)
+        hipLaunchKernelGGL(conv3x3_c3_run4_kernel<0>, dim3(spnet_ew_grid(total, 256)), dim3(256), 0, st, a, b, out, B, H, W);
+      else
+        hipLaunchKernelGGL(conv3x3_c3_run4_kernel<1>, dim3(spnet_ew_grid(total, 256)), dim3(256), 0, st, a, b, out, B, H, W);
+      return (int)hipGetLastError();
+    }
   }
   if (op == 0) {  // forward: a = x, b = w
     const long total = (long)B * OH * OW;

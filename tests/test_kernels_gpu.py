@@ -1070,7 +1070,7 @@ def test_avgpool(L, C):
                                                       (3, 32, 2, 0, 48, 64), (1, 3, 1, 1, 96, 128),
                                                       # widths that are multiples of 8: the 3 -> 3 weight gradient by pixel runs
                                                       (3, 3, 1, 1, 7, 8), (3, 3, 1, 1, 12, 32), (3, 3, 1, 1, 48, 64),
-                                                      (3, 3, 1, 1, 1, 16)])
+                                                      (3, 3, 1, 1, 1, 16), (3, 3, 1, 1, 5, 4), (3, 3, 1, 1, 192, 256)])
 def test_small_conv(L, cin, cout, stride, same, H, W):
     rs = np.random.RandomState(cin * cout + H)
     B = 2
@@ -1090,6 +1090,20 @@ def test_small_conv(L, cin, cout, stride, same, H, W):
     dwd = torch.empty_like(wd)
     L.spnet_conv3x3_small(2, cin, cout, stride, same, xd.data_ptr(), dyd.data_ptr(), dwd.data_ptr(), B, H, W, ws.data_ptr(), WS, st())
     close(dwd, w.grad, rtol=1e-4, atol=1e-4 * np.sqrt(B * H * W))
+    if cin == 3 and cout == 3 and W % 4 == 0:
+        # round 5: the runs-of-four-pixels kernels (aligned buffers) against the one-thread-per-pixel kernels the library
+        # falls back to when a buffer is only 4-byte aligned: the same fmaf chains, bit for bit
+        def off(t):
+            buf = torch.empty(t.numel() + 4, device="cuda")
+            v = buf[1:1 + t.numel()].view(t.shape)
+            v.copy_(t)
+            return buf, v
+        (_, xo), (_, dyo) = off(xd), off(dyd)
+        (_, yo), (_, dxo) = off(yd), off(dxd)
+        assert xo.data_ptr() % 16 == 4
+        L.spnet_conv3x3_small(0, cin, cout, stride, same, xo.data_ptr(), wd.data_ptr(), yo.data_ptr(), B, H, W, ws.data_ptr(), WS, st())
+        L.spnet_conv3x3_small(1, cin, cout, stride, same, dyo.data_ptr(), wd.data_ptr(), dxo.data_ptr(), B, H, W, ws.data_ptr(), WS, st())
+        assert torch.equal(yo, yd) and torch.equal(dxo, dxd)
 
 
 @pytest.mark.parametrize("B,H,W", [(2, 9, 40), (1, 33, 47), (3, 5, 34), (2, 40, 70)])
