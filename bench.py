@@ -152,12 +152,22 @@ def gemm_family_by_kernel(tim, steps):
     tot_n, tot_ms, tot_fl = tim.totals()["gemm"]
     rows, seen, taken = {}, [0, 0.0, 0.0], set()
     for kern, prefix, peak, what in GEMM_KERNELS:
+        alg_bytes = None
         if prefix is None:
             n, ms, fl = tot_n - seen[0], tot_ms - seen[1], tot_fl - seen[2]
         else:
             hit = [t for t in tim.tagged() if isinstance(t, tuple) and str(t[0]).startswith(prefix) and t not in taken]
             taken.update(hit)
             sel = [tim.tagged()[t] for t in hit]
+            # HBM bytes the launches have to move at the least (planes 6 B per operand element, fp32 results): what the
+            # PMC figure `traffic` is to be read against
+            if kern == "gemm_bf16x3_pp_kernel":
+                alg_bytes = sum(tim.tagged()[t][0] * (6.0 * (t[1] + t[2]) * t[3] + 4.0 * t[1] * t[2]) for t in hit)
+            elif kern == "gemm_bf16x3_wgrad_kernel":          # tag: (name "... xN batched", cin, cout, M)
+                nb = lambda t: int(str(t[0]).split(" x")[1].split()[0]) if " x" in str(t[0]) else 1
+                alg_bytes = sum(tim.tagged()[t][0] * nb(t) * (6.0 * t[3] * (t[1] + t[2]) + 4.0 * t[1] * t[2]) for t in hit)
+            else:
+                alg_bytes = None
             n, ms, fl = (sum(v[i] for v in sel) for i in range(3))
             seen = [seen[0] + n, seen[1] + ms, seen[2] + fl]
         if n <= 0:
@@ -167,6 +177,8 @@ def gemm_family_by_kernel(tim, steps):
                       "avg_launch_us": round(1e3 * ms / n, 2), "algorithmic_flops_per_launch": round(fl / n),
                       "achieved": round(tf, 1), "peak": round(peak, 1), "unit": "TFLOP/s" + (" (fp32-equivalent)" if prefix else ""),
                       "frac": round(tf / peak, 4)}
+        if alg_bytes:
+            rows[kern]["algorithmic_bytes_per_launch"] = round(alg_bytes / n)
     ideal_ms = sum(r["algorithmic_flops_per_launch"] * r["launches_per_step"] / (r["peak"] * 1e9) for r in rows.values())
     fam_ms = sum(r["ms_per_step"] for r in rows.values())
     # the dominant KERNEL: a single kernel, not the group row (a dozen gemm_f32_kernel<...> instantiations and the three
@@ -188,6 +200,7 @@ def gemm_roofline_block(tim, steps, traffic=None):
            "launches_per_step": d["launches_per_step"], "ms_per_step": d["ms_per_step"],
            "peak_note": "dense bf16 MFMA peak 2500 TFLOP/s / 6 MFMAs per fp32 product block" if dom.startswith("gemm_bf16x3") else
                         "fp32 MFMA peak (v_mfma_f32_*_f32 at the vector rate)",
+           "algorithmic_bytes_per_launch": d.get("algorithmic_bytes_per_launch"),
            "by_kernel": rows,
            "family": {"kernels": list(rows), "launches_per_step": g_n / steps, "ms_per_step": round(g_ms / steps, 3),
                       "frac_time_weighted": fam_frac,
@@ -1120,6 +1133,11 @@ def run(args):
             if dom in tr and roof_gemm["launches_per_step"] > 0:      # PMC bytes of that kernel per launch
                 roof_gemm["traffic"] = round((tr[dom]["hbm_read_bytes_per_step"] + tr[dom]["hbm_write_bytes_per_step"]) /
                                              roof_gemm["launches_per_step"])
+                if roof_gemm.get("algorithmic_bytes_per_launch"):
+                    roof_gemm["traffic_over_algorithmic"] = round(roof_gemm["traffic"] / roof_gemm["algorithmic_bytes_per_launch"], 3)
+                    roof_gemm["traffic_note"] = ("PMC bytes past the L2 per launch (FETCH_SIZE x 2 + WRITE_SIZE) against 6 B per operand "
+                                                 "element + 4 B per result: the eight XCDs each fetch the weight planes (3.2 MB) into "
+                                                 "their own L2, and Infinity-Cache hits count as fetches")
             if "gemm" in tr:
                 roof_gemm["family"]["traffic_per_launch"] = round(g_traffic)
             roof_dw = {"kernel": "dw3x3_{stream,tile}_fwd_kernel + dw3x3_{stream,tile}_bwd_kernel (34 depthwise layers, fwd + fused bwd: streaming form on the entry-flow planes, LDS-tiled form with the folded BatchNorm finalize on the 12x16 / 6x8 planes)",
