@@ -151,6 +151,11 @@ def test_bench_default_line_carries_every_block():
     assert roof["kernel"].startswith("gemm_bf16x3_") and abs(roof["peak"] - 416.7) < 0.1 and 0 < roof["frac"] < 1
     assert abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-3
     assert {"gemm_bf16x3_pp_kernel", "gemm_bf16x3_wgrad_kernel"} <= set(bk) and len(bk) >= 3
+    # the planes kernels carry the bytes they have to move per launch (what the PMC figure `traffic` is read against)
+    assert bk["gemm_bf16x3_pp_kernel"]["algorithmic_bytes_per_launch"] > 4e7
+    assert bk["gemm_bf16x3_wgrad_kernel"]["algorithmic_bytes_per_launch"] > 1e8
+    if roof["traffic"] is not None and roof.get("algorithmic_bytes_per_launch"):
+        assert 0.9 < roof["traffic_over_algorithmic"] < 3.0
     assert all(v["launches_per_step"] > 0 and v["ms_per_step"] > 0 and 0 < v["frac"] < 1 for v in bk.values())
     fam = roof["family"]
     assert 0 < fam["frac_time_weighted"] < 1 and "frac_vs_fp32_peak_legacy" in fam
