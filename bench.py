@@ -724,8 +724,18 @@ def bf16x3_alt_measure(dev, iters=200):
         torch.cuda.synchronize()
         return e0.elapsed_time(e1) * 1e3 / iters
 
+    # yardstick only (the product never calls the library): the vendor's bf16 GEMM executing the same number of bf16 MFMAs
+    # as one bf16x3 product -- [M][6K] x [N][6K]^T, fp32 accumulate (its operand bytes are twice the planes')
+    a6 = [torch.randn(M, 6 * K, device=dev, generator=g).to(torch.bfloat16) for _ in range(nb)]
+    w6 = (torch.randn(N, 6 * K, device=dev, generator=g) * 0.05).to(torch.bfloat16)
+    fv = lambda i: torch.mm(a6[i % nb], w6.t())
     split()
     tp, t3, t1, ts, tw = t(fp), t(f3), t(f1), t(split), t(fw)
+    try:
+        tv = t(fv)
+    except Exception:                    # (a library without a bf16 path: no yardstick)
+        tv = None
+    del a6, w6
     fp(0); f3(0); f1(0)
     ref = a[0].double() @ w.double()
     scale = a[0].double().norm(dim=1)[:, None] * w.double().norm(dim=0)[None, :]
@@ -740,6 +750,9 @@ def bf16x3_alt_measure(dev, iters=200):
             "peak_note": "dense bf16 MFMA peak %.0f TFLOP/s / 6 MFMAs per product block" % BF16_MFMA_PEAK_TFLOPS,
             "avg_launch_us": round(tp, 1), "fp32_a_split_in_kernel_us": round(t3, 1), "exact_fp32_kernel_us": round(t1, 1),
             "speedup_vs_exact": round(t1 / tp, 3), "bit_identical_to_fp32_a_kernel": same,
+            "vendor_bf16_gemm_same_mfma_work_us": None if tv is None else round(tv, 1),
+            "vendor_note": "torch.mm on bf16 [M][6K] x [N][6K]^T (hipBLASLt / rocBLAS, fp32 accumulate): the matrix work of this "
+                           "bf16x3 product done by the vendor's GEMM; a yardstick for `frac`, never on the product path",
             "wgrad_from_planes_us": round(tw / NW, 1), "wgrad_tflops_fp32_equivalent": round(NW * fl / tw / 1e6, 1),
             "wgrad_note": "per layer, %d layers of this shape per launch (gemm_bf16x3_wgrad_kernel)" % NW,
             "weight_split_us": round(ts, 1),
